@@ -1,0 +1,163 @@
+/*
+ * jpeg2png_amd — MI355X (gfx950) implementation of jpeg2png's deblocking solver.
+ *
+ * C-ABI of libjpeg2png_amd.so.  Plain pointers and sizes only; every function
+ * except j2p_last_error()/j2p_version() returns 0 on success and a negative
+ * J2P_E* code on failure (message via j2p_last_error()); nothing here ever
+ * calls exit().  Citations are into the reference tree (victorvde/jpeg2png).
+ *
+ * Two layers:
+ *
+ *  1. Drop-in layer (declared in jpeg2png_amd_compute.h, C host code):
+ *       void compute(unsigned nchannel, struct coef coefs[], struct logger *log,
+ *                    struct progressbar *pb, float weight, float pweight[],
+ *                    unsigned iterations);
+ *     same symbol, signature, ownership and callback behaviour as
+ *     compute.h:8 / compute.c:407-465, linked in place of compute.o.
+ *
+ *  2. Shim layer (this file): what that host code — or any other FFI (ctypes,
+ *     cgo, JNI) — binds.  A `j2p_solver` owns the device-resident working set of
+ *     ONE compute() call (the reference's `struct aux`, compute.c:21-34, for all
+ *     channels) on one GPU.  A solver may hold just a horizontal BAND of rows of
+ *     a taller plane (row tiling over several GPUs); the caller then exchanges
+ *     the band-edge rows and the per-row-of-tiles gradient norms between the two
+ *     phase calls of every iteration.
+ */
+#ifndef JPEG2PNG_AMD_H
+#define JPEG2PNG_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define J2P_OK          0
+#define J2P_EINVAL     -1   /* bad argument / precondition of compute() violated   */
+#define J2P_ENOMEM     -2   /* host or device allocation failed                    */
+#define J2P_EDEVICE    -3   /* HIP runtime error, no usable gfx950 device          */
+#define J2P_ESTATE     -4   /* call sequence error                                 */
+
+#define J2P_MAX_CHANNELS 3  /* ASSUME(nchannel <= 3), compute.c:118                */
+#define J2P_HALO_ROWS    2  /* TGV2 gradient reach in rows, compute.c:137-143,165-183 */
+#define J2P_TILE_ROWS   16  /* rows per gradient tile = granularity of the norm partials */
+
+/* One colour component as compute() receives it — the fields of `struct coef`
+ * (jpeg2png.h:7-20) that the solver reads.  All pointers are HOST pointers. */
+typedef struct j2p_plane {
+        unsigned w, h;              /* coefficient-plane size; multiples of 8 (box.c:6-7)   */
+        unsigned w_samp, h_samp;    /* max_samp / comp_samp (jpeg.c:57-58), >= 1            */
+        const int16_t *data;        /* quantised DCT coefficients, block-major
+                                       [h/8][w/8][64], natural order (jpeg.c:68-77)         */
+        const float *fdata;         /* decoded plane, row-major w*h (jpeg.c:83-92 +
+                                       jpeg2png.c:131-139); may be NULL: the library then
+                                       decodes `data` itself on the device                  */
+        const uint16_t *quant_table;/* 64 entries, natural order, all non-zero (jpeg.c:41-46) */
+} j2p_plane;
+
+/* Row band of the canvas this solver owns, in canvas rows.  {0,0} = whole canvas.
+ * row_begin/row_end must be multiples of lcm(8*h_samp) over channels and of
+ * J2P_TILE_ROWS so that no DCT block and no gradient tile straddles two GPUs. */
+typedef struct j2p_band {
+        unsigned row_begin, row_end;
+} j2p_band;
+
+typedef struct j2p_solver j2p_solver;
+
+/* per-iteration log row = arguments of logger_log() (logger.c:20, compute.c:271-272) */
+typedef struct j2p_log_row {
+        double objective, prob_dist, tv, tv2;
+} j2p_log_row;
+
+const char *j2p_version(void);
+const char *j2p_last_error(void);            /* thread-local */
+int j2p_device_count(int *count);
+
+/* aux_init (compute.c:278-310) on the device: uploads the planes (for a band:
+ * only the coefficient rows the band covers; `planes` always describes the
+ * WHOLE image, host arrays may be band-local when band_local_arrays != 0),
+ * allocates x_k, x_{k-1}, gradient, prob state, and sets x_k = x_{k-1} =
+ * replicate-upsample(fdata).  `iterations` fixes the step size
+ * radius/sqrtf(1+iterations) (compute.c:443).  `stream` is a hipStream_t
+ * (NULL = the solver creates its own). */
+int j2p_solver_create(j2p_solver **out, int device, void *stream,
+                      unsigned nchannel, const j2p_plane planes[],
+                      float weight, const float pweight[], unsigned iterations,
+                      j2p_band band, int band_local_arrays);
+void j2p_solver_destroy(j2p_solver *s);
+
+/* canvas geometry (compute.c:410-416) and band bookkeeping */
+int j2p_solver_canvas(const j2p_solver *s, unsigned *W, unsigned *H);
+int j2p_solver_band(const j2p_solver *s, unsigned *row_begin, unsigned *row_end);
+
+/* back to iteration 0 from the inputs that are already resident in HBM */
+int j2p_solver_reset(j2p_solver *s);
+
+/* The whole iteration loop (compute.c:427-453) for a solver that owns the whole
+ * canvas.  Runs `n` further iterations asynchronously on the solver's stream;
+ * if `rows` is non-NULL it receives n log rows (this synchronises at the end). */
+int j2p_solver_run(j2p_solver *s, unsigned n, j2p_log_row *rows);
+
+/* The same loop split at its two device-wide dependencies, for row-tiled runs.
+ *   phase_gradient : FISTA point (compute.c:430-440) + prob/TV/TGV2 gradient
+ *                    (compute.c:239-261) for the band; leaves one double per
+ *                    channel per row-of-tiles (sum of g*g) in the partials buffer.
+ *   [caller all-gathers the partials of all bands into norm_partials_all]
+ *   phase_project  : norm (compute.c:200-207, fixed summation order over the
+ *                    GLOBAL partial array => GPU-count invariant), step
+ *                    (:209-216), projection (:334-404), next prob state.
+ *   [caller sends the band's first/last J2P_HALO_ROWS rows of the new iterate
+ *    to the neighbouring bands' halo rows]
+ */
+int j2p_solver_phase_gradient(j2p_solver *s);
+int j2p_solver_phase_project(j2p_solver *s);
+
+/* Device addresses the caller needs for the exchanges (all on the solver's device).
+ *   partials_local : nchannel * local_tile_rows doubles written by phase_gradient
+ *   partials_all   : nchannel * global_tile_rows doubles read by phase_project;
+ *                    for a whole-canvas solver both are the same buffer. Layout
+ *                    [channel][tile_row].
+ *   halo addresses : for channel c, the rows of the CURRENT iterate x_k:
+ *                    send_top  = first J2P_HALO_ROWS own rows, recv_top = the halo
+ *                    rows above them (same for bottom); each J2P_HALO_ROWS*W floats. */
+typedef struct j2p_exchange {
+        double *partials_local;  unsigned local_tile_rows;
+        double *partials_all;    unsigned global_tile_rows; unsigned first_tile_row;
+        float *send_top[J2P_MAX_CHANNELS], *recv_top[J2P_MAX_CHANNELS];
+        float *send_bottom[J2P_MAX_CHANNELS], *recv_bottom[J2P_MAX_CHANNELS];
+        size_t halo_floats;
+} j2p_exchange;
+int j2p_solver_exchange_info(j2p_solver *s, j2p_exchange *info);
+
+/* band-local arrays only: after the caller has exchanged the halo rows of the INITIAL
+ * iterate, copy them into x_{k-1}'s halo rows too (fista = copy(fdata), compute.c:307-309) */
+int j2p_solver_commit_initial_halo(j2p_solver *s);
+
+/* copy channel c's band rows of the current iterate to host (W * band_rows floats);
+ * this is what compute() hands back in coef->fdata (compute.c:455-461) */
+int j2p_solver_download(j2p_solver *s, unsigned c, float *out);
+
+/* device pointer to channel c's current iterate (own rows), for on-device consumers */
+int j2p_solver_plane_ptr(j2p_solver *s, unsigned c, float **dev_ptr);
+
+int j2p_solver_sync(j2p_solver *s);
+
+/* average device time of the two phase kernels since the last reset, measured
+ * with HIP events on the solver's stream (bench.py's roofline leg) */
+int j2p_solver_kernel_times(j2p_solver *s, double *gradient_ms, double *project_ms, unsigned *samples);
+int j2p_solver_enable_timing(j2p_solver *s, int on);
+
+/* decode_coefficients + unbox (jpeg.c:83-92, box.c:5-19) on the device:
+ * out[h*w] raster floats from block-major int16 coefficients.  Host pointers. */
+int j2p_decode_plane(int device, unsigned w, unsigned h, const int16_t *data,
+                     const uint16_t *quant_table, float *out);
+
+/* 8x8 transforms on the device for n blocks of 64 floats, in place (host pointers);
+ * dct8x8s / idct8x8s of ooura/dct.c:98 / :34 — exposed for the parity tests */
+int j2p_dct8x8_blocks(int device, float *blocks, size_t n, int inverse);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,77 @@
+/*
+ * Drop-in layer of libjpeg2png_amd.so: the reference's solver entry point with
+ * the reference's own types, so that the library links in place of compute.o
+ * (reference Makefile:33) without touching jpeg2png.c.
+ *
+ * The three structs restate the reference's interface types field for field —
+ * `struct coef` jpeg2png.h:7-20, `struct logger` logger.h:6-11,
+ * `struct progressbar` progressbar.h:4-7 — because they cross the boundary by
+ * value/pointer.  When this header is included AFTER the reference's own
+ * headers (a build inside the reference tree) the guards below skip the
+ * re-definitions.
+ */
+#ifndef JPEG2PNG_AMD_COMPUTE_H
+#define JPEG2PNG_AMD_COMPUTE_H
+
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef JPEG2PNG_PROGRESSBAR_H
+#define JPEG2PNG_PROGRESSBAR_H
+struct progressbar {
+        unsigned current;
+        unsigned max;
+};
+void progressbar_inc(struct progressbar *pb);        /* progressbar.c:53-55; provided by the host program */
+#endif
+
+#ifndef JPEG2PNG_LOGGER_H
+#define JPEG2PNG_LOGGER_H
+struct logger {
+        FILE *f;
+        const char *filename;
+        unsigned channel;
+        unsigned iteration;
+};
+/* logger.c:20-28; provided by the host program */
+void logger_log(struct logger *log, double objective, double prob_dist, double tv, double tv2);
+#endif
+
+#ifndef JPEG2PNG_JPEG2PNG_H
+#define JPEG2PNG_JPEG2PNG_H
+struct coef {
+        unsigned h;
+        unsigned w;
+        unsigned h_samp;          /* vertical subsampling factor   */
+        unsigned w_samp;          /* horizontal subsampling factor */
+        int16_t *data;            /* DCT coefficients              */
+        float *fdata;             /* image data                    */
+        uint16_t quant_table[64];
+};
+#endif
+
+/* compute.h:8 / compute.c:407.  Same contract as the reference:
+ *  - frees the incoming coef->fdata (aligned_alloc'd, compute.c:304-305) and hands back a
+ *    new 16-byte aligned W*H plane in coef->fdata, rewriting coef->w/h to the canvas size
+ *    (compute.c:455-461);
+ *  - sets log->iteration and calls logger_log() once per iteration (compute.c:428,272),
+ *    progressbar_inc() once per iteration when pb != NULL (compute.c:449-452);
+ *  - re-entrant and thread-safe (callers: jpeg2png.c:144, :147-152 inside omp parallel);
+ *  - errors: prints "jpeg2png: <message>" to stderr and exit(EXIT_FAILURE), like die()
+ *    (utils.c:20-28).  There is NO CPU fallback: without a gfx950 device it dies.
+ * Device selection: environment variable J2P_DEVICE (default 0). */
+void compute(unsigned nchannel, struct coef coefs[], struct logger *log, struct progressbar *pb,
+             float weight, float pweight[], unsigned iterations);
+
+/* same, with an explicit device and an error code instead of exit(); 0 on success */
+int j2p_compute(int device, unsigned nchannel, struct coef coefs[], struct logger *log,
+                struct progressbar *pb, float weight, const float pweight[], unsigned iterations);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

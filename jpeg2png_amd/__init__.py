@@ -1,0 +1,247 @@
+"""jpeg2png_amd — MI355X (gfx950) implementation of jpeg2png's TV/TGV deblocking solver.
+
+Python here is only a ctypes binding of the C-ABI in include/jpeg2png_amd.h (used by
+tests/ and bench.py, and as the host-side mirror of the reference's compute()
+interface).  The product is libjpeg2png_amd.so: hand-written HIP kernels behind a
+plain-C shim plus a C `compute()` with the reference's own signature.
+
+There is NO CPU fallback: if the shared library is missing or no GPU is present the
+calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .synth import Plane  # noqa: F401  (re-export: the Python twin of struct coef)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjpeg2png_amd.so")
+
+J2P_MAX_CHANNELS = 3
+J2P_HALO_ROWS = 2
+J2P_TILE_ROWS = 16
+
+
+class J2PError(RuntimeError):
+    pass
+
+
+class _CPlane(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_uint), ("h", ctypes.c_uint),
+                ("w_samp", ctypes.c_uint), ("h_samp", ctypes.c_uint),
+                ("data", ctypes.c_void_p), ("fdata", ctypes.c_void_p),
+                ("quant_table", ctypes.c_void_p)]
+
+
+class _CBand(ctypes.Structure):
+    _fields_ = [("row_begin", ctypes.c_uint), ("row_end", ctypes.c_uint)]
+
+
+class _CLogRow(ctypes.Structure):
+    _fields_ = [("objective", ctypes.c_double), ("prob_dist", ctypes.c_double),
+                ("tv", ctypes.c_double), ("tv2", ctypes.c_double)]
+
+
+class _CExchange(ctypes.Structure):
+    _fields_ = [("partials_local", ctypes.c_void_p), ("local_tile_rows", ctypes.c_uint),
+                ("partials_all", ctypes.c_void_p), ("global_tile_rows", ctypes.c_uint),
+                ("first_tile_row", ctypes.c_uint),
+                ("send_top", ctypes.c_void_p * 3), ("recv_top", ctypes.c_void_p * 3),
+                ("send_bottom", ctypes.c_void_p * 3), ("recv_bottom", ctypes.c_void_p * 3),
+                ("halo_floats", ctypes.c_size_t)]
+
+
+# every symbol include/jpeg2png_amd.h and include/jpeg2png_amd_compute.h declare
+C_ABI_SYMBOLS = [
+    "j2p_version", "j2p_last_error", "j2p_device_count",
+    "j2p_solver_create", "j2p_solver_destroy", "j2p_solver_canvas", "j2p_solver_band",
+    "j2p_solver_reset", "j2p_solver_run", "j2p_solver_phase_gradient", "j2p_solver_phase_project",
+    "j2p_solver_exchange_info", "j2p_solver_commit_initial_halo", "j2p_solver_download",
+    "j2p_solver_plane_ptr", "j2p_solver_sync", "j2p_solver_kernel_times", "j2p_solver_enable_timing",
+    "j2p_decode_plane", "j2p_dct8x8_blocks",
+    "compute", "j2p_compute",
+]
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    from .build import build as _build
+    return _build(force=force, verbose=verbose)
+
+
+def load_library():
+    """dlopen libjpeg2png_amd.so; raises J2PError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise J2PError(f"{LIB_PATH} is missing: run `python -m jpeg2png_amd.build` "
+                       "(the HIP extension is the only implementation; there is no fallback)")
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    lib.j2p_version.restype = ctypes.c_char_p
+    lib.j2p_last_error.restype = ctypes.c_char_p
+    lib.j2p_solver_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_uint, ctypes.POINTER(_CPlane), ctypes.c_float,
+                                      ctypes.POINTER(ctypes.c_float), ctypes.c_uint, _CBand, ctypes.c_int]
+    lib.j2p_solver_destroy.argtypes = [ctypes.c_void_p]
+    lib.j2p_solver_destroy.restype = None
+    for name in ("j2p_solver_reset", "j2p_solver_phase_gradient", "j2p_solver_phase_project",
+                 "j2p_solver_sync", "j2p_solver_commit_initial_halo"):
+        getattr(lib, name).argtypes = [ctypes.c_void_p]
+    lib.j2p_solver_canvas.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
+    lib.j2p_solver_band.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
+    lib.j2p_solver_run.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.POINTER(_CLogRow)]
+    lib.j2p_solver_exchange_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(_CExchange)]
+    lib.j2p_solver_download.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p]
+    lib.j2p_solver_plane_ptr.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_void_p)]
+    lib.j2p_solver_kernel_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint)]
+    lib.j2p_solver_enable_timing.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.j2p_decode_plane.argtypes = [ctypes.c_int, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_void_p]
+    lib.j2p_dct8x8_blocks.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    lib.j2p_device_count.argtypes = [ctypes.POINTER(ctypes.c_int)]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise J2PError(f"jpeg2png_amd error {rc}: {load_library().j2p_last_error().decode()}")
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    _check(load_library().j2p_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def decode_plane(plane, device=0):
+    """decode_coefficients + unbox on the GPU (jpeg.c:83-92, box.c:5-19) -> float32 [h, w]."""
+    lib = load_library()
+    data = np.ascontiguousarray(plane.data, dtype=np.int16)
+    q = np.ascontiguousarray(plane.quant_table, dtype=np.uint16)
+    out = np.empty((plane.h, plane.w), dtype=np.float32)
+    _check(lib.j2p_decode_plane(device, plane.w, plane.h, data.ctypes.data, q.ctypes.data, out.ctypes.data))
+    return out
+
+
+def dct8x8_blocks(blocks, inverse=False, device=0):
+    """dct8x8s / idct8x8s (ooura/dct.c:98 / :34) of n blocks of 64 floats on the GPU."""
+    lib = load_library()
+    b = np.array(blocks, dtype=np.float32, order="C").reshape(-1, 64)
+    _check(lib.j2p_dct8x8_blocks(device, b.ctypes.data, b.shape[0], 1 if inverse else 0))
+    return b
+
+
+class Solver:
+    """Device-resident working set of one compute() call (include/jpeg2png_amd.h)."""
+
+    def __init__(self, planes, weight, pweight, iterations, device=0, stream=None, band=None,
+                 band_local_arrays=False):
+        lib = load_library()
+        self._lib = lib
+        self._h = None
+        self.nch = len(planes)
+        keep = []
+        cpl = (_CPlane * self.nch)()
+        for i, p in enumerate(planes):
+            d = np.ascontiguousarray(p.data, dtype=np.int16)
+            q = np.ascontiguousarray(p.quant_table, dtype=np.uint16)
+            f = None if p.fdata is None else np.ascontiguousarray(p.fdata, dtype=np.float32)
+            keep += [d, q, f]
+            cpl[i] = _CPlane(p.w, p.h, p.w_samp, p.h_samp, d.ctypes.data, None if f is None else f.ctypes.data,
+                             q.ctypes.data)
+        pw = (ctypes.c_float * self.nch)(*[float(x) for x in pweight])
+        b = _CBand(0, 0) if band is None else _CBand(int(band[0]), int(band[1]))
+        h = ctypes.c_void_p()
+        _check(lib.j2p_solver_create(ctypes.byref(h), device, stream, self.nch, cpl, float(weight), pw,
+                                     int(iterations), b, 1 if band_local_arrays else 0))
+        self._h = h
+        del keep
+        W, H = ctypes.c_uint(), ctypes.c_uint()
+        _check(lib.j2p_solver_canvas(h, ctypes.byref(W), ctypes.byref(H)))
+        self.W, self.H = W.value, H.value
+        r0, r1 = ctypes.c_uint(), ctypes.c_uint()
+        _check(lib.j2p_solver_band(h, ctypes.byref(r0), ctypes.byref(r1)))
+        self.row_begin, self.row_end = r0.value, r1.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.j2p_solver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def reset(self):
+        _check(self._lib.j2p_solver_reset(self._h))
+
+    def run(self, n, log=False):
+        """n iterations of the loop compute.c:427-453; returns [n,4] (objective, prob_dist, tv, tv2) if log."""
+        if not log:
+            _check(self._lib.j2p_solver_run(self._h, n, None))
+            return None
+        rows = (_CLogRow * max(n, 1))()
+        _check(self._lib.j2p_solver_run(self._h, n, rows))
+        return np.array([[r.objective, r.prob_dist, r.tv, r.tv2] for r in rows[:n]], dtype=np.float64).reshape(n, 4)
+
+    def phase_gradient(self):
+        _check(self._lib.j2p_solver_phase_gradient(self._h))
+
+    def phase_project(self):
+        _check(self._lib.j2p_solver_phase_project(self._h))
+
+    def commit_initial_halo(self):
+        _check(self._lib.j2p_solver_commit_initial_halo(self._h))
+
+    def exchange_info(self):
+        e = _CExchange()
+        _check(self._lib.j2p_solver_exchange_info(self._h, ctypes.byref(e)))
+        return e
+
+    def sync(self):
+        _check(self._lib.j2p_solver_sync(self._h))
+
+    def download(self, c):
+        out = np.empty((self.row_end - self.row_begin, self.W), dtype=np.float32)
+        _check(self._lib.j2p_solver_download(self._h, c, out.ctypes.data))
+        return out
+
+    def plane_ptr(self, c):
+        p = ctypes.c_void_p()
+        _check(self._lib.j2p_solver_plane_ptr(self._h, c, ctypes.byref(p)))
+        return p.value
+
+    def enable_timing(self, on=True):
+        _check(self._lib.j2p_solver_enable_timing(self._h, 1 if on else 0))
+
+    def kernel_times(self):
+        g, p, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint()
+        _check(self._lib.j2p_solver_kernel_times(self._h, ctypes.byref(g), ctypes.byref(p), ctypes.byref(n)))
+        return g.value, p.value, n.value
+
+
+def compute(planes, weight, pweight, iterations, log=False, device=0):
+    """Python twin of the reference's compute() (compute.h:8): same arguments and the same
+    in/out convention — on return every plane's `fdata` is the W x H canvas plane and its
+    w/h are rewritten to the canvas size (compute.c:455-461).  Returns the log rows when asked."""
+    for p in planes:
+        if p.fdata is None:
+            raise J2PError("compute() expects decoded planes in fdata (jpeg.c:83-92); use decode_plane()")
+    with Solver(planes, weight, pweight, iterations, device=device) as s:
+        rows = s.run(iterations, log=log)
+        outs = [s.download(c) for c in range(len(planes))]
+        W, H = s.W, s.H
+    for p, o in zip(planes, outs):
+        p.fdata = o
+        p.w, p.h = W, H
+    return rows

@@ -1,0 +1,65 @@
+"""Build libjpeg2png_amd.so (HIP kernels + C-ABI shim + C host drop-in) in-tree for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only container too.
+Device code is built with -ffp-contract=off and no fast-math: the solver has to
+reproduce the reference arithmetic operation for operation.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+LIB = os.path.join(HERE, "libjpeg2png_amd.so")
+
+HIP_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+    "-ffp-contract=off",            # no fused multiply-add: reference is built with -ffp-contract=off (Makefile:41-45)
+    "-fno-fast-math",
+    "-fhip-fp32-correctly-rounded-divide-sqrt",
+    "-fno-gpu-flush-denormals-to-zero",
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, f) for f in ("j2p_solver.hip", "j2p_kernels.hip.h", "compute_host.c")]
+    srcs += [os.path.join(INCLUDE, f) for f in ("jpeg2png_amd.h", "jpeg2png_amd_compute.h")]
+    srcs.append(os.path.abspath(__file__))
+    if not force and not _newer(LIB, srcs):
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    gcc = shutil.which("gcc") or "gcc"
+    obj = os.path.join(CSRC, "compute_host.o")
+    hobj = os.path.join(CSRC, "j2p_solver.o")
+    cmds = [
+        [gcc, "-std=c11", "-O2", "-fPIC", "-Wall", "-Wextra", "-ffp-contract=off", "-I", INCLUDE,
+         "-c", os.path.join(CSRC, "compute_host.c"), "-o", obj],
+        [hipcc, *HIP_FLAGS, "-I", INCLUDE, "-I", CSRC, "-c",
+         os.path.join(CSRC, "j2p_solver.hip"), "-o", hobj],
+        [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", hobj, obj, "-lpthread", "-o", LIB],
+    ]
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("build failed: " + " ".join(cmd))
+        if verbose and (r.stdout or r.stderr):
+            print(r.stdout + r.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,768 @@
+// jpeg2png_amd — C-ABI shim over the gfx950 kernels (include/jpeg2png_amd.h).
+//
+// A j2p_solver is the device-resident twin of the reference's per-call working
+// set (`struct aux` x nchannel, compute.c:21-34) plus the iteration scalars of
+// compute()/compute_step() (compute.c:425-443, :245, :258), which are evaluated
+// here on the host in float exactly as the reference does and handed to the
+// kernels as arguments.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "jpeg2png_amd.h"
+#include "j2p_kernels.hip.h"
+
+using namespace j2p;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+        va_list l;
+        va_start(l, fmt);
+        vsnprintf(g_err, sizeof(g_err), fmt, l);
+        va_end(l);
+        return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+        do {                                                                                       \
+                hipError_t e_ = (expr);                                                            \
+                if(e_ != hipSuccess) {                                                             \
+                        return fail(e_ == hipErrorOutOfMemory ? J2P_ENOMEM : J2P_EDEVICE,          \
+                                    "%s failed: %s", #expr, hipGetErrorString(e_));                \
+                }                                                                                  \
+        } while(0)
+
+struct ChanHost {
+        unsigned cw = 0, ch = 0, ws = 1, hs = 1;
+        unsigned crow0 = 0, crows = 0;       // coefficient rows of d / pg held on this device
+        unsigned frow0 = 0, frows = 0;       // coefficient rows of the decoded input held (init only)
+        float *xbuf[2] = {nullptr, nullptr}; // allocation bases, (rows + 2*halo) * W floats
+        float *grad = nullptr;
+        float *pg = nullptr;
+        int16_t *d = nullptr;
+        float *q = nullptr;
+        float *decoded = nullptr;            // frows * cw floats
+        float pweight = 0.f;
+};
+
+}  // namespace
+
+struct j2p_solver {
+        int device = 0;
+        hipStream_t stream = nullptr;
+        bool own_stream = false;
+        unsigned nch = 0;
+        unsigned W = 0, H = 0;
+        unsigned row0 = 0, rows = 0;
+        bool whole = true;
+        bool band_local = false;
+        ChanHost ch[kMaxCh];
+        float weight = 0.f;
+        unsigned iterations = 0;
+        // iteration state
+        unsigned iter = 0;
+        float t = 1.f;
+        float factor = 0.f;      // of the iteration whose gradient phase ran last
+        int cur = 0;             // xbuf[cur] is x_k
+        bool grad_done = false;
+        // reductions
+        unsigned ntx = 0, ntr_local = 0, ntr_global = 0, first_tr = 0;
+        double *part_g2 = nullptr;       // [c][ntr_local][ntx]
+        double *rowsum_local = nullptr;  // [c][ntr_local]
+        double *rowsum_all = nullptr;    // [c][ntr_global]  (== rowsum_local when whole)
+        float *norm = nullptr;           // [c]
+        // logging
+        double *part_tv = nullptr;       // [ntiles][2]
+        double *part_prob = nullptr;     // [c][strips]
+        unsigned strips_stride = 0;
+        double *logsums = nullptr;       // [iter chunk][2 + kMaxCh]
+        unsigned logsums_cap = 0;
+        double carried_prob[kMaxCh] = {0., 0., 0.};
+        bool carried_valid = true;
+        // timing
+        bool timing = false;
+        std::vector<hipEvent_t> ev;      // triples: before gradient, after gradient/before reduce.., see record()
+        size_t ev_used = 0;
+        double acc_grad_ms = 0., acc_proj_ms = 0.;
+        unsigned acc_samples = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+        int prev = -1;
+        bool ok = true;
+        explicit DeviceGuard(int dev)
+        {
+                if(hipGetDevice(&prev) != hipSuccess) { prev = -1; }
+                if(prev != dev) { ok = hipSetDevice(dev) == hipSuccess; }
+        }
+        ~DeviceGuard()
+        {
+                if(prev >= 0) { (void)hipSetDevice(prev); }
+        }
+};
+
+unsigned gcd_u(unsigned a, unsigned b) { return b ? gcd_u(b, a % b) : a; }
+unsigned lcm_u(unsigned a, unsigned b) { return a / gcd_u(a, b) * b; }
+
+ChanDev chan_dev(const j2p_solver *s, unsigned c)
+{
+        const ChanHost &h = s->ch[c];
+        ChanDev k;
+        const size_t halo = (size_t)kHalo * s->W;
+        k.xcur = h.xbuf[s->cur] + halo;
+        k.xprev = h.xbuf[s->cur ^ 1] + halo;
+        k.grad = h.grad;
+        k.pg = h.pg;
+        k.d = h.d;
+        k.q = h.q;
+        k.cw = h.cw;
+        k.ch = h.ch;
+        k.ws = h.ws;
+        k.hs = h.hs;
+        k.crow0 = h.crow0;
+        k.p_alpha = h.pweight * 2 * 255 * sqrtf(2);       // compute.c:245
+        k.prob_on = h.pweight != 0.f;
+        return k;
+}
+
+Geo geo_of(const j2p_solver *s)
+{
+        Geo g;
+        g.W = s->W;
+        g.H = s->H;
+        g.row0 = s->row0;
+        g.rows = s->rows;
+        g.ntx = s->ntx;
+        return g;
+}
+
+template <int NCH, bool TGV, bool LOG>
+void launch_gradient_t(const GradArgs &a, dim3 grid, hipStream_t st)
+{
+        constexpr size_t lds = gradient_lds_bytes<NCH, TGV>();
+        static bool attr_done = false;
+        if(!attr_done) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gradient<NCH, TGV, LOG>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_done = true;
+        }
+        hipLaunchKernelGGL((k_gradient<NCH, TGV, LOG>), grid, dim3(256), lds, st, a);
+}
+
+template <int NCH>
+void launch_gradient_n(const GradArgs &a, dim3 grid, hipStream_t st, bool tgv, bool log)
+{
+        if(tgv) {
+                if(log) { launch_gradient_t<NCH, true, true>(a, grid, st); }
+                else { launch_gradient_t<NCH, true, false>(a, grid, st); }
+        } else {
+                if(log) { launch_gradient_t<NCH, false, true>(a, grid, st); }
+                else { launch_gradient_t<NCH, false, false>(a, grid, st); }
+        }
+}
+
+hipEvent_t next_event(j2p_solver *s)
+{
+        if(s->ev_used == s->ev.size()) {
+                hipEvent_t e;
+                if(hipEventCreate(&e) != hipSuccess) { return nullptr; }
+                s->ev.push_back(e);
+        }
+        return s->ev[s->ev_used++];
+}
+
+void mark(j2p_solver *s)
+{
+        if(!s->timing) { return; }
+        hipEvent_t e = next_event(s);
+        if(e) { (void)hipEventRecord(e, s->stream); }
+}
+
+// fold recorded events (groups of 4: gradient begin/end, project begin/end) into the accumulators
+int flush_timing(j2p_solver *s)
+{
+        if(s->ev_used == 0) { return J2P_OK; }
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        for(size_t i = 0; i + 3 < s->ev_used; i += 4) {
+                float g = 0.f, p = 0.f;
+                HIP_TRY(hipEventElapsedTime(&g, s->ev[i], s->ev[i + 1]));
+                HIP_TRY(hipEventElapsedTime(&p, s->ev[i + 2], s->ev[i + 3]));
+                s->acc_grad_ms += g;
+                s->acc_proj_ms += p;
+                s->acc_samples++;
+        }
+        s->ev_used = 0;
+        return J2P_OK;
+}
+
+int do_phase_gradient(j2p_solver *s, bool log)
+{
+        if(s->grad_done) { return fail(J2P_ESTATE, "phase_gradient called twice without phase_project"); }
+        // FISTA scalars in float, as compute.c:431-432,440
+        const float tnext = (1 + sqrtf(1 + 4 * (s->t * s->t))) / 2;
+        s->factor = (s->t - 1) / tnext;
+        s->t = tnext;
+
+        GradArgs a;
+        for(unsigned c = 0; c < s->nch; c++) { a.ch[c] = chan_dev(s, c); }
+        a.geo = geo_of(s);
+        a.factor = s->factor;
+        a.a_tv = (float)(1. / (double)sqrtf((float)s->nch));                    // compute.c:90
+        const float alpha = s->weight / sqrtf((float)(4 / 2));                  // compute.c:258
+        a.a_tgv = (float)((double)alpha * 1. / (double)sqrtf((float)s->nch));   // compute.c:154
+        a.part_g2 = s->part_g2;
+        a.part_tv = s->part_tv;
+        const bool tgv = s->weight != 0.f;
+        dim3 grid(s->ntx, s->ntr_local);
+        mark(s);
+        switch(s->nch) {
+        case 1: launch_gradient_n<1>(a, grid, s->stream, tgv, log); break;
+        case 2: launch_gradient_n<2>(a, grid, s->stream, tgv, log); break;
+        default: launch_gradient_n<3>(a, grid, s->stream, tgv, log); break;
+        }
+        mark(s);
+        const unsigned nrs = s->ntr_local * s->nch;
+        hipLaunchKernelGGL(k_rowsums, dim3((nrs + 255) / 256), dim3(256), 0, s->stream,
+                           (const double *)s->part_g2, s->rowsum_local, s->ntx, s->ntr_local, s->nch);
+        HIP_TRY(hipGetLastError());
+        s->grad_done = true;
+        return J2P_OK;
+}
+
+int do_phase_project(j2p_solver *s, bool log)
+{
+        if(!s->grad_done) { return fail(J2P_ESTATE, "phase_project called before phase_gradient"); }
+        unsigned P = 1;
+        while(P < s->ntr_global) { P <<= 1; }
+        hipLaunchKernelGGL(k_norm_finish, dim3(s->nch), dim3(256), P * sizeof(double), s->stream,
+                           (const double *)s->rowsum_all, s->ntr_global, s->norm);
+        ProjArgs a;
+        unsigned max_strips = 0;
+        for(unsigned c = 0; c < s->nch; c++) {
+                a.ch[c] = chan_dev(s, c);
+                const ChanHost &h = s->ch[c];
+                const unsigned strips_x = (s->W + 64 * h.ws - 1) / (64 * h.ws);
+                const unsigned brows = (s->rows + 8 * h.hs - 1) / (8 * h.hs);
+                if(strips_x * brows > max_strips) { max_strips = strips_x * brows; }
+        }
+        a.geo = geo_of(s);
+        a.factor = s->factor;
+        const float radius = sqrtf((float)s->H * (float)s->W) / 2;             // compute.c:425
+        a.step = radius / sqrtf((float)(1 + s->iterations));                    // compute.c:443
+        a.norm = s->norm;
+        a.part_prob = s->part_prob;
+        a.strips_per_chan = s->strips_stride;
+        dim3 grid((max_strips + 3) / 4, 1, s->nch);
+        mark(s);
+        if(log) { hipLaunchKernelGGL((k_project<true>), grid, dim3(256), 0, s->stream, a); }
+        else { hipLaunchKernelGGL((k_project<false>), grid, dim3(256), 0, s->stream, a); }
+        mark(s);
+        HIP_TRY(hipGetLastError());
+        s->cur ^= 1;        // SWAP(fdata, fista) of compute.c:438: the buffer just written is x_{k+1}
+        s->iter++;
+        s->grad_done = false;
+        return J2P_OK;
+}
+
+int upload(void *dst, const void *src, size_t bytes, hipStream_t st)
+{
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+        return J2P_OK;
+}
+
+int launch_init(j2p_solver *s)
+{
+        for(unsigned c = 0; c < s->nch; c++) {
+                const ChanHost &h = s->ch[c];
+                ChanDev k = chan_dev(s, c);
+                k.crow0 = h.frow0;          // the decoded input has its own row window
+                const int fill_halo = s->band_local ? 0 : 1;
+                hipLaunchKernelGGL(k_init_state, dim3(2048), dim3(256), 0, s->stream, k, geo_of(s),
+                                   (const float *)h.decoded, fill_halo);
+                if(h.crows) {
+                        hipLaunchKernelGGL(k_fill_zero, dim3(1024), dim3(256), 0, s->stream, h.pg, (size_t)h.crows * h.cw);
+                }
+        }
+        HIP_TRY(hipGetLastError());
+        s->iter = 0;
+        s->t = 1.f;
+        s->cur = 0;
+        s->grad_done = false;
+        for(unsigned c = 0; c < kMaxCh; c++) { s->carried_prob[c] = 0.; }
+        s->carried_valid = true;
+        return J2P_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *j2p_version(void) { return "jpeg2png_amd 0.1 (gfx950)"; }
+const char *j2p_last_error(void) { return g_err; }
+
+int j2p_device_count(int *count)
+{
+        if(!count) { return fail(J2P_EINVAL, "count is NULL"); }
+        int n = 0;
+        if(hipGetDeviceCount(&n) != hipSuccess) { n = 0; }
+        *count = n;
+        return J2P_OK;
+}
+
+void j2p_solver_destroy(j2p_solver *s)
+{
+        if(!s) { return; }
+        DeviceGuard guard(s->device);
+        if(s->stream) { (void)hipStreamSynchronize(s->stream); }
+        for(unsigned c = 0; c < kMaxCh; c++) {
+                ChanHost &h = s->ch[c];
+                (void)hipFree(h.xbuf[0]);
+                (void)hipFree(h.xbuf[1]);
+                (void)hipFree(h.grad);
+                (void)hipFree(h.pg);
+                (void)hipFree(h.d);
+                (void)hipFree(h.q);
+                (void)hipFree(h.decoded);
+        }
+        (void)hipFree(s->part_g2);
+        (void)hipFree(s->rowsum_local);
+        if(s->rowsum_all != s->rowsum_local) { (void)hipFree(s->rowsum_all); }
+        (void)hipFree(s->norm);
+        (void)hipFree(s->part_tv);
+        (void)hipFree(s->part_prob);
+        (void)hipFree(s->logsums);
+        for(hipEvent_t e : s->ev) { (void)hipEventDestroy(e); }
+        if(s->own_stream && s->stream) { (void)hipStreamDestroy(s->stream); }
+        delete s;
+}
+
+int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchannel, const j2p_plane planes[],
+                      float weight, const float pweight[], unsigned iterations, j2p_band band, int band_local_arrays)
+{
+        if(!out || !planes || !pweight) { return fail(J2P_EINVAL, "NULL argument"); }
+        *out = nullptr;
+        if(nchannel == 0 || nchannel > kMaxCh) { return fail(J2P_EINVAL, "nchannel must be 1..3 (compute.c:118), got %u", nchannel); }
+        unsigned W = 0, H = 0, align = (unsigned)J2P_TILE_ROWS;
+        for(unsigned c = 0; c < nchannel; c++) {
+                const j2p_plane &p = planes[c];
+                if(p.w == 0 || p.h == 0 || (p.w & 7) || (p.h & 7)) {
+                        return fail(J2P_EINVAL, "channel %u: coefficient plane %ux%u is not a positive multiple of 8 (box.c:6-7)", c, p.w, p.h);
+                }
+                if(p.w_samp == 0 || p.h_samp == 0) { return fail(J2P_EINVAL, "channel %u: zero sampling factor", c); }
+                if(!p.data || !p.quant_table) { return fail(J2P_EINVAL, "channel %u: data/quant_table is NULL", c); }
+                for(int j = 0; j < 64; j++) {
+                        if(p.quant_table[j] == 0) { return fail(J2P_EINVAL, "channel %u: invalid quantization table (jpeg.c:41-45)", c); }
+                }
+                if(p.w * p.w_samp > W) { W = p.w * p.w_samp; }     // compute.c:410-416
+                if(p.h * p.h_samp > H) { H = p.h * p.h_samp; }
+                align = lcm_u(align, 8 * p.h_samp);
+        }
+        if(H > (unsigned)kMaxTileRows * kTY) { return fail(J2P_EINVAL, "canvas height %u exceeds %u", H, kMaxTileRows * kTY); }
+        bool whole = band.row_begin == 0 && (band.row_end == 0 || band.row_end >= H);
+        unsigned row0 = whole ? 0 : band.row_begin, row1 = whole ? H : band.row_end;
+        if(!whole) {
+                if(row0 >= row1 || row1 > H) { return fail(J2P_EINVAL, "bad band [%u,%u) for canvas height %u", row0, row1, H); }
+                if(row0 % align || (row1 % align && row1 != H)) {
+                        return fail(J2P_EINVAL, "band [%u,%u) must be aligned to %u rows", row0, row1, align);
+                }
+        }
+        int ndev = 0;
+        if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+                return fail(J2P_EDEVICE, "no HIP device available: the jpeg2png_amd solver has no CPU fallback");
+        }
+        if(device < 0 || device >= ndev) { return fail(J2P_EINVAL, "device %d out of range (0..%d)", device, ndev - 1); }
+        DeviceGuard guard(device);
+        if(!guard.ok) { return fail(J2P_EDEVICE, "hipSetDevice(%d) failed", device); }
+
+        j2p_solver *s = new(std::nothrow) j2p_solver();
+        if(!s) { return fail(J2P_ENOMEM, "host allocation failed"); }
+        s->device = device;
+        s->nch = nchannel;
+        s->W = W;
+        s->H = H;
+        s->row0 = row0;
+        s->rows = row1 - row0;
+        s->whole = whole;
+        s->band_local = !whole && band_local_arrays != 0;
+        s->weight = weight;
+        s->iterations = iterations;
+        int rc = J2P_OK;
+#define CREATE_TRY(expr)                                                                           \
+        do {                                                                                       \
+                hipError_t e_ = (expr);                                                            \
+                if(e_ != hipSuccess) {                                                             \
+                        rc = fail(e_ == hipErrorOutOfMemory ? J2P_ENOMEM : J2P_EDEVICE,            \
+                                  "%s failed: %s", #expr, hipGetErrorString(e_));                  \
+                        j2p_solver_destroy(s);                                                     \
+                        return rc;                                                                 \
+                }                                                                                  \
+        } while(0)
+        if(stream) { s->stream = (hipStream_t)stream; }
+        else {
+                CREATE_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+                s->own_stream = true;
+        }
+
+        const size_t plane_floats = (size_t)(s->rows + 2 * kHalo) * W;
+        for(unsigned c = 0; c < nchannel; c++) {
+                const j2p_plane &p = planes[c];
+                ChanHost &h = s->ch[c];
+                h.cw = p.w; h.ch = p.h; h.ws = p.w_samp; h.hs = p.h_samp;
+                h.pweight = pweight[c];
+                // coefficient rows of the band (block aligned because the band is)
+                unsigned c0 = row0 / h.hs, c1 = (row1 + h.hs - 1) / h.hs;
+                if(c0 > h.ch) { c0 = h.ch; }
+                if(c1 > h.ch) { c1 = h.ch; }
+                h.crow0 = c0;
+                h.crows = c1 - c0;
+                // rows of the decoded input the init kernel touches (own rows + halo, clamped like compute.c:298)
+                if(s->band_local) {
+                        if(h.ch * h.hs < H) {
+                                rc = fail(J2P_EINVAL, "band-local arrays need every channel to cover the canvas height");
+                                j2p_solver_destroy(s);
+                                return rc;
+                        }
+                        h.frow0 = h.crow0;
+                        h.frows = h.crows;
+                } else {
+                        const unsigned y0 = row0 >= (unsigned)kHalo ? row0 - kHalo : 0;
+                        const unsigned y1 = row1 + kHalo < H ? row1 + kHalo : H;
+                        unsigned f0 = y0 / h.hs, f1 = (y1 - 1) / h.hs + 1;
+                        if(f0 > h.ch - 1) { f0 = h.ch - 1; }
+                        if(f1 > h.ch) { f1 = h.ch; }
+                        if(f1 <= f0) { f1 = f0 + 1; }
+                        h.frow0 = f0;
+                        h.frows = f1 - f0;
+                }
+                CREATE_TRY(hipMalloc(&h.xbuf[0], plane_floats * sizeof(float)));
+                CREATE_TRY(hipMalloc(&h.xbuf[1], plane_floats * sizeof(float)));
+                CREATE_TRY(hipMalloc(&h.grad, (size_t)s->rows * W * sizeof(float)));
+                CREATE_TRY(hipMalloc(&h.q, 64 * sizeof(float)));
+                CREATE_TRY(hipMalloc(&h.decoded, (size_t)h.frows * h.cw * sizeof(float)));
+                if(h.crows) {
+                        CREATE_TRY(hipMalloc(&h.pg, (size_t)h.crows * h.cw * sizeof(float)));
+                        CREATE_TRY(hipMalloc(&h.d, (size_t)h.crows * h.cw * sizeof(int16_t)));
+                }
+                float qf[64];
+                for(int j = 0; j < 64; j++) { qf[j] = (float)p.quant_table[j]; }
+                CREATE_TRY(hipMemcpy(h.q, qf, sizeof(qf), hipMemcpyHostToDevice));
+                // host arrays: whole-image unless band_local
+                const size_t host_row0 = s->band_local ? h.crow0 : 0;
+                if(h.crows) {
+                        // block-major: coefficient row r lives in block row r/8; rows are block aligned
+                        const int16_t *src = p.data + (size_t)(h.crow0 - host_row0) * h.cw;
+                        CREATE_TRY(hipMemcpy(h.d, src, (size_t)h.crows * h.cw * sizeof(int16_t), hipMemcpyHostToDevice));
+                }
+                if(p.fdata) {
+                        const float *src = p.fdata + (size_t)(h.frow0 - host_row0) * h.cw;
+                        CREATE_TRY(hipMemcpy(h.decoded, src, (size_t)h.frows * h.cw * sizeof(float), hipMemcpyHostToDevice));
+                } else {
+                        // decode on the device (jpeg.c:83-92 + box.c:5-19); needs block-aligned row window
+                        const unsigned b0 = h.frow0 / 8, b1 = (h.frow0 + h.frows + 7) / 8;
+                        const size_t nb_rows = b1 - b0;
+                        int16_t *dtmp = nullptr;
+                        float *ftmp = nullptr;
+                        CREATE_TRY(hipMalloc(&dtmp, nb_rows * 8 * h.cw * sizeof(int16_t)));
+                        hipError_t e2 = hipMalloc(&ftmp, nb_rows * 8 * h.cw * sizeof(float));
+                        if(e2 != hipSuccess) { (void)hipFree(dtmp); CREATE_TRY(e2); }
+                        const int16_t *src = p.data + (size_t)(b0 * 8 - host_row0) * h.cw;
+                        hipError_t e3 = hipMemcpy(dtmp, src, nb_rows * 8 * h.cw * sizeof(int16_t), hipMemcpyHostToDevice);
+                        if(e3 == hipSuccess) {
+                                const unsigned groups = ((h.cw / 8 + 7) / 8) * (unsigned)nb_rows;
+                                hipLaunchKernelGGL(k_decode, dim3((groups + 3) / 4), dim3(256), 0, s->stream,
+                                                   (const int16_t *)dtmp, (const float *)h.q, ftmp, h.cw, (unsigned)nb_rows);
+                                e3 = hipMemcpyAsync(h.decoded, ftmp + (size_t)(h.frow0 - b0 * 8) * h.cw,
+                                                    (size_t)h.frows * h.cw * sizeof(float), hipMemcpyDeviceToDevice, s->stream);
+                                if(e3 == hipSuccess) { e3 = hipStreamSynchronize(s->stream); }
+                        }
+                        (void)hipFree(dtmp);
+                        (void)hipFree(ftmp);
+                        CREATE_TRY(e3);
+                }
+        }
+        // reductions: tile rows are counted on the canvas, the band owns a contiguous range
+        s->ntx = (W + kTX - 1) / kTX;
+        s->ntr_local = (s->rows + kTY - 1) / kTY;
+        s->ntr_global = (H + kTY - 1) / kTY;
+        s->first_tr = row0 / kTY;
+        const size_t ntiles = (size_t)s->ntx * s->ntr_local;
+        CREATE_TRY(hipMalloc(&s->part_g2, ntiles * nchannel * sizeof(double)));
+        CREATE_TRY(hipMalloc(&s->rowsum_local, (size_t)s->ntr_local * nchannel * sizeof(double)));
+        if(whole) { s->rowsum_all = s->rowsum_local; }
+        else { CREATE_TRY(hipMalloc(&s->rowsum_all, (size_t)s->ntr_global * nchannel * sizeof(double))); }
+        CREATE_TRY(hipMalloc(&s->norm, kMaxCh * sizeof(float)));
+        CREATE_TRY(hipMalloc(&s->part_tv, ntiles * 2 * sizeof(double)));
+        unsigned max_strips = 0;
+        for(unsigned c = 0; c < nchannel; c++) {
+                const ChanHost &h = s->ch[c];
+                const unsigned strips = ((W + 64 * h.ws - 1) / (64 * h.ws)) * ((s->rows + 8 * h.hs - 1) / (8 * h.hs));
+                if(strips > max_strips) { max_strips = strips; }
+        }
+        s->strips_stride = max_strips;
+        CREATE_TRY(hipMalloc(&s->part_prob, (size_t)max_strips * nchannel * sizeof(double)));
+        CREATE_TRY(hipMemset(s->part_prob, 0, (size_t)max_strips * nchannel * sizeof(double)));
+#undef CREATE_TRY
+        rc = launch_init(s);
+        if(rc != J2P_OK) { j2p_solver_destroy(s); return rc; }
+        *out = s;
+        return J2P_OK;
+}
+
+int j2p_solver_canvas(const j2p_solver *s, unsigned *W, unsigned *H)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        if(W) { *W = s->W; }
+        if(H) { *H = s->H; }
+        return J2P_OK;
+}
+
+int j2p_solver_band(const j2p_solver *s, unsigned *row_begin, unsigned *row_end)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        if(row_begin) { *row_begin = s->row0; }
+        if(row_end) { *row_end = s->row0 + s->rows; }
+        return J2P_OK;
+}
+
+int j2p_solver_reset(j2p_solver *s)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        DeviceGuard guard(s->device);
+        int rc = flush_timing(s);
+        if(rc != J2P_OK) { return rc; }
+        s->acc_grad_ms = s->acc_proj_ms = 0.;
+        s->acc_samples = 0;
+        return launch_init(s);
+}
+
+int j2p_solver_phase_gradient(j2p_solver *s)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        DeviceGuard guard(s->device);
+        return do_phase_gradient(s, false);
+}
+
+int j2p_solver_phase_project(j2p_solver *s)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        DeviceGuard guard(s->device);
+        return do_phase_project(s, false);
+}
+
+int j2p_solver_run(j2p_solver *s, unsigned n, j2p_log_row *rows)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        if(!s->whole) { return fail(J2P_ESTATE, "j2p_solver_run needs a whole-canvas solver; drive bands with the phase calls"); }
+        DeviceGuard guard(s->device);
+        const bool log = rows != nullptr;
+        constexpr unsigned kRow = 2 + kMaxCh;
+        if(log && s->logsums_cap < n) {
+                (void)hipFree(s->logsums);
+                s->logsums = nullptr;
+                s->logsums_cap = 0;
+                HIP_TRY(hipMalloc(&s->logsums, (size_t)n * kRow * sizeof(double)));
+                s->logsums_cap = n;
+        }
+        for(unsigned i = 0; i < n; i++) {
+                int rc = do_phase_gradient(s, log);
+                if(rc != J2P_OK) { return rc; }
+                if(log) {
+                        hipLaunchKernelGGL(k_log_sums, dim3(1), dim3(256), 0, s->stream, (const double *)s->part_tv,
+                                           s->ntx * s->ntr_local, (const double *)s->part_prob, 0u, s->strips_stride, s->nch,
+                                           s->logsums + (size_t)i * kRow, 0);
+                }
+                rc = do_phase_project(s, log);
+                if(rc != J2P_OK) { return rc; }
+                if(log) {
+                        hipLaunchKernelGGL(k_log_sums, dim3(1), dim3(256), 0, s->stream, (const double *)s->part_tv, 0u,
+                                           (const double *)s->part_prob, s->strips_stride, s->strips_stride, s->nch,
+                                           s->logsums + (size_t)i * kRow, 1);
+                }
+                if(s->timing && s->ev_used >= 4096) {
+                        rc = flush_timing(s);
+                        if(rc != J2P_OK) { return rc; }
+                }
+        }
+        HIP_TRY(hipGetLastError());
+        if(log) {
+                std::vector<double> host((size_t)n * kRow);
+                HIP_TRY(hipMemcpyAsync(host.data(), s->logsums, host.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+                HIP_TRY(hipStreamSynchronize(s->stream));
+                // compute.c:226-272: total_alpha in float, objective in double
+                float total_alpha = 0.f;
+                for(unsigned c = 0; c < s->nch; c++) {
+                        if(s->ch[c].pweight != 0.f) { total_alpha += s->ch[c].pweight * 2 * 255 * sqrtf(2); }
+                }
+                total_alpha += s->nch;
+                if(s->weight != 0.f) { total_alpha += (s->weight / sqrtf((float)(4 / 2))) * s->nch; }
+                for(unsigned i = 0; i < n; i++) {
+                        const double *h = &host[(size_t)i * kRow];
+                        double prob = 0.;
+                        for(unsigned c = 0; c < s->nch; c++) {
+                                if(s->ch[c].pweight != 0.f) { prob += 0.5 * s->carried_prob[c]; }   // compute_simd_step.c:61
+                        }
+                        if(!s->carried_valid) { prob = NAN; }
+                        rows[i].tv = h[0];
+                        rows[i].tv2 = s->weight != 0.f ? h[1] : 0.;
+                        rows[i].prob_dist = prob;
+                        rows[i].objective = (rows[i].tv + rows[i].tv2 + prob) / total_alpha;
+                        for(unsigned c = 0; c < s->nch; c++) { s->carried_prob[c] = h[2 + c]; }
+                        s->carried_valid = true;
+                }
+        } else if(n) {
+                s->carried_valid = false;
+        }
+        return J2P_OK;
+}
+
+int j2p_solver_exchange_info(j2p_solver *s, j2p_exchange *info)
+{
+        if(!s || !info) { return fail(J2P_EINVAL, "NULL argument"); }
+        memset(info, 0, sizeof(*info));
+        info->partials_local = s->rowsum_local;
+        info->local_tile_rows = s->ntr_local;
+        info->partials_all = s->rowsum_all;
+        info->global_tile_rows = s->ntr_global;
+        info->first_tile_row = s->first_tr;
+        info->halo_floats = (size_t)kHalo * s->W;
+        for(unsigned c = 0; c < s->nch; c++) {
+                float *base = s->ch[c].xbuf[s->cur];
+                info->recv_top[c] = base;
+                info->send_top[c] = base + (size_t)kHalo * s->W;
+                info->send_bottom[c] = base + (size_t)s->rows * s->W;
+                info->recv_bottom[c] = base + (size_t)(s->rows + kHalo) * s->W;
+        }
+        return J2P_OK;
+}
+
+int j2p_solver_commit_initial_halo(j2p_solver *s)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        if(s->iter != 0 || s->grad_done) { return fail(J2P_ESTATE, "initial halo can only be committed at iteration 0"); }
+        DeviceGuard guard(s->device);
+        const size_t hb = (size_t)kHalo * s->W * sizeof(float);
+        for(unsigned c = 0; c < s->nch; c++) {
+                float *cur = s->ch[c].xbuf[s->cur], *prev = s->ch[c].xbuf[s->cur ^ 1];
+                HIP_TRY(hipMemcpyAsync(prev, cur, hb, hipMemcpyDeviceToDevice, s->stream));
+                const size_t off = (size_t)(s->rows + kHalo) * s->W;
+                HIP_TRY(hipMemcpyAsync(prev + off, cur + off, hb, hipMemcpyDeviceToDevice, s->stream));
+        }
+        return J2P_OK;
+}
+
+int j2p_solver_download(j2p_solver *s, unsigned c, float *out)
+{
+        if(!s || !out) { return fail(J2P_EINVAL, "NULL argument"); }
+        if(c >= s->nch) { return fail(J2P_EINVAL, "channel %u out of range", c); }
+        if(s->grad_done) { return fail(J2P_ESTATE, "download between the two phases of an iteration"); }
+        DeviceGuard guard(s->device);
+        const float *src = s->ch[c].xbuf[s->cur] + (size_t)kHalo * s->W;
+        HIP_TRY(hipMemcpyAsync(out, src, (size_t)s->rows * s->W * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        return J2P_OK;
+}
+
+int j2p_solver_plane_ptr(j2p_solver *s, unsigned c, float **dev_ptr)
+{
+        if(!s || !dev_ptr) { return fail(J2P_EINVAL, "NULL argument"); }
+        if(c >= s->nch) { return fail(J2P_EINVAL, "channel %u out of range", c); }
+        *dev_ptr = s->ch[c].xbuf[s->cur] + (size_t)kHalo * s->W;
+        return J2P_OK;
+}
+
+int j2p_solver_sync(j2p_solver *s)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        DeviceGuard guard(s->device);
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        return J2P_OK;
+}
+
+int j2p_solver_enable_timing(j2p_solver *s, int on)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        DeviceGuard guard(s->device);
+        int rc = flush_timing(s);
+        s->timing = on != 0;
+        return rc;
+}
+
+int j2p_solver_kernel_times(j2p_solver *s, double *gradient_ms, double *project_ms, unsigned *samples)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        DeviceGuard guard(s->device);
+        int rc = flush_timing(s);
+        if(rc != J2P_OK) { return rc; }
+        const double n = s->acc_samples ? (double)s->acc_samples : 1.;
+        if(gradient_ms) { *gradient_ms = s->acc_grad_ms / n; }
+        if(project_ms) { *project_ms = s->acc_proj_ms / n; }
+        if(samples) { *samples = s->acc_samples; }
+        return J2P_OK;
+}
+
+int j2p_decode_plane(int device, unsigned w, unsigned h, const int16_t *data, const uint16_t *quant_table, float *out)
+{
+        if(!data || !quant_table || !out) { return fail(J2P_EINVAL, "NULL argument"); }
+        if(w == 0 || h == 0 || (w & 7) || (h & 7)) { return fail(J2P_EINVAL, "plane %ux%u is not a positive multiple of 8", w, h); }
+        int ndev = 0;
+        if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { return fail(J2P_EDEVICE, "no HIP device available"); }
+        DeviceGuard guard(device);
+        if(!guard.ok) { return fail(J2P_EDEVICE, "hipSetDevice(%d) failed", device); }
+        const size_t n = (size_t)w * h;
+        int16_t *dd = nullptr;
+        float *df = nullptr, *dq = nullptr;
+        float qf[64];
+        for(int j = 0; j < 64; j++) { qf[j] = (float)quant_table[j]; }
+        int rc = J2P_OK;
+        hipError_t e = hipMalloc(&dd, n * sizeof(int16_t));
+        if(e == hipSuccess) { e = hipMalloc(&df, n * sizeof(float)); }
+        if(e == hipSuccess) { e = hipMalloc(&dq, sizeof(qf)); }
+        if(e == hipSuccess) { e = hipMemcpy(dd, data, n * sizeof(int16_t), hipMemcpyHostToDevice); }
+        if(e == hipSuccess) { e = hipMemcpy(dq, qf, sizeof(qf), hipMemcpyHostToDevice); }
+        if(e == hipSuccess) {
+                const unsigned groups = ((w / 8 + 7) / 8) * (h / 8);
+                hipLaunchKernelGGL(k_decode, dim3((groups + 3) / 4), dim3(256), 0, nullptr, (const int16_t *)dd,
+                                   (const float *)dq, df, w, h / 8);
+                e = hipGetLastError();
+        }
+        if(e == hipSuccess) { e = hipMemcpy(out, df, n * sizeof(float), hipMemcpyDeviceToHost); }
+        if(e != hipSuccess) { rc = fail(e == hipErrorOutOfMemory ? J2P_ENOMEM : J2P_EDEVICE, "decode_plane: %s", hipGetErrorString(e)); }
+        (void)hipFree(dd);
+        (void)hipFree(df);
+        (void)hipFree(dq);
+        return rc;
+}
+
+int j2p_dct8x8_blocks(int device, float *blocks, size_t n, int inverse)
+{
+        if(!blocks) { return fail(J2P_EINVAL, "NULL argument"); }
+        if(n == 0) { return J2P_OK; }
+        int ndev = 0;
+        if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { return fail(J2P_EDEVICE, "no HIP device available"); }
+        DeviceGuard guard(device);
+        if(!guard.ok) { return fail(J2P_EDEVICE, "hipSetDevice(%d) failed", device); }
+        float *db = nullptr;
+        int rc = J2P_OK;
+        hipError_t e = hipMalloc(&db, n * 64 * sizeof(float));
+        if(e == hipSuccess) { e = hipMemcpy(db, blocks, n * 64 * sizeof(float), hipMemcpyHostToDevice); }
+        if(e == hipSuccess) {
+                hipLaunchKernelGGL(k_dct_blocks, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, nullptr, db, n, inverse);
+                e = hipGetLastError();
+        }
+        if(e == hipSuccess) { e = hipMemcpy(blocks, db, n * 64 * sizeof(float), hipMemcpyDeviceToHost); }
+        if(e != hipSuccess) { rc = fail(e == hipErrorOutOfMemory ? J2P_ENOMEM : J2P_EDEVICE, "dct8x8_blocks: %s", hipGetErrorString(e)); }
+        (void)hipFree(db);
+        return rc;
+}
+
+}  // extern "C"
