@@ -117,7 +117,7 @@ int j2p_solver_phase_project(j2p_solver *s);
  *   partials_local : nchannel * local_tile_rows doubles written by phase_gradient
  *   partials_all   : nchannel * global_tile_rows doubles read by phase_project;
  *                    for a whole-canvas solver both are the same buffer. Layout
- *                    [channel][tile_row].
+ *                    [tile_row][channel], so the bands of consecutive GPUs concatenate.
  *   halo addresses : for channel c, the rows of the CURRENT iterate x_k:
  *                    send_top  = first J2P_HALO_ROWS own rows, recv_top = the halo
  *                    rows above them (same for bottom); each J2P_HALO_ROWS*W floats. */
@@ -146,7 +146,7 @@ int j2p_solver_sync(j2p_solver *s);
 /* average device time of the two phase kernels since the last reset, measured
  * with HIP events on the solver's stream (bench.py's roofline leg) */
 int j2p_solver_kernel_times(j2p_solver *s, double *gradient_ms, double *project_ms, unsigned *samples);
-int j2p_solver_enable_timing(j2p_solver *s, int on);
+int j2p_solver_enable_timing(j2p_solver *s, int every);   /* 0 = off, k = sample every k-th iteration */
 
 /* decode_coefficients + unbox (jpeg.c:83-92, box.c:5-19) on the device:
  * out[h*w] raster floats from block-major int16 coefficients.  Host pointers. */

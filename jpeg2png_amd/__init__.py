@@ -221,8 +221,9 @@ class Solver:
         _check(self._lib.j2p_solver_plane_ptr(self._h, c, ctypes.byref(p)))
         return p.value
 
-    def enable_timing(self, on=True):
-        _check(self._lib.j2p_solver_enable_timing(self._h, 1 if on else 0))
+    def enable_timing(self, every=1):
+        """record HIP events around the two phase kernels of every `every`-th iteration (0 = off)."""
+        _check(self._lib.j2p_solver_enable_timing(self._h, int(every)))
 
     def kernel_times(self):
         g, p, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint()

@@ -369,13 +369,15 @@ constexpr size_t gradient_lds_bytes()
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rowsums(const double *part, double *rowsum, unsigned ntx, unsigned nrows_local, unsigned nch)
 {
-        // part: [c][local tile row][tile col] -> rowsum: [c][local tile row]
+        // part: [c][local tile row][tile col] -> rowsum: [local tile row][c]  (tile-row major, so that
+        // concatenating the bands of consecutive GPUs yields the global array)
         const unsigned i = blockIdx.x * 256 + threadIdx.x;
         if(i >= nrows_local * nch) { return; }
+        const unsigned c = i / nrows_local, r = i % nrows_local;
         const double *p = part + (size_t)i * ntx;
         double s = 0.;
         for(unsigned t = 0; t < ntx; t++) { s += p[t]; }
-        rowsum[i] = s;
+        rowsum[(size_t)r * nch + c] = s;
 }
 
 constexpr int kMaxTileRows = 4096;   // canvas height <= 65536 (JPEG limit) / kTY
@@ -393,14 +395,14 @@ __device__ __forceinline__ double tree_sum_lds(double *buf, unsigned n, unsigned
 }
 
 // one block per channel: norm[c] = sqrtf((float) sum)   (compute.c:200-207)
-__global__ __launch_bounds__(256) void k_norm_finish(const double *rowsum_all, unsigned nrows_global, float *norm)
+__global__ __launch_bounds__(256) void k_norm_finish(const double *rowsum_all, unsigned nrows_global, unsigned nch, float *norm)
 {
         extern __shared__ __attribute__((aligned(16))) float smem[];
         double *buf = reinterpret_cast<double *>(smem);
         unsigned P = 1;
         while(P < nrows_global) { P <<= 1; }
-        const double *src = rowsum_all + (size_t)blockIdx.x * nrows_global;
-        for(unsigned i = threadIdx.x; i < P; i += 256) { buf[i] = i < nrows_global ? src[i] : 0.; }
+        const double *src = rowsum_all + blockIdx.x;      // [tile row][c]
+        for(unsigned i = threadIdx.x; i < P; i += 256) { buf[i] = i < nrows_global ? src[(size_t)i * nch] : 0.; }
         const double s = tree_sum_lds(buf, nrows_global, P);
         if(threadIdx.x == 0) { norm[blockIdx.x] = sqrtf((float)s); }
 }

@@ -76,8 +76,8 @@ struct j2p_solver {
         // reductions
         unsigned ntx = 0, ntr_local = 0, ntr_global = 0, first_tr = 0;
         double *part_g2 = nullptr;       // [c][ntr_local][ntx]
-        double *rowsum_local = nullptr;  // [c][ntr_local]
-        double *rowsum_all = nullptr;    // [c][ntr_global]  (== rowsum_local when whole)
+        double *rowsum_local = nullptr;  // [ntr_local][c]
+        double *rowsum_all = nullptr;    // [ntr_global][c]  (== rowsum_local when whole)
         float *norm = nullptr;           // [c]
         // logging
         double *part_tv = nullptr;       // [ntiles][2]
@@ -88,7 +88,7 @@ struct j2p_solver {
         double carried_prob[kMaxCh] = {0., 0., 0.};
         bool carried_valid = true;
         // timing
-        bool timing = false;
+        unsigned timing = 0;     // 0 = off, k = time every k-th iteration
         std::vector<hipEvent_t> ev;      // triples: before gradient, after gradient/before reduce.., see record()
         size_t ev_used = 0;
         double acc_grad_ms = 0., acc_proj_ms = 0.;
@@ -183,7 +183,7 @@ hipEvent_t next_event(j2p_solver *s)
 
 void mark(j2p_solver *s)
 {
-        if(!s->timing) { return; }
+        if(!s->timing || s->iter % s->timing) { return; }
         hipEvent_t e = next_event(s);
         if(e) { (void)hipEventRecord(e, s->stream); }
 }
@@ -245,7 +245,7 @@ int do_phase_project(j2p_solver *s, bool log)
         unsigned P = 1;
         while(P < s->ntr_global) { P <<= 1; }
         hipLaunchKernelGGL(k_norm_finish, dim3(s->nch), dim3(256), P * sizeof(double), s->stream,
-                           (const double *)s->rowsum_all, s->ntr_global, s->norm);
+                           (const double *)s->rowsum_all, s->ntr_global, s->nch, s->norm);
         ProjArgs a;
         unsigned max_strips = 0;
         for(unsigned c = 0; c < s->nch; c++) {
@@ -540,8 +540,6 @@ int j2p_solver_reset(j2p_solver *s)
         DeviceGuard guard(s->device);
         int rc = flush_timing(s);
         if(rc != J2P_OK) { return rc; }
-        s->acc_grad_ms = s->acc_proj_ms = 0.;
-        s->acc_samples = 0;
         return launch_init(s);
 }
 
@@ -693,7 +691,9 @@ int j2p_solver_enable_timing(j2p_solver *s, int on)
         if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
         DeviceGuard guard(s->device);
         int rc = flush_timing(s);
-        s->timing = on != 0;
+        s->timing = on > 0 ? (unsigned)on : 0u;
+        s->acc_grad_ms = s->acc_proj_ms = 0.;
+        s->acc_samples = 0;
         return rc;
 }
 

@@ -1,0 +1,192 @@
+"""Row tiling of ONE plane set over several GPUs (BASELINE.json config 4).
+
+One process per GPU.  Each rank owns a contiguous band of canvas rows (a multiple
+of 8*h_samp and of the 16-row gradient tile, so no DCT block and no gradient tile
+straddles two GPUs) and runs the same two phase kernels as the single-GPU solver.
+Per iteration there are exactly two exchanges:
+
+  1. after phase_gradient: all-gather of one double per channel per row-of-tiles
+     (sum g*g).  Every rank then reduces the SAME global array in the SAME fixed
+     order inside phase_project, so ||g|| — and therefore the result — does not
+     depend on the number of GPUs;
+  2. after phase_project: the first/last 2 rows of the new iterate go to the
+     neighbouring bands' halo rows (TGV2 reaches 2 rows, compute.c:137-143,165-183;
+     x_{k-1}'s halo is already there from the previous iteration, so each rank
+     forms the FISTA point of its halo locally).  Grouped isend/irecv, no wrap-around.
+
+torch.distributed is plumbing only (backend "nccl" = RCCL over xGMI on the GPUs,
+"gloo" in the CPU tests); the arithmetic lives behind the `engine` object.  The
+production engine is HipBandEngine (the C-ABI solver, device memory aliased as
+torch tensors); tests drive the same exchange code with a CPU engine over gloo.
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import J2P_HALO_ROWS, J2P_TILE_ROWS, Solver
+
+
+def band_alignment(planes):
+    """rows a band boundary must be a multiple of: lcm(16, 8*h_samp of every channel)."""
+    import math
+    a = J2P_TILE_ROWS
+    for p in planes:
+        a = math.lcm(a, 8 * p.h_samp)
+    return a
+
+
+def split_rows(H, world, align):
+    """contiguous, aligned, near-equal bands [(row_begin, row_end)] covering [0, H)."""
+    units = (H + align - 1) // align
+    if units < world:
+        raise ValueError(f"canvas of {H} rows has only {units} bands of {align} rows for {world} ranks")
+    out, start = [], 0
+    for r in range(world):
+        n = units // world + (1 if r < units % world else 0)
+        end = min(H, (start + n) * align) if r < world - 1 else H
+        out.append((start * align, end))
+        start += n
+    return out
+
+
+class _DeviceArray:
+    """__cuda_array_interface__ view of raw device memory (no copy, no ownership)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def alias_tensor(ptr, n, dtype, device):
+    typestr = {torch.float32: "<f4", torch.float64: "<f8"}[dtype]
+    t = torch.as_tensor(_DeviceArray(ptr, n, typestr), device=device)
+    assert t.data_ptr() == int(ptr) and t.dtype == dtype
+    return t
+
+
+class HipBandEngine:
+    """The C-ABI band solver with its exchange buffers exposed as torch tensors."""
+
+    def __init__(self, planes, weight, pweight, iterations, band, device, band_local_arrays=True):
+        self.device = torch.device("cuda", device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.solver = Solver(planes, weight, pweight, iterations, device=device,
+                             stream=ctypes.c_void_p(self.stream.cuda_stream), band=band,
+                             band_local_arrays=band_local_arrays)
+        self.nch = self.solver.nch
+        e = self.solver.exchange_info()
+        self.local_tile_rows, self.global_tile_rows = e.local_tile_rows, e.global_tile_rows
+        self.first_tile_row = e.first_tile_row
+        self.partials_local = alias_tensor(e.partials_local, e.local_tile_rows * self.nch, torch.float64, self.device)
+        self.partials_all = alias_tensor(e.partials_all, e.global_tile_rows * self.nch, torch.float64, self.device)
+        self._halo = {}
+        self._parity = 0
+
+    def _views(self):
+        if self._parity not in self._halo:
+            e = self.solver.exchange_info()
+            n = e.halo_floats
+            mk = lambda p: alias_tensor(p, n, torch.float32, self.device)  # noqa: E731
+            self._halo[self._parity] = {k: [mk(getattr(e, k)[c]) for c in range(self.nch)]
+                                        for k in ("send_top", "recv_top", "send_bottom", "recv_bottom")}
+        return self._halo[self._parity]
+
+    def halo(self):
+        return self._views()
+
+    def stream_context(self):
+        """collectives order themselves against torch's CURRENT stream: make it the solver's"""
+        return torch.cuda.stream(self.stream)
+
+    def phase_gradient(self):
+        self.solver.phase_gradient()
+
+    def phase_project(self):
+        self.solver.phase_project()
+        self._parity ^= 1           # the iterate now lives in the other buffer
+
+    def commit_initial_halo(self):
+        self.solver.commit_initial_halo()
+
+    def reset(self):
+        self.solver.reset()
+        self._parity = 0
+
+    def download(self, c):
+        return self.solver.download(c)
+
+    def close(self):
+        self.solver.close()
+
+
+class RowTiledSolver:
+    """Drives one band engine per rank through the iteration loop (compute.c:427-453)."""
+
+    def __init__(self, engine, group=None):
+        self.e = engine
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.up = self.rank - 1 if self.rank > 0 else None
+        self.down = self.rank + 1 if self.rank < self.world - 1 else None
+        counts = torch.zeros(self.world, dtype=torch.int64)
+        counts[self.rank] = engine.local_tile_rows
+        counts = counts.to(engine.partials_local.device)
+        dist.all_reduce(counts, group=group)
+        self.counts = [int(x) for x in counts.cpu()]
+        self.equal = len(set(self.counts)) == 1
+        if not self.equal:
+            self._stage = torch.zeros(self.world * max(self.counts) * engine.nch, dtype=torch.float64,
+                                      device=engine.partials_local.device)
+            self._pad = torch.zeros(max(self.counts) * engine.nch, dtype=torch.float64,
+                                    device=engine.partials_local.device)
+
+    # -- exchanges ---------------------------------------------------------
+    def gather_partials(self):
+        e = self.e
+        if self.world == 1:
+            if e.partials_all.data_ptr() != e.partials_local.data_ptr():
+                e.partials_all.copy_(e.partials_local)
+            return
+        if self.equal:
+            dist.all_gather_into_tensor(e.partials_all, e.partials_local, group=self.group)
+            return
+        m = max(self.counts) * e.nch
+        self._pad.zero_()
+        self._pad[: e.partials_local.numel()] = e.partials_local
+        dist.all_gather_into_tensor(self._stage, self._pad, group=self.group)
+        off = 0
+        for r, n in enumerate(self.counts):
+            e.partials_all[off: off + n * e.nch] = self._stage[r * m: r * m + n * e.nch]
+            off += n * e.nch
+
+    def exchange_halo(self):
+        if self.world == 1:
+            return
+        h = self.e.halo()
+        ops = []
+        for c in range(self.e.nch):
+            if self.up is not None:
+                ops.append(dist.P2POp(dist.isend, h["send_top"][c], self.up, self.group))
+                ops.append(dist.P2POp(dist.irecv, h["recv_top"][c], self.up, self.group))
+            if self.down is not None:
+                ops.append(dist.P2POp(dist.isend, h["send_bottom"][c], self.down, self.group))
+                ops.append(dist.P2POp(dist.irecv, h["recv_bottom"][c], self.down, self.group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+    # -- loop --------------------------------------------------------------
+    def start(self):
+        """initial halo rows of x_0 (needed when every rank only uploaded its own band)."""
+        with self.e.stream_context():
+            self.exchange_halo()
+            self.e.commit_initial_halo()
+
+    def iterate(self, n):
+        with self.e.stream_context():
+            for _ in range(n):
+                self.e.phase_gradient()
+                self.gather_partials()
+                self.e.phase_project()
+                self.exchange_halo()

@@ -160,7 +160,7 @@ def test_band_split_matches_whole(lib, oracle):
             for dst in infos:
                 for src in infos:
                     n = src.local_tile_rows
-                    hip.hipMemcpy(dst.partials_all + 8 * src.first_tile_row, src.partials_local, 8 * n, D2D)
+                    hip.hipMemcpy(dst.partials_all + 8 * src.first_tile_row, src.partials_local, 8 * n, D2D)  # nch == 1
             for s in bands:
                 s.phase_project()
             for s in bands:
