@@ -54,12 +54,13 @@ def parse():
 
 
 def cpu_baseline(width, seed):
-    """time the reference solver on a bounded sample: same geometry class (Y-only, Q10, same
-    weights), 1024 rows x `width`, 12 iterations, 1 thread (joint/1-channel mode gains nothing
-    from OpenMP)."""
+    """time the reference solver on a bounded sample of the same workload: the same plane
+    (same seed, Y-only, Q10, same weights), 4096 rows x `width`, but 40 iterations instead of
+    500 (per-iteration cost is constant), 1 thread (1-channel/joint mode gains nothing from
+    OpenMP)."""
     from jpeg2png_amd import synth
     from oracle import bindings as ob
-    rows, its = 1024, 12
+    rows, its = 4096, 40
     planes = synth.make_planes(width, rows, "444", 10, seed=seed, y_only=True)
     for p in planes:
         p.fdata = ob.decode_plane(p)

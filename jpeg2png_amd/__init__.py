@@ -79,7 +79,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise J2PError(f"{LIB_PATH} is missing: run `python -m jpeg2png_amd.build` "
                        "(the HIP extension is the only implementation; there is no fallback)")
-    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    lib = ctypes.CDLL(LIB_PATH)   # RTLD_LOCAL: our `compute` must not interpose other libraries' symbols
     lib.j2p_version.restype = ctypes.c_char_p
     lib.j2p_last_error.restype = ctypes.c_char_p
     lib.j2p_solver_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p,

@@ -355,6 +355,325 @@ __global__ __launch_bounds__(256) void k_gradient(GradArgs a)
         }
 }
 
+
+// ---------------------------------------------------------------------------
+// Phase A, register-marching form (the one that ships).
+//
+// One wavefront owns a strip of 64*CPL consecutive columns (CPL columns per
+// lane) and walks down RPW rows.  Everything the gather needs from neighbouring
+// COLUMNS moves between lanes with DPP wave shifts; everything it needs from
+// neighbouring ROWS is carried in registers from one loop trip to the next:
+// no LDS, no barriers.  The two outermost columns on each side of the strip are
+// halo (loaded and differenced, never stored), so a strip yields 64*CPL-4 output
+// columns; likewise each strip recomputes the source terms of one row above and
+// below its RPW rows.
+//
+// Per loop trip (source row r, with y rows r-1, r, r+1 in registers):
+//   S_r  = per-pixel terms every neighbour will need from pixel (x,r):
+//          TV  : tvx=(a*gx)/n  tvy=(a*gy)/n  tvo=(a*-(gx+gy))/n       (compute.c:98-103)
+//          TGV2: A=a2*((s+gxx)/n2) B=a2*((gyy+s)/n2) C=a2*((-s)/n2)
+//                O=a2*(-(2gxx+2s+2gyy)/n2)                              (compute.c:165-182)
+//   then target row t=r-1 is complete:
+//          g = p_alpha*P  + S_{t-1}.tvy + S_t.tvx(x-1) + S_t.tvo
+//              + S_{t-1}.B + S_{t-1}.C(x+1) + S_t.A(x-1) + S_t.O + S_t.A(x+1)
+//              + S_{t+1}.C(x-1) + S_{t+1}.B          (the reference's raster order)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float lane_from_left(float v)    // value held by lane-1 (0 in lane 0)
+{
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_from_right(float v)   // value held by lane+1 (0 in lane 63)
+{
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+template <int CPL>
+struct Cols {
+        float v[CPL];
+};
+// column x-1 / x+1 of a per-lane group of CPL adjacent columns
+template <int CPL>
+__device__ __forceinline__ Cols<CPL> left_of(const Cols<CPL> &a)
+{
+        Cols<CPL> r;
+        r.v[0] = lane_from_left(a.v[CPL - 1]);
+#pragma unroll
+        for(int j = 1; j < CPL; j++) { r.v[j] = a.v[j - 1]; }
+        return r;
+}
+template <int CPL>
+__device__ __forceinline__ Cols<CPL> right_of(const Cols<CPL> &a)
+{
+        Cols<CPL> r;
+        r.v[CPL - 1] = lane_from_right(a.v[0]);
+#pragma unroll
+        for(int j = 0; j < CPL - 1; j++) { r.v[j] = a.v[j + 1]; }
+        return r;
+}
+
+constexpr int kRPW = 32;         // rows per wavefront strip (multiple of kTY)
+
+template <int NCH, bool TGV, bool LOG, int CPL>
+__global__ __launch_bounds__(256) void k_gradient_march(GradArgs a)
+{
+        constexpr int VALIDW = 64 * CPL - 4;
+        const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+        const int wcol = (int)blockIdx.x * 4 + wave;
+        if(wcol >= (int)a.geo.ntx) { return; }
+        const int W = (int)a.geo.W, H = (int)a.geo.H;
+        const int rows = (int)a.geo.rows, row0 = (int)a.geo.row0;
+        const int t0 = (int)blockIdx.y * kRPW;                 // band-local target rows [t0, t1)
+        const int t1 = t0 + kRPW < rows ? t0 + kRPW : rows;
+        const int xl = wcol * VALIDW - 2 + lane * CPL;         // canvas column of v[0]
+
+        bool col_in[CPL], col_own[CPL];
+#pragma unroll
+        for(int j = 0; j < CPL; j++) {
+                const int x = xl + j, rel = lane * CPL + j;
+                col_in[j] = x >= 0 && x < W;
+                col_own[j] = col_in[j] && rel >= 2 && rel < 64 * CPL - 2;
+        }
+
+        // FISTA point of one row for this lane's columns (compute.c:433-439); 0 outside the image
+        auto load_y = [&](int lr, Cols<CPL> (&y)[NCH]) {
+                const int gr = row0 + lr;
+                const bool rin = gr >= 0 && gr < H;
+#pragma unroll
+                for(int c = 0; c < NCH; c++) {
+                        const ptrdiff_t off = (ptrdiff_t)lr * W + xl;
+                        if(CPL == 2) {
+                                float2 xc = make_float2(0.f, 0.f), xp = make_float2(0.f, 0.f);
+                                if(rin && col_in[0]) {          // W and xl are even: the pair is in or out together
+                                        xc = *reinterpret_cast<const float2 *>(a.ch[c].xcur + off);
+                                        xp = *reinterpret_cast<const float2 *>(a.ch[c].xprev + off);
+                                }
+                                y[c].v[0] = xc.x + a.factor * (xc.x - xp.x);
+                                y[c].v[CPL - 1] = xc.y + a.factor * (xc.y - xp.y);
+                        } else {
+#pragma unroll
+                                for(int j = 0; j < CPL; j++) {
+                                        float xc = 0.f, xp = 0.f;
+                                        if(rin && col_in[j]) {
+                                                xc = a.ch[c].xcur[off + j];
+                                                xp = a.ch[c].xprev[off + j];
+                                        }
+                                        y[c].v[j] = xc + a.factor * (xc - xp);
+                                }
+                        }
+                }
+        };
+        // forward differences of row r given rows r and r+1 (compute.c:79,81)
+        auto diffs = [&](int gr, const Cols<CPL> (&yc)[NCH], const Cols<CPL> (&yn)[NCH], Cols<CPL> (&gx)[NCH], Cols<CPL> (&gy)[NCH]) {
+#pragma unroll
+                for(int c = 0; c < NCH; c++) {
+                        const Cols<CPL> yr = right_of<CPL>(yc[c]);
+#pragma unroll
+                        for(int j = 0; j < CPL; j++) {
+                                gx[c].v[j] = xl + j >= W - 1 ? 0.f : yr.v[j] - yc[c].v[j];
+                                gy[c].v[j] = gr >= H - 1 ? 0.f : yn[c].v[j] - yc[c].v[j];
+                        }
+                }
+        };
+
+        Cols<CPL> yc[NCH], yn[NCH], gxp[NCH], gyp[NCH];
+        {
+                Cols<CPL> ym[NCH];
+                load_y(t0 - 2, ym);
+                load_y(t0 - 1, yc);
+                load_y(t0, yn);
+                diffs(row0 + t0 - 2, ym, yc, gxp, gyp);
+        }
+        // carried source terms: row t (p1*) and the part of row t-1 the next target still needs (p2*)
+        Cols<CPL> p1_tvxL[NCH], p1_tvo[NCH], p1_tvy[NCH], p1_AL[NCH], p1_O[NCH], p1_AR[NCH], p1_B[NCH], p1_CR[NCH];
+        Cols<CPL> p2_tvy[NCH], p2_B[NCH], p2_CR[NCH];
+#pragma unroll
+        for(int c = 0; c < NCH; c++) {
+#pragma unroll
+                for(int j = 0; j < CPL; j++) {
+                        p1_tvxL[c].v[j] = p1_tvo[c].v[j] = p1_tvy[c].v[j] = 0.f;
+                        p1_AL[c].v[j] = p1_O[c].v[j] = p1_AR[c].v[j] = p1_B[c].v[j] = p1_CR[c].v[j] = 0.f;
+                        p2_tvy[c].v[j] = p2_B[c].v[j] = p2_CR[c].v[j] = 0.f;
+                }
+        }
+        double g2[NCH];
+#pragma unroll
+        for(int c = 0; c < NCH; c++) { g2[c] = 0.; }
+        double tv_acc = 0., tv2_acc = 0.;
+        const size_t ntiles_row = a.geo.ntx;
+        const size_t nparts = (size_t)((rows + kTY - 1) / kTY) * ntiles_row;
+
+#pragma unroll 1
+        for(int r = t0 - 1; r <= t1; r++) {
+                const int gr = row0 + r;
+                Cols<CPL> ynn[NCH];
+                load_y(r + 2 <= t1 + 1 ? r + 2 : -(int)kHalo - 1 - row0, ynn);   // prefetch for the next trip; past the
+                                                                                 // halo nothing is needed (maps to a row < 0)
+                // ---- source terms of row r ----
+                const bool rin = gr >= 0 && gr < H;
+                Cols<CPL> gx[NCH], gy[NCH];
+                diffs(gr, yc, yn, gx, gy);
+                Cols<CPL> n1;
+#pragma unroll
+                for(int j = 0; j < CPL; j++) {
+                        float n = 0.f;
+#pragma unroll
+                        for(int c = 0; c < NCH; c++) {
+                                n += gx[c].v[j] * gx[c].v[j];
+                                n += gy[c].v[j] * gy[c].v[j];
+                        }
+                        n1.v[j] = rin && col_in[j] ? sqrtf(n) : 0.f;
+                        if(LOG && col_own[j] && r >= t0 && r < t1) { tv_acc += (double)(a.a_tv * n1.v[j]); }
+                }
+                Cols<CPL> s_tvx[NCH], s_tvy[NCH], s_tvo[NCH];
+#pragma unroll
+                for(int c = 0; c < NCH; c++) {
+#pragma unroll
+                        for(int j = 0; j < CPL; j++) {
+                                const float n = n1.v[j];
+                                const bool nz = n != 0.f;
+                                s_tvx[c].v[j] = nz ? a.a_tv * gx[c].v[j] / n : 0.f;
+                                s_tvy[c].v[j] = nz ? a.a_tv * gy[c].v[j] / n : 0.f;
+                                s_tvo[c].v[j] = nz ? a.a_tv * -(gx[c].v[j] + gy[c].v[j]) / n : 0.f;
+                        }
+                }
+                Cols<CPL> s_A[NCH], s_B[NCH], s_C[NCH], s_O[NCH];
+                if(TGV) {
+                        Cols<CPL> xx[NCH], sy[NCH], yy[NCH];
+                        Cols<CPL> n2;
+#pragma unroll
+                        for(int j = 0; j < CPL; j++) { n2.v[j] = 0.f; }
+#pragma unroll
+                        for(int c = 0; c < NCH; c++) {
+                                const Cols<CPL> gxl = left_of<CPL>(gx[c]), gyl = left_of<CPL>(gy[c]);
+#pragma unroll
+                                for(int j = 0; j < CPL; j++) {
+                                        const bool x0 = xl + j == 0;
+                                        xx[c].v[j] = x0 ? 0.f : gx[c].v[j] - gxl.v[j];
+                                        const float gyx = x0 ? 0.f : gy[c].v[j] - gyl.v[j];
+                                        const float gxy = gr == 0 ? 0.f : gx[c].v[j] - gxp[c].v[j];
+                                        yy[c].v[j] = gr == 0 ? 0.f : gy[c].v[j] - gyp[c].v[j];
+                                        sy[c].v[j] = (gxy + gyx) / 2.f;
+                                        n2.v[j] += xx[c].v[j] * xx[c].v[j] + 2 * (sy[c].v[j] * sy[c].v[j]) + yy[c].v[j] * yy[c].v[j];
+                                }
+                        }
+#pragma unroll
+                        for(int j = 0; j < CPL; j++) {
+                                n2.v[j] = rin && col_in[j] ? sqrtf(n2.v[j]) : 0.f;
+                                if(LOG && col_own[j] && r >= t0 && r < t1) { tv2_acc += (double)(a.a_tgv * n2.v[j]); }
+                        }
+#pragma unroll
+                        for(int c = 0; c < NCH; c++) {
+#pragma unroll
+                                for(int j = 0; j < CPL; j++) {
+                                        const float n = n2.v[j];
+                                        const bool nz = n != 0.f;
+                                        s_A[c].v[j] = nz ? a.a_tgv * ((sy[c].v[j] + xx[c].v[j]) / n) : 0.f;
+                                        s_B[c].v[j] = nz ? a.a_tgv * ((yy[c].v[j] + sy[c].v[j]) / n) : 0.f;
+                                        s_C[c].v[j] = nz ? a.a_tgv * ((-sy[c].v[j]) / n) : 0.f;
+                                        s_O[c].v[j] = nz ? a.a_tgv * (-(2 * xx[c].v[j] + 2 * sy[c].v[j] + 2 * yy[c].v[j]) / n) : 0.f;
+                                }
+                        }
+                }
+                // ---- target row t = r-1 ----
+                const int t = r - 1;
+                if(t >= t0) {
+                        const int gt = row0 + t;
+#pragma unroll
+                        for(int c = 0; c < NCH; c++) {
+                                const ChanDev &k = a.ch[c];
+                                Cols<CPL> g;
+#pragma unroll
+                                for(int j = 0; j < CPL; j++) { g.v[j] = 0.f; }
+                                if(k.prob_on && (unsigned)gt < k.ch * k.hs) {
+                                        const size_t prow = (size_t)((unsigned)gt / k.hs - k.crow0) * k.cw;
+#pragma unroll
+                                        for(int j = 0; j < CPL; j++) {
+                                                const int x = xl + j;
+                                                if(col_own[j] && (unsigned)x < k.cw * k.ws) {
+                                                        g.v[j] += k.p_alpha * k.pg[prow + (unsigned)x / k.ws];
+                                                }
+                                        }
+                                }
+                                Cols<CPL> cL, aL_unused;
+                                (void)aL_unused;
+                                if(TGV) { cL = left_of<CPL>(s_C[c]); }
+#pragma unroll
+                                for(int j = 0; j < CPL; j++) {
+                                        float v = g.v[j];
+                                        v += p2_tvy[c].v[j];        // TV from (x, t-1)
+                                        v += p1_tvxL[c].v[j];       // TV from (x-1, t)
+                                        v += p1_tvo[c].v[j];        // TV own
+                                        if(TGV) {
+                                                v += p2_B[c].v[j];  // (x,   t-1)
+                                                v += p2_CR[c].v[j]; // (x+1, t-1)
+                                                v += p1_AL[c].v[j]; // (x-1, t)
+                                                v += p1_O[c].v[j];  // own
+                                                v += p1_AR[c].v[j]; // (x+1, t)
+                                                v += cL.v[j];       // (x-1, t+1)
+                                                v += s_B[c].v[j];   // (x,   t+1)
+                                        }
+                                        g.v[j] = v;
+                                        if(col_own[j]) { g2[c] += (double)(v * v); }    // compute.c:203
+                                }
+                                float *dst = k.grad + (size_t)t * W + xl;
+                                if(CPL == 2) {
+                                        if(col_own[0]) { *reinterpret_cast<float2 *>(dst) = make_float2(g.v[0], g.v[CPL - 1]); }
+                                } else {
+#pragma unroll
+                                        for(int j = 0; j < CPL; j++) {
+                                                if(col_own[j]) { dst[j] = g.v[j]; }
+                                        }
+                                }
+                        }
+                        // one partial per 16-row tile row and strip: the granularity of the GPU-count
+                        // invariant norm reduction
+                        if((t & (kTY - 1)) == kTY - 1 || t == t1 - 1) {
+#pragma unroll
+                                for(int c = 0; c < NCH; c++) {
+                                        double v = g2[c];
+#pragma unroll
+                                        for(int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); }
+                                        if(lane == 0) { a.part_g2[c * nparts + (size_t)(t / kTY) * ntiles_row + wcol] = v; }
+                                        g2[c] = 0.;
+                                }
+                        }
+                }
+                // ---- rotate the carried state ----
+#pragma unroll
+                for(int c = 0; c < NCH; c++) {
+                        p2_tvy[c] = p1_tvy[c];
+                        p1_tvy[c] = s_tvy[c];
+                        p1_tvxL[c] = left_of<CPL>(s_tvx[c]);
+                        p1_tvo[c] = s_tvo[c];
+                        if(TGV) {
+                                p2_B[c] = p1_B[c];
+                                p2_CR[c] = p1_CR[c];
+                                p1_B[c] = s_B[c];
+                                p1_CR[c] = right_of<CPL>(s_C[c]);
+                                p1_AL[c] = left_of<CPL>(s_A[c]);
+                                p1_AR[c] = right_of<CPL>(s_A[c]);
+                                p1_O[c] = s_O[c];
+                        }
+                        gxp[c] = gx[c];
+                        gyp[c] = gy[c];
+                        yc[c] = yn[c];
+                        yn[c] = ynn[c];
+                }
+        }
+        if(LOG) {
+#pragma unroll
+                for(int off = 32; off > 0; off >>= 1) {
+                        tv_acc += __shfl_down(tv_acc, off, 64);
+                        tv2_acc += __shfl_down(tv2_acc, off, 64);
+                }
+                if(lane == 0) {
+                        const size_t w = (size_t)blockIdx.y * ntiles_row + wcol;
+                        a.part_tv[2 * w] = tv_acc;
+                        a.part_tv[2 * w + 1] = tv2_acc;
+                }
+        }
+}
+
 template <int NCH, bool TGV>
 constexpr size_t gradient_lds_bytes()
 {

@@ -74,7 +74,7 @@ struct j2p_solver {
         int cur = 0;             // xbuf[cur] is x_k
         bool grad_done = false;
         // reductions
-        unsigned ntx = 0, ntr_local = 0, ntr_global = 0, first_tr = 0;
+        unsigned ntx = 0, nseg = 0, ntr_local = 0, ntr_global = 0, first_tr = 0;   // strips per row, row segments
         double *part_g2 = nullptr;       // [c][ntr_local][ntx]
         double *rowsum_local = nullptr;  // [ntr_local][c]
         double *rowsum_all = nullptr;    // [ntr_global][c]  (== rowsum_local when whole)
@@ -146,28 +146,18 @@ Geo geo_of(const j2p_solver *s)
         return g;
 }
 
-template <int NCH, bool TGV, bool LOG>
-void launch_gradient_t(const GradArgs &a, dim3 grid, hipStream_t st)
-{
-        constexpr size_t lds = gradient_lds_bytes<NCH, TGV>();
-        static bool attr_done = false;
-        if(!attr_done) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gradient<NCH, TGV, LOG>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr_done = true;
-        }
-        hipLaunchKernelGGL((k_gradient<NCH, TGV, LOG>), grid, dim3(256), lds, st, a);
-}
+constexpr int kCPL = 2;                       // columns per lane of the marching gradient kernel
+constexpr int kStripW = 64 * kCPL - 4;        // output columns per wavefront strip
 
 template <int NCH>
 void launch_gradient_n(const GradArgs &a, dim3 grid, hipStream_t st, bool tgv, bool log)
 {
         if(tgv) {
-                if(log) { launch_gradient_t<NCH, true, true>(a, grid, st); }
-                else { launch_gradient_t<NCH, true, false>(a, grid, st); }
+                if(log) { hipLaunchKernelGGL((k_gradient_march<NCH, true, true, kCPL>), grid, dim3(256), 0, st, a); }
+                else { hipLaunchKernelGGL((k_gradient_march<NCH, true, false, kCPL>), grid, dim3(256), 0, st, a); }
         } else {
-                if(log) { launch_gradient_t<NCH, false, true>(a, grid, st); }
-                else { launch_gradient_t<NCH, false, false>(a, grid, st); }
+                if(log) { hipLaunchKernelGGL((k_gradient_march<NCH, false, true, kCPL>), grid, dim3(256), 0, st, a); }
+                else { hipLaunchKernelGGL((k_gradient_march<NCH, false, false, kCPL>), grid, dim3(256), 0, st, a); }
         }
 }
 
@@ -223,7 +213,7 @@ int do_phase_gradient(j2p_solver *s, bool log)
         a.part_g2 = s->part_g2;
         a.part_tv = s->part_tv;
         const bool tgv = s->weight != 0.f;
-        dim3 grid(s->ntx, s->ntr_local);
+        dim3 grid((s->ntx + 3) / 4, s->nseg);
         mark(s);
         switch(s->nch) {
         case 1: launch_gradient_n<1>(a, grid, s->stream, tgv, log); break;
@@ -491,7 +481,8 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 }
         }
         // reductions: tile rows are counted on the canvas, the band owns a contiguous range
-        s->ntx = (W + kTX - 1) / kTX;
+        s->ntx = (W + kStripW - 1) / kStripW;
+        s->nseg = (s->rows + kRPW - 1) / kRPW;
         s->ntr_local = (s->rows + kTY - 1) / kTY;
         s->ntr_global = (H + kTY - 1) / kTY;
         s->first_tr = row0 / kTY;
@@ -576,7 +567,7 @@ int j2p_solver_run(j2p_solver *s, unsigned n, j2p_log_row *rows)
                 if(rc != J2P_OK) { return rc; }
                 if(log) {
                         hipLaunchKernelGGL(k_log_sums, dim3(1), dim3(256), 0, s->stream, (const double *)s->part_tv,
-                                           s->ntx * s->ntr_local, (const double *)s->part_prob, 0u, s->strips_stride, s->nch,
+                                           s->ntx * s->nseg, (const double *)s->part_prob, 0u, s->strips_stride, s->nch,
                                            s->logsums + (size_t)i * kRow, 0);
                 }
                 rc = do_phase_project(s, log);
