@@ -157,6 +157,12 @@ int j2p_decode_plane(int device, unsigned w, unsigned h, const int16_t *data,
  * dct8x8s / idct8x8s of ooura/dct.c:98 / :34 — exposed for the parity tests */
 int j2p_dct8x8_blocks(int device, float *blocks, size_t n, int inverse);
 
+/* test hook: compares the kernels' fast division / square root (the compiler's IEEE
+ * sequences without range scaling) with `/` and sqrtf() on n pseudo-random operand pairs
+ * inside the range the kernels screen for; both counters must come back 0 */
+int j2p_math_selftest(int device, size_t n, unsigned seed, unsigned long long *div_mismatches,
+                      unsigned long long *sqrt_mismatches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,7 +59,7 @@ C_ABI_SYMBOLS = [
     "j2p_solver_reset", "j2p_solver_run", "j2p_solver_phase_gradient", "j2p_solver_phase_project",
     "j2p_solver_exchange_info", "j2p_solver_commit_initial_halo", "j2p_solver_download",
     "j2p_solver_plane_ptr", "j2p_solver_sync", "j2p_solver_kernel_times", "j2p_solver_enable_timing",
-    "j2p_decode_plane", "j2p_dct8x8_blocks",
+    "j2p_decode_plane", "j2p_dct8x8_blocks", "j2p_math_selftest",
     "compute", "j2p_compute",
 ]
 
@@ -103,6 +103,8 @@ def load_library():
                                      ctypes.c_void_p, ctypes.c_void_p]
     lib.j2p_dct8x8_blocks.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     lib.j2p_device_count.argtypes = [ctypes.POINTER(ctypes.c_int)]
+    lib.j2p_math_selftest.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_uint,
+                                      ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
     _lib = lib
     return lib
 
@@ -134,6 +136,13 @@ def dct8x8_blocks(blocks, inverse=False, device=0):
     b = np.array(blocks, dtype=np.float32, order="C").reshape(-1, 64)
     _check(lib.j2p_dct8x8_blocks(device, b.ctypes.data, b.shape[0], 1 if inverse else 0))
     return b
+
+
+def math_selftest(n, seed=1, device=0):
+    """(division mismatches, sqrt mismatches) of the fast paths vs IEEE on n random operand pairs."""
+    d, q = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+    _check(load_library().j2p_math_selftest(device, n, seed, ctypes.byref(d), ctypes.byref(q)))
+    return d.value, q.value
 
 
 class Solver:

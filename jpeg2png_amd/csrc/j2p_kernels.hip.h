@@ -24,6 +24,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace j2p {
 
@@ -176,10 +177,8 @@ struct ProjArgs {
         unsigned strips_per_chan;   // stride of part_prob
 };
 
-// gradient tile
-constexpr int kTX = 64, kTY = 16;
-constexpr int kYW = kTX + 2 * kHalo, kYH = kTY + 2 * kHalo;   // 68 x 20 pixels of y
-constexpr int kSW = kTX + 2, kSH = kTY + 2;                   // 66 x 18 sources
+// rows per norm partial: the granularity of the GPU-count invariant reduction (J2P_TILE_ROWS)
+constexpr int kTY = 16;
 
 // deterministic block-wide sum of one double per thread (256 threads); result valid in thread 0
 __device__ __forceinline__ double block_sum(double v, double *red /* >= 4 doubles */)
@@ -194,179 +193,16 @@ __device__ __forceinline__ double block_sum(double v, double *red /* >= 4 double
 }
 
 // ---------------------------------------------------------------------------
-// Phase A: gradient
-// ---------------------------------------------------------------------------
-template <int NCH, bool TGV, bool LOG>
-__global__ __launch_bounds__(256) void k_gradient(GradArgs a)
-{
-        extern __shared__ __attribute__((aligned(16))) float smem[];
-        float *Y = smem;                                   // [NCH][kYH][kYW]
-        float *N1 = Y + NCH * kYH * kYW;                   // [kSH][kSW]
-        float *TG = N1 + kSH * kSW;                        // [NCH][4][kSH][kSW]  (TGV only)
-        double *red = reinterpret_cast<double *>(TG + (TGV ? NCH * 4 * kSH * kSW : 0)) ;
-
-        const int W = (int)a.geo.W, H = (int)a.geo.H;
-        const int tx0 = (int)blockIdx.x * kTX;
-        const int ty0 = (int)blockIdx.y * kTY;             // band-local
-        const int gy0 = (int)a.geo.row0 + ty0;             // canvas row of tile row 0
-        const int tid = (int)threadIdx.x;
-
-        // ---- stage 1: FISTA point for tile + halo (compute.c:433-439) ----
-        for(int i = tid; i < kYH * kYW; i += 256) {
-                const int lx = i % kYW - kHalo, ly = i / kYW - kHalo;
-                const int gx = tx0 + lx, gy = gy0 + ly;
-                const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
-                const ptrdiff_t off = (ptrdiff_t)(ty0 + ly) * W + gx;
-#pragma unroll
-                for(int c = 0; c < NCH; c++) {
-                        float y = 0.f;
-                        if(in) {
-                                const float xc = a.ch[c].xcur[off], xp = a.ch[c].xprev[off];
-                                y = xc + a.factor * (xc - xp);
-                        }
-                        Y[c * kYH * kYW + i] = y;
-                }
-        }
-        __syncthreads();
-
-        auto yat = [&](int c, int lx, int ly) -> float {
-                return Y[c * kYH * kYW + (ly + kHalo) * kYW + lx + kHalo];
-        };
-        // forward differences with the reference's border rule (compute.c:79,81)
-        auto dxf = [&](int c, int lx, int ly) -> float {
-                return tx0 + lx >= W - 1 ? 0.f : yat(c, lx + 1, ly) - yat(c, lx, ly);
-        };
-        auto dyf = [&](int c, int lx, int ly) -> float {
-                return gy0 + ly >= H - 1 ? 0.f : yat(c, lx, ly + 1) - yat(c, lx, ly);
-        };
-
-        // ---- stage 2: per-source norms and TGV2 terms for tile + 1-pixel ring ----
-        double tv_acc = 0., tv2_acc = 0.;
-        for(int i = tid; i < kSH * kSW; i += 256) {
-                const int lx = i % kSW - 1, ly = i / kSW - 1;
-                const int gx = tx0 + lx, gy = gy0 + ly;
-                const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
-                const bool own = lx >= 0 && lx < kTX && ly >= 0 && ly < kTY;
-                float n1 = 0.f;
-                if(in) {
-#pragma unroll
-                        for(int c = 0; c < NCH; c++) {
-                                const float gxv = dxf(c, lx, ly), gyv = dyf(c, lx, ly);
-                                n1 += gxv * gxv;
-                                n1 += gyv * gyv;
-                        }
-                        n1 = sqrtf(n1);
-                        if(LOG && own) { tv_acc += (double)(a.a_tv * n1); }
-                }
-                N1[i] = n1;
-                if(TGV) {
-                        float xx[NCH], sy[NCH], yy[NCH];
-                        float n2 = 0.f;
-                        if(in) {
-#pragma unroll
-                                for(int c = 0; c < NCH; c++) {
-                                        // backward differences of the forward differences (compute.c:136-146)
-                                        const float gxv = dxf(c, lx, ly), gyv = dyf(c, lx, ly);
-                                        xx[c] = gx == 0 ? 0.f : gxv - dxf(c, lx - 1, ly);
-                                        const float gyx = gx == 0 ? 0.f : gyv - dyf(c, lx - 1, ly);
-                                        const float gxy = gy == 0 ? 0.f : gxv - dxf(c, lx, ly - 1);
-                                        yy[c] = gy == 0 ? 0.f : gyv - dyf(c, lx, ly - 1);
-                                        sy[c] = (gxy + gyx) / 2.f;
-                                        n2 += xx[c] * xx[c] + 2 * (sy[c] * sy[c]) + yy[c] * yy[c];
-                                }
-                                n2 = sqrtf(n2);
-                                if(LOG && own) { tv2_acc += (double)(a.a_tgv * n2); }
-                        }
-#pragma unroll
-                        for(int c = 0; c < NCH; c++) {
-                                float tA = 0.f, tB = 0.f, tC = 0.f, tO = 0.f;
-                                if(in && n2 != 0.f) {
-                                        // compute.c:165-183: a2 * (expr / n2), division first
-                                        tA = a.a_tgv * ((sy[c] + xx[c]) / n2);                    // to (x-1,y), (x+1,y)
-                                        tB = a.a_tgv * ((yy[c] + sy[c]) / n2);                    // to (x,y-1), (x,y+1)
-                                        tC = a.a_tgv * ((-sy[c]) / n2);                           // to (x+1,y-1), (x-1,y+1)
-                                        tO = a.a_tgv * (-(2 * xx[c] + 2 * sy[c] + 2 * yy[c]) / n2); // own
-                                }
-                                float *t = TG + (c * 4) * kSH * kSW + i;
-                                t[0] = tA;
-                                t[kSH * kSW] = tB;
-                                t[2 * kSH * kSW] = tC;
-                                t[3 * kSH * kSW] = tO;
-                        }
-                }
-        }
-        __syncthreads();
-
-        // ---- stage 3: gather per target pixel, raster order of the sources ----
-        double g2[NCH];
-#pragma unroll
-        for(int c = 0; c < NCH; c++) { g2[c] = 0.; }
-        const int lx = tid & 63;
-        const int gx = tx0 + lx;
-#pragma unroll
-        for(int r = 0; r < kTY / 4; r++) {
-                const int ly = (tid >> 6) + 4 * r;
-                const int gy = gy0 + ly;
-                if(gx < W && gy < H && ty0 + ly < (int)a.geo.rows) {
-                        const int si = (ly + 1) * kSW + lx + 1;      // own source slot
-                        const float nU = N1[si - kSW], nL = N1[si - 1], nO = N1[si];
-#pragma unroll
-                        for(int c = 0; c < NCH; c++) {
-                                const ChanDev &k = a.ch[c];
-                                float g = 0.f;
-                                if(k.prob_on && (unsigned)gx < k.cw * k.ws && (unsigned)gy < k.ch * k.hs) {
-                                        const unsigned cy = (unsigned)gy / k.hs - k.crow0, cx = (unsigned)gx / k.ws;
-                                        g += k.p_alpha * k.pg[(size_t)cy * k.cw + cx];
-                                }
-                                // TV (compute.c:97-104): (a*v)/n
-                                if(nU != 0.f) { g += a.a_tv * dyf(c, lx, ly - 1) / nU; }
-                                if(nL != 0.f) { g += a.a_tv * dxf(c, lx - 1, ly) / nL; }
-                                if(nO != 0.f) { g += a.a_tv * -(dxf(c, lx, ly) + dyf(c, lx, ly)) / nO; }
-                                if(TGV) {
-                                        const float *t = TG + (c * 4) * kSH * kSW + si;
-                                        const float *tA = t, *tB = t + kSH * kSW, *tC = t + 2 * kSH * kSW, *tO = t + 3 * kSH * kSW;
-                                        g += tB[-kSW];          // (x,  y-1)
-                                        g += tC[-kSW + 1];      // (x+1,y-1)
-                                        g += tA[-1];            // (x-1,y)
-                                        g += tO[0];             // own
-                                        g += tA[1];             // (x+1,y)
-                                        g += tC[kSW - 1];       // (x-1,y+1)
-                                        g += tB[kSW];           // (x,  y+1)
-                                }
-                                k.grad[(size_t)(ty0 + ly) * W + gx] = g;
-                                g2[c] += (double)(g * g);       // compute.c:203
-                        }
-                }
-        }
-        const size_t tile = (size_t)blockIdx.y * a.geo.ntx + blockIdx.x;
-        const size_t ntiles = (size_t)gridDim.y * a.geo.ntx;
-#pragma unroll
-        for(int c = 0; c < NCH; c++) {
-                const double s = block_sum(g2[c], red);
-                if(tid == 0) { a.part_g2[c * ntiles + tile] = s; }
-        }
-        if(LOG) {
-                const double s1 = block_sum(tv_acc, red);
-                const double s2 = block_sum(tv2_acc, red);
-                if(tid == 0) {
-                        a.part_tv[2 * tile] = s1;
-                        a.part_tv[2 * tile + 1] = s2;
-                }
-        }
-}
-
-
-// ---------------------------------------------------------------------------
-// Phase A, register-marching form (the one that ships).
+// Phase A: gradient, register-marching form.
 //
-// One wavefront owns a strip of 64*CPL consecutive columns (CPL columns per
-// lane) and walks down RPW rows.  Everything the gather needs from neighbouring
-// COLUMNS moves between lanes with DPP wave shifts; everything it needs from
-// neighbouring ROWS is carried in registers from one loop trip to the next:
-// no LDS, no barriers.  The two outermost columns on each side of the strip are
-// halo (loaded and differenced, never stored), so a strip yields 64*CPL-4 output
-// columns; likewise each strip recomputes the source terms of one row above and
-// below its RPW rows.
+// One wavefront owns a strip of 128 consecutive columns (2 per lane, handled as
+// packed float2 so that the arithmetic issues as v_pk_* ops) and walks down kRPW
+// rows.  Everything the gather needs from neighbouring COLUMNS moves between
+// lanes with DPP wave shifts; everything it needs from neighbouring ROWS is
+// carried in registers from one loop trip to the next: no LDS, no barriers.
+// The two outermost columns on each side of the strip are halo (loaded and
+// differenced, never stored), so a strip yields 124 output columns; likewise
+// each strip recomputes the source terms of one row above and below its rows.
 //
 // Per loop trip (source row r, with y rows r-1, r, r+1 in registers):
 //   S_r  = per-pixel terms every neighbour will need from pixel (x,r):
@@ -377,7 +213,24 @@ __global__ __launch_bounds__(256) void k_gradient(GradArgs a)
 //          g = p_alpha*P  + S_{t-1}.tvy + S_t.tvx(x-1) + S_t.tvo
 //              + S_{t-1}.B + S_{t-1}.C(x+1) + S_t.A(x-1) + S_t.O + S_t.A(x+1)
 //              + S_{t+1}.C(x-1) + S_{t+1}.B          (the reference's raster order)
+// The loop is unrolled by hand three times over a ring of row slots so that the
+// carried state never has to be copied.
+//
+// Division and square root.  Both are IEEE-correct.  The fast path is the compiler's own
+// f32 sequence with the range scaling left out (division: rcp, one Newton step,
+// quotient, two fma residual corrections, the refined reciprocal shared by the 3-4
+// numerators of a pixel; square root: v_sqrt_f32 then the two fma residual tests
+// against the neighbouring floats), written on float2 so that it issues as v_pk_fma.
+// It is bit-identical to `/` and sqrtf() whenever the compiler's version would not
+// have rescaled its operands, and that is guaranteed by screening the INPUT of the
+// whole stencil once per loaded pixel: if every y is 0 or 2^-20 <= |y| < 2^40, all
+// first/second differences are multiples of 2^-44, hence 0 or >= 2^-44, their
+// squares are normal, the norms lie in [2^-43, 2^43] and no quotient is subnormal.
+// A wavefront that loads a pixel outside that range (never seen on image data)
+// takes the plain `/` and sqrtf() path for the rows that pixel touches.
 // ---------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float lane_from_left(float v)    // value held by lane-1 (0 in lane 0)
 {
         return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
@@ -386,37 +239,144 @@ __device__ __forceinline__ float lane_from_right(float v)   // value held by lan
 {
         return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
+// columns x-1 / x+1 of a lane's column pair
+__device__ __forceinline__ v2f left_of(v2f a) { return v2f{lane_from_left(a.y), a.x}; }
+__device__ __forceinline__ v2f right_of(v2f a) { return v2f{a.y, lane_from_right(a.x)}; }
 
-template <int CPL>
-struct Cols {
-        float v[CPL];
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+// shared part of the division: reciprocal refined by one Newton step
+__device__ __forceinline__ v2f div_prepare(v2f d)
+{
+        const v2f r = v2f{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+        const v2f e = pk_fma(-d, r, v2f{1.f, 1.f});
+        return pk_fma(e, r, r);
+}
+// x / d given r = div_prepare(d)
+__device__ __forceinline__ v2f div_shared(v2f x, v2f d, v2f r)
+{
+        const v2f q0 = x * r;
+        const v2f q1 = pk_fma(pk_fma(-d, q0, x), r, q0);
+        return pk_fma(pk_fma(-d, q1, x), r, q1);
+}
+// true when a loaded pixel is outside the range for which the fast paths are exact:
+// 0 < |y| < 2^-20 (y * 2^-106 is subnormal), |y| >= 2^41 (y * 2^87 overflows), or NaN
+__device__ __forceinline__ bool y_suspect(v2f y)
+{
+        const v2f lo = y * 0x1p-106f, hi = y * 0x1p87f;
+        constexpr int kDenorm = 0x090, kInfNan = 0x207;
+        return __builtin_amdgcn_classf(lo.x, kDenorm) | __builtin_amdgcn_classf(lo.y, kDenorm) |
+               __builtin_amdgcn_classf(hi.x, kInfNan) | __builtin_amdgcn_classf(hi.y, kInfNan);
+}
+
+// sqrtf for 0 or 2^-96 <= x < 2^126: v_sqrt_f32 is within 1 ulp; pick the correctly rounded
+// neighbour with two exact residuals (the compiler's own expansion without its rescaling)
+__device__ __forceinline__ v2f sqrt_fast(v2f x)
+{
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        const v2f s = v2f{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
+        // the neighbouring floats, through integer VECTOR arithmetic: written element-wise
+        // (v2f{bitcast(int(s.x)-1), bitcast(int(s.y)-1)}) hipcc 7.2 reuses the .x result for .y
+        const v2i si = __builtin_bit_cast(v2i, s);
+        const v2f dn = __builtin_bit_cast(v2f, si - 1);
+        const v2f up = __builtin_bit_cast(v2f, si + 1);
+        const v2f vp = pk_fma(-dn, s, x), vs = pk_fma(-up, s, x);
+        v2f r = v2f{vp.x <= 0.f ? dn.x : s.x, vp.y <= 0.f ? dn.y : s.y};
+        r = v2f{vs.x > 0.f ? up.x : r.x, vs.y > 0.f ? up.y : r.y};
+        return r;
+}
+
+constexpr int kRPW = 32;          // rows per wavefront strip (multiple of kTY)
+constexpr int kStripCols = 124;   // output columns per wavefront strip
+
+template <int NCH, bool TGV>
+struct SourceTerms {
+        v2f tvxL[NCH], tvo[NCH], tvy[NCH];                        // TV: from (x-1), own, to the row below
+        v2f AL[NCH], AR[NCH], O[NCH], B[NCH], CL[NCH], CR[NCH];   // TGV2
 };
-// column x-1 / x+1 of a per-lane group of CPL adjacent columns
-template <int CPL>
-__device__ __forceinline__ Cols<CPL> left_of(const Cols<CPL> &a)
+
+template <bool FAST>
+__device__ __forceinline__ v2f sqrt_pair(v2f x)
 {
-        Cols<CPL> r;
-        r.v[0] = lane_from_left(a.v[CPL - 1]);
-#pragma unroll
-        for(int j = 1; j < CPL; j++) { r.v[j] = a.v[j - 1]; }
-        return r;
+        if(FAST) { return sqrt_fast(x); }
+        return v2f{sqrtf(x.x), sqrtf(x.y)};
 }
-template <int CPL>
-__device__ __forceinline__ Cols<CPL> right_of(const Cols<CPL> &a)
+template <bool FAST>
+__device__ __forceinline__ v2f div_pair(v2f x, v2f d, v2f r)
 {
-        Cols<CPL> r;
-        r.v[CPL - 1] = lane_from_right(a.v[0]);
-#pragma unroll
-        for(int j = 0; j < CPL - 1; j++) { r.v[j] = a.v[j + 1]; }
-        return r;
+        if(FAST) { return div_shared(x, d, r); }
+        return v2f{x.x / d.x, x.y / d.y};
 }
 
-constexpr int kRPW = 32;         // rows per wavefront strip (multiple of kTY)
-
-template <int NCH, bool TGV, bool LOG, int CPL>
-__global__ __launch_bounds__(256) void k_gradient_march(GradArgs a)
+// Source terms of one image row for a lane's column pair.  gx,gy: forward differences of
+// this row, gxp,gyp: of the row above.  m_hx / m_hy zero the second differences on the first
+// column / first row (compute.c:137-143).  tv / tv2 receive the log sums when `log_row`.
+template <int NCH, bool TGV, bool LOG, bool FAST>
+__device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&gy)[NCH], const v2f (&gxp)[NCH],
+                                             const v2f (&gyp)[NCH], v2f m_hx, v2f m_hy, float a_tv, float a_tgv,
+                                             bool log_row, double &tv, double &tv2, SourceTerms<NCH, TGV> &s)
 {
-        constexpr int VALIDW = 64 * CPL - 4;
+        // ---- TV (compute.c:84-104) ----
+        v2f n1 = v2f{0.f, 0.f};
+#pragma unroll
+        for(int c = 0; c < NCH; c++) {
+                n1 += gx[c] * gx[c];
+                n1 += gy[c] * gy[c];
+        }
+        n1 = sqrt_pair<FAST>(n1);
+        if(LOG && log_row) {
+                tv += (double)(a_tv * n1.x);
+                tv += (double)(a_tv * n1.y);
+        }
+        // a pixel with zero norm contributes nothing (compute.c:97): divide by 1, scale by 0
+        const v2f d1 = v2f{n1.x == 0.f ? 1.f : n1.x, n1.y == 0.f ? 1.f : n1.y};
+        const v2f a1 = v2f{n1.x == 0.f ? 0.f : a_tv, n1.y == 0.f ? 0.f : a_tv};
+        const v2f r1 = FAST ? div_prepare(d1) : d1;
+#pragma unroll
+        for(int c = 0; c < NCH; c++) {
+                s.tvxL[c] = left_of(div_pair<FAST>(a1 * gx[c], d1, r1));
+                s.tvy[c] = div_pair<FAST>(a1 * gy[c], d1, r1);
+                s.tvo[c] = div_pair<FAST>(a1 * -(gx[c] + gy[c]), d1, r1);
+        }
+        // ---- TGV2 (compute.c:136-183) ----
+        if(TGV) {
+                v2f n2 = v2f{0.f, 0.f};
+                v2f xx[NCH], sy[NCH], yy[NCH];
+#pragma unroll
+                for(int c = 0; c < NCH; c++) {
+                        xx[c] = (gx[c] - left_of(gx[c])) * m_hx;
+                        const v2f gyx = (gy[c] - left_of(gy[c])) * m_hx;
+                        const v2f gxy = (gx[c] - gxp[c]) * m_hy;
+                        yy[c] = (gy[c] - gyp[c]) * m_hy;
+                        sy[c] = (gxy + gyx) * 0.5f;                     // (g_xy + g_yx) / 2.
+                        n2 += xx[c] * xx[c] + 2.f * (sy[c] * sy[c]) + yy[c] * yy[c];
+                }
+                n2 = sqrt_pair<FAST>(n2);
+                if(LOG && log_row) {
+                        tv2 += (double)(a_tgv * n2.x);
+                        tv2 += (double)(a_tgv * n2.y);
+                }
+                const v2f d2 = v2f{n2.x == 0.f ? 1.f : n2.x, n2.y == 0.f ? 1.f : n2.y};
+                const v2f a2 = v2f{n2.x == 0.f ? 0.f : a_tgv, n2.y == 0.f ? 0.f : a_tgv};   // compute.c:158
+                const v2f r2 = FAST ? div_prepare(d2) : d2;
+#pragma unroll
+                for(int c = 0; c < NCH; c++) {
+                        // a2 * (expr / n2): division first (compute.c:165-182)
+                        const v2f tA = a2 * div_pair<FAST>(sy[c] + xx[c], d2, r2);        // to (x-1,y), (x+1,y)
+                        s.B[c] = a2 * div_pair<FAST>(yy[c] + sy[c], d2, r2);              // to (x,y-1), (x,y+1)
+                        const v2f tC = a2 * div_pair<FAST>(-sy[c], d2, r2);               // to (x+1,y-1), (x-1,y+1)
+                        s.O[c] = a2 * div_pair<FAST>(-(2.f * xx[c] + 2.f * sy[c] + 2.f * yy[c]), d2, r2);
+                        s.AL[c] = left_of(tA);
+                        s.AR[c] = right_of(tA);
+                        s.CL[c] = left_of(tC);
+                        s.CR[c] = right_of(tC);
+                }
+        }
+}
+
+template <int NCH, bool TGV, bool LOG>
+__global__ __launch_bounds__(256, (NCH == 1 ? 5 : NCH == 2 ? 3 : 2)) void k_gradient(GradArgs a)
+{
         const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
         const int wcol = (int)blockIdx.x * 4 + wave;
         if(wcol >= (int)a.geo.ntx) { return; }
@@ -424,76 +384,54 @@ __global__ __launch_bounds__(256) void k_gradient_march(GradArgs a)
         const int rows = (int)a.geo.rows, row0 = (int)a.geo.row0;
         const int t0 = (int)blockIdx.y * kRPW;                 // band-local target rows [t0, t1)
         const int t1 = t0 + kRPW < rows ? t0 + kRPW : rows;
-        const int xl = wcol * VALIDW - 2 + lane * CPL;         // canvas column of v[0]
+        const int xl = wcol * kStripCols - 2 + lane * 2;       // canvas column of .x (even; W is even too)
 
-        bool col_in[CPL], col_own[CPL];
-#pragma unroll
-        for(int j = 0; j < CPL; j++) {
-                const int x = xl + j, rel = lane * CPL + j;
-                col_in[j] = x >= 0 && x < W;
-                col_own[j] = col_in[j] && rel >= 2 && rel < 64 * CPL - 2;
-        }
+        const bool pair_in = xl >= 0 && xl < W;                // both columns in the image, or neither
+        const bool pair_own = pair_in && lane >= 1 && lane <= 62;
+        // per-lane constant masks (1.f / 0.f), multiplied instead of selected: v*1 is exact, v*0 = +-0
+        const float in_f = pair_in ? 1.f : 0.f;
+        const v2f m_gx = v2f{in_f, xl + 1 >= W - 1 ? 0.f : in_f};   // gx = 0 on the last column (compute.c:79)
+        const v2f m_hx = v2f{xl == 0 ? 0.f : in_f, in_f};           // gxx, gyx = 0 on the first column
 
         // FISTA point of one row for this lane's columns (compute.c:433-439); 0 outside the image
-        auto load_y = [&](int lr, Cols<CPL> (&y)[NCH]) {
+        auto load_y = [&](int lr, v2f (&y)[NCH], bool &suspect) {
                 const int gr = row0 + lr;
-                const bool rin = gr >= 0 && gr < H;
+                const bool rin = gr >= 0 && gr < H && pair_in;
+                const ptrdiff_t off = (ptrdiff_t)lr * W + xl;
+                suspect = false;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
-                        const ptrdiff_t off = (ptrdiff_t)lr * W + xl;
-                        if(CPL == 2) {
-                                float2 xc = make_float2(0.f, 0.f), xp = make_float2(0.f, 0.f);
-                                if(rin && col_in[0]) {          // W and xl are even: the pair is in or out together
-                                        xc = *reinterpret_cast<const float2 *>(a.ch[c].xcur + off);
-                                        xp = *reinterpret_cast<const float2 *>(a.ch[c].xprev + off);
-                                }
-                                y[c].v[0] = xc.x + a.factor * (xc.x - xp.x);
-                                y[c].v[CPL - 1] = xc.y + a.factor * (xc.y - xp.y);
-                        } else {
-#pragma unroll
-                                for(int j = 0; j < CPL; j++) {
-                                        float xc = 0.f, xp = 0.f;
-                                        if(rin && col_in[j]) {
-                                                xc = a.ch[c].xcur[off + j];
-                                                xp = a.ch[c].xprev[off + j];
-                                        }
-                                        y[c].v[j] = xc + a.factor * (xc - xp);
-                                }
+                        v2f xc = v2f{0.f, 0.f}, xp = v2f{0.f, 0.f};
+                        if(rin) {
+                                xc = *reinterpret_cast<const v2f *>(a.ch[c].xcur + off);
+                                xp = *reinterpret_cast<const v2f *>(a.ch[c].xprev + off);
                         }
+                        y[c] = xc + a.factor * (xc - xp);
+                        suspect |= y_suspect(y[c]);
                 }
         };
-        // forward differences of row r given rows r and r+1 (compute.c:79,81)
-        auto diffs = [&](int gr, const Cols<CPL> (&yc)[NCH], const Cols<CPL> (&yn)[NCH], Cols<CPL> (&gx)[NCH], Cols<CPL> (&gy)[NCH]) {
+        // forward differences of row gr given rows gr and gr+1 (compute.c:79,81)
+        auto diffs = [&](int gr, const v2f (&yc)[NCH], const v2f (&yn)[NCH], v2f (&gx)[NCH], v2f (&gy)[NCH]) {
+                const float m_gy = gr >= 0 && gr < H - 1 ? 1.f : 0.f;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
-                        const Cols<CPL> yr = right_of<CPL>(yc[c]);
-#pragma unroll
-                        for(int j = 0; j < CPL; j++) {
-                                gx[c].v[j] = xl + j >= W - 1 ? 0.f : yr.v[j] - yc[c].v[j];
-                                gy[c].v[j] = gr >= H - 1 ? 0.f : yn[c].v[j] - yc[c].v[j];
-                        }
+                        gx[c] = (right_of(yc[c]) - yc[c]) * m_gx;
+                        gy[c] = (yn[c] - yc[c]) * m_gy;
                 }
         };
 
-        Cols<CPL> yc[NCH], yn[NCH], gxp[NCH], gyp[NCH];
+        // ring of three row slots
+        v2f Y[3][NCH], GX[3][NCH], GY[3][NCH];
+        bool bad[3];
+        SourceTerms<NCH, TGV> S[3];
         {
-                Cols<CPL> ym[NCH];
-                load_y(t0 - 2, ym);
-                load_y(t0 - 1, yc);
-                load_y(t0, yn);
-                diffs(row0 + t0 - 2, ym, yc, gxp, gyp);
-        }
-        // carried source terms: row t (p1*) and the part of row t-1 the next target still needs (p2*)
-        Cols<CPL> p1_tvxL[NCH], p1_tvo[NCH], p1_tvy[NCH], p1_AL[NCH], p1_O[NCH], p1_AR[NCH], p1_B[NCH], p1_CR[NCH];
-        Cols<CPL> p2_tvy[NCH], p2_B[NCH], p2_CR[NCH];
-#pragma unroll
-        for(int c = 0; c < NCH; c++) {
-#pragma unroll
-                for(int j = 0; j < CPL; j++) {
-                        p1_tvxL[c].v[j] = p1_tvo[c].v[j] = p1_tvy[c].v[j] = 0.f;
-                        p1_AL[c].v[j] = p1_O[c].v[j] = p1_AR[c].v[j] = p1_B[c].v[j] = p1_CR[c].v[j] = 0.f;
-                        p2_tvy[c].v[j] = p2_B[c].v[j] = p2_CR[c].v[j] = 0.f;
-                }
+                v2f ym[NCH];
+                bool bm;
+                load_y(t0 - 2, ym, bm);
+                load_y(t0 - 1, Y[0], bad[0]);
+                load_y(t0, Y[1], bad[1]);
+                bad[0] |= bm;                                  // row t0-2 only feeds the first trip
+                diffs(row0 + t0 - 2, ym, Y[0], GX[2], GY[2]);
         }
         double g2[NCH];
 #pragma unroll
@@ -502,127 +440,67 @@ __global__ __launch_bounds__(256) void k_gradient_march(GradArgs a)
         const size_t ntiles_row = a.geo.ntx;
         const size_t nparts = (size_t)((rows + kTY - 1) / kTY) * ntiles_row;
 
-#pragma unroll 1
-        for(int r = t0 - 1; r <= t1; r++) {
+        // one trip: source terms of row r into slot P, then target row r-1
+        auto trip = [&](auto phase, int r) {
+                constexpr int P = decltype(phase)::value, P1 = (P + 1) % 3, P2 = (P + 2) % 3;
                 const int gr = row0 + r;
-                Cols<CPL> ynn[NCH];
-                load_y(r + 2 <= t1 + 1 ? r + 2 : -(int)kHalo - 1 - row0, ynn);   // prefetch for the next trip; past the
-                                                                                 // halo nothing is needed (maps to a row < 0)
-                // ---- source terms of row r ----
-                const bool rin = gr >= 0 && gr < H;
-                Cols<CPL> gx[NCH], gy[NCH];
-                diffs(gr, yc, yn, gx, gy);
-                Cols<CPL> n1;
-#pragma unroll
-                for(int j = 0; j < CPL; j++) {
-                        float n = 0.f;
+                const bool prev_bad = bad[P2];                 // row r-1, about to be overwritten by the prefetch
+                // prefetch y[r+2] for the next trip; past the halo nothing is needed (maps to a row < 0)
+                load_y(r + 2 <= t1 + 1 ? r + 2 : -(int)kHalo - 1 - row0, Y[P2], bad[P2]);
+                SourceTerms<NCH, TGV> &s = S[P];
+                diffs(gr, Y[P], Y[P1], GX[P], GY[P]);
+                if(gr >= 0 && gr < H) {                        // wave-uniform
+                        const bool log_row = LOG && pair_own && r >= t0 && r < t1;
+                        const float hy = gr == 0 ? 0.f : in_f;  // gxy, gyy = 0 on the first row
+                        const v2f m_hy = v2f{hy, hy};
+                        if(__builtin_amdgcn_ballot_w64(prev_bad | bad[P] | bad[P1]) == 0) {
+                                source_terms<NCH, TGV, LOG, true>(GX[P], GY[P], GX[P2], GY[P2], m_hx, m_hy, a.a_tv, a.a_tgv,
+                                                                  log_row, tv_acc, tv2_acc, s);
+                        } else {
+                                source_terms<NCH, TGV, LOG, false>(GX[P], GY[P], GX[P2], GY[P2], m_hx, m_hy, a.a_tv, a.a_tgv,
+                                                                   log_row, tv_acc, tv2_acc, s);
+                        }
+                } else {
+                        // a row above or below the image contributes nothing
 #pragma unroll
                         for(int c = 0; c < NCH; c++) {
-                                n += gx[c].v[j] * gx[c].v[j];
-                                n += gy[c].v[j] * gy[c].v[j];
-                        }
-                        n1.v[j] = rin && col_in[j] ? sqrtf(n) : 0.f;
-                        if(LOG && col_own[j] && r >= t0 && r < t1) { tv_acc += (double)(a.a_tv * n1.v[j]); }
-                }
-                Cols<CPL> s_tvx[NCH], s_tvy[NCH], s_tvo[NCH];
-#pragma unroll
-                for(int c = 0; c < NCH; c++) {
-#pragma unroll
-                        for(int j = 0; j < CPL; j++) {
-                                const float n = n1.v[j];
-                                const bool nz = n != 0.f;
-                                s_tvx[c].v[j] = nz ? a.a_tv * gx[c].v[j] / n : 0.f;
-                                s_tvy[c].v[j] = nz ? a.a_tv * gy[c].v[j] / n : 0.f;
-                                s_tvo[c].v[j] = nz ? a.a_tv * -(gx[c].v[j] + gy[c].v[j]) / n : 0.f;
+                                s.tvxL[c] = s.tvo[c] = s.tvy[c] = v2f{0.f, 0.f};
+                                if(TGV) { s.AL[c] = s.AR[c] = s.O[c] = s.B[c] = s.CL[c] = s.CR[c] = v2f{0.f, 0.f}; }
                         }
                 }
-                Cols<CPL> s_A[NCH], s_B[NCH], s_C[NCH], s_O[NCH];
-                if(TGV) {
-                        Cols<CPL> xx[NCH], sy[NCH], yy[NCH];
-                        Cols<CPL> n2;
-#pragma unroll
-                        for(int j = 0; j < CPL; j++) { n2.v[j] = 0.f; }
-#pragma unroll
-                        for(int c = 0; c < NCH; c++) {
-                                const Cols<CPL> gxl = left_of<CPL>(gx[c]), gyl = left_of<CPL>(gy[c]);
-#pragma unroll
-                                for(int j = 0; j < CPL; j++) {
-                                        const bool x0 = xl + j == 0;
-                                        xx[c].v[j] = x0 ? 0.f : gx[c].v[j] - gxl.v[j];
-                                        const float gyx = x0 ? 0.f : gy[c].v[j] - gyl.v[j];
-                                        const float gxy = gr == 0 ? 0.f : gx[c].v[j] - gxp[c].v[j];
-                                        yy[c].v[j] = gr == 0 ? 0.f : gy[c].v[j] - gyp[c].v[j];
-                                        sy[c].v[j] = (gxy + gyx) / 2.f;
-                                        n2.v[j] += xx[c].v[j] * xx[c].v[j] + 2 * (sy[c].v[j] * sy[c].v[j]) + yy[c].v[j] * yy[c].v[j];
-                                }
-                        }
-#pragma unroll
-                        for(int j = 0; j < CPL; j++) {
-                                n2.v[j] = rin && col_in[j] ? sqrtf(n2.v[j]) : 0.f;
-                                if(LOG && col_own[j] && r >= t0 && r < t1) { tv2_acc += (double)(a.a_tgv * n2.v[j]); }
-                        }
-#pragma unroll
-                        for(int c = 0; c < NCH; c++) {
-#pragma unroll
-                                for(int j = 0; j < CPL; j++) {
-                                        const float n = n2.v[j];
-                                        const bool nz = n != 0.f;
-                                        s_A[c].v[j] = nz ? a.a_tgv * ((sy[c].v[j] + xx[c].v[j]) / n) : 0.f;
-                                        s_B[c].v[j] = nz ? a.a_tgv * ((yy[c].v[j] + sy[c].v[j]) / n) : 0.f;
-                                        s_C[c].v[j] = nz ? a.a_tgv * ((-sy[c].v[j]) / n) : 0.f;
-                                        s_O[c].v[j] = nz ? a.a_tgv * (-(2 * xx[c].v[j] + 2 * sy[c].v[j] + 2 * yy[c].v[j]) / n) : 0.f;
-                                }
-                        }
-                }
-                // ---- target row t = r-1 ----
+                // ---- target row t = r-1: rows t-1, t, t+1 live in slots P1, P2, P ----
                 const int t = r - 1;
                 if(t >= t0) {
+                        const SourceTerms<NCH, TGV> &up = S[P1], &mid = S[P2];
                         const int gt = row0 + t;
 #pragma unroll
                         for(int c = 0; c < NCH; c++) {
                                 const ChanDev &k = a.ch[c];
-                                Cols<CPL> g;
-#pragma unroll
-                                for(int j = 0; j < CPL; j++) { g.v[j] = 0.f; }
-                                if(k.prob_on && (unsigned)gt < k.ch * k.hs) {
-                                        const size_t prow = (size_t)((unsigned)gt / k.hs - k.crow0) * k.cw;
-#pragma unroll
-                                        for(int j = 0; j < CPL; j++) {
-                                                const int x = xl + j;
-                                                if(col_own[j] && (unsigned)x < k.cw * k.ws) {
-                                                        g.v[j] += k.p_alpha * k.pg[prow + (unsigned)x / k.ws];
-                                                }
-                                        }
+                                v2f g = v2f{0.f, 0.f};
+                                if(k.prob_on && pair_own && (unsigned)gt < k.ch * k.hs && (unsigned)xl < k.cw * k.ws) {
+                                        const float *prow = k.pg + (size_t)((unsigned)gt / k.hs - k.crow0) * k.cw;
+                                        v2f pv;
+                                        if(k.ws == 1) { pv = *reinterpret_cast<const v2f *>(prow + xl); }
+                                        else { pv = v2f{prow[(unsigned)xl / k.ws], prow[(unsigned)(xl + 1) / k.ws]}; }
+                                        g += k.p_alpha * pv;
                                 }
-                                Cols<CPL> cL, aL_unused;
-                                (void)aL_unused;
-                                if(TGV) { cL = left_of<CPL>(s_C[c]); }
-#pragma unroll
-                                for(int j = 0; j < CPL; j++) {
-                                        float v = g.v[j];
-                                        v += p2_tvy[c].v[j];        // TV from (x, t-1)
-                                        v += p1_tvxL[c].v[j];       // TV from (x-1, t)
-                                        v += p1_tvo[c].v[j];        // TV own
-                                        if(TGV) {
-                                                v += p2_B[c].v[j];  // (x,   t-1)
-                                                v += p2_CR[c].v[j]; // (x+1, t-1)
-                                                v += p1_AL[c].v[j]; // (x-1, t)
-                                                v += p1_O[c].v[j];  // own
-                                                v += p1_AR[c].v[j]; // (x+1, t)
-                                                v += cL.v[j];       // (x-1, t+1)
-                                                v += s_B[c].v[j];   // (x,   t+1)
-                                        }
-                                        g.v[j] = v;
-                                        if(col_own[j]) { g2[c] += (double)(v * v); }    // compute.c:203
+                                g += up.tvy[c];                  // TV from (x, t-1)
+                                g += mid.tvxL[c];                // TV from (x-1, t)
+                                g += mid.tvo[c];                 // TV own
+                                if(TGV) {
+                                        g += up.B[c];            // (x,   t-1)
+                                        g += up.CR[c];           // (x+1, t-1)
+                                        g += mid.AL[c];          // (x-1, t)
+                                        g += mid.O[c];           // own
+                                        g += mid.AR[c];          // (x+1, t)
+                                        g += s.CL[c];            // (x-1, t+1)
+                                        g += s.B[c];             // (x,   t+1)
                                 }
-                                float *dst = k.grad + (size_t)t * W + xl;
-                                if(CPL == 2) {
-                                        if(col_own[0]) { *reinterpret_cast<float2 *>(dst) = make_float2(g.v[0], g.v[CPL - 1]); }
-                                } else {
-#pragma unroll
-                                        for(int j = 0; j < CPL; j++) {
-                                                if(col_own[j]) { dst[j] = g.v[j]; }
-                                        }
+                                if(pair_own) {
+                                        *reinterpret_cast<v2f *>(k.grad + (size_t)t * W + xl) = g;
+                                        const v2f sq = g * g;
+                                        g2[c] += (double)sq.x;   // compute.c:203
+                                        g2[c] += (double)sq.y;
                                 }
                         }
                         // one partial per 16-row tile row and strip: the granularity of the GPU-count
@@ -638,27 +516,14 @@ __global__ __launch_bounds__(256) void k_gradient_march(GradArgs a)
                                 }
                         }
                 }
-                // ---- rotate the carried state ----
-#pragma unroll
-                for(int c = 0; c < NCH; c++) {
-                        p2_tvy[c] = p1_tvy[c];
-                        p1_tvy[c] = s_tvy[c];
-                        p1_tvxL[c] = left_of<CPL>(s_tvx[c]);
-                        p1_tvo[c] = s_tvo[c];
-                        if(TGV) {
-                                p2_B[c] = p1_B[c];
-                                p2_CR[c] = p1_CR[c];
-                                p1_B[c] = s_B[c];
-                                p1_CR[c] = right_of<CPL>(s_C[c]);
-                                p1_AL[c] = left_of<CPL>(s_A[c]);
-                                p1_AR[c] = right_of<CPL>(s_A[c]);
-                                p1_O[c] = s_O[c];
-                        }
-                        gxp[c] = gx[c];
-                        gyp[c] = gy[c];
-                        yc[c] = yn[c];
-                        yn[c] = ynn[c];
-                }
+        };
+
+        for(int r = t0 - 1; r <= t1; r += 3) {
+                trip(std::integral_constant<int, 0>{}, r);
+                if(r + 1 > t1) { break; }
+                trip(std::integral_constant<int, 1>{}, r + 1);
+                if(r + 2 > t1) { break; }
+                trip(std::integral_constant<int, 2>{}, r + 2);
         }
         if(LOG) {
 #pragma unroll
@@ -672,12 +537,6 @@ __global__ __launch_bounds__(256) void k_gradient_march(GradArgs a)
                         a.part_tv[2 * w + 1] = tv2_acc;
                 }
         }
-}
-
-template <int NCH, bool TGV>
-constexpr size_t gradient_lds_bytes()
-{
-        return sizeof(float) * (NCH * kYH * kYW + kSH * kSW + (TGV ? NCH * 4 * kSH * kSW : 0)) + 4 * sizeof(double) + 16;
 }
 
 // ---------------------------------------------------------------------------
@@ -994,6 +853,49 @@ __global__ __launch_bounds__(256) void k_dct_blocks(float *blocks, size_t nblock
 #pragma unroll
                 for(int u = 0; u < 8; u++) { blocks[blk * 64 + rr * 8 + u] = v[u]; }
         }
+}
+
+// ---------------------------------------------------------------------------
+// Self-test of the fast division / square root against the compiler's IEEE forms
+// on n pseudo-random operand pairs inside the screened range (tests/ only).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mix32(unsigned x)
+{
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        return x;
+}
+// random float with exponent in [elo, ehi] (biased) and random sign / mantissa
+__device__ __forceinline__ float rnd_float(unsigned h, unsigned elo, unsigned ehi)
+{
+        const unsigned e = elo + (h >> 9) % (ehi - elo + 1);
+        return __builtin_bit_cast(float, (h << 31) | (e << 23) | (mix32(h) & 0x7fffffu));
+}
+__global__ __launch_bounds__(256) void k_math_selftest(size_t n, unsigned seed, unsigned long long *mism /* [2] */)
+{
+        unsigned long long bad_div = 0, bad_sqrt = 0;
+        for(size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+                const unsigned h0 = mix32((unsigned)i * 2654435761u + seed), h1 = mix32(h0 + 0x9e3779b9u);
+                const unsigned h2 = mix32(h1 + 0x9e3779b9u), h3 = mix32(h2 + 0x9e3779b9u);
+                // denominators: norms in [2^-44, 2^44]; numerators: 0 or magnitude in [2^-45, 2^45]
+                v2f d = v2f{fabsf(rnd_float(h0, 83, 171)), fabsf(rnd_float(h1, 83, 171))};
+                v2f x = v2f{rnd_float(h2, 82, 172), rnd_float(h3, 82, 172)};
+                if((h3 & 0xff) == 0) { x.x = 0.f; }
+                if((h2 & 0xff) == 1) { x.y = d.y; }
+                const v2f q = div_shared(x, d, div_prepare(d));
+                const v2f qi = v2f{x.x / d.x, x.y / d.y};
+                bad_div += __builtin_bit_cast(unsigned, q.x) != __builtin_bit_cast(unsigned, qi.x) && !(q.x == 0.f && qi.x == 0.f);
+                bad_div += __builtin_bit_cast(unsigned, q.y) != __builtin_bit_cast(unsigned, qi.y) && !(q.y == 0.f && qi.y == 0.f);
+                // square roots: sums of squares in [2^-90, 2^90], or exactly 0, or perfect squares
+                v2f sx = v2f{fabsf(rnd_float(h1 ^ h2, 37, 217)), fabsf(rnd_float(h0 ^ h3, 37, 217))};
+                if((h0 & 0xff) == 0) { sx.x = 0.f; }
+                if((h1 & 0xff) == 1) { sx.y = d.y * d.y; }
+                const v2f sf = sqrt_fast(sx);
+                const v2f si = v2f{sqrtf(sx.x), sqrtf(sx.y)};
+                bad_sqrt += __builtin_bit_cast(unsigned, sf.x) != __builtin_bit_cast(unsigned, si.x);
+                bad_sqrt += __builtin_bit_cast(unsigned, sf.y) != __builtin_bit_cast(unsigned, si.y);
+        }
+        if(bad_div) { atomicAdd(&mism[0], bad_div); }
+        if(bad_sqrt) { atomicAdd(&mism[1], bad_sqrt); }
 }
 
 }  // namespace j2p

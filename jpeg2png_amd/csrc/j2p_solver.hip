@@ -146,18 +146,15 @@ Geo geo_of(const j2p_solver *s)
         return g;
 }
 
-constexpr int kCPL = 2;                       // columns per lane of the marching gradient kernel
-constexpr int kStripW = 64 * kCPL - 4;        // output columns per wavefront strip
-
 template <int NCH>
 void launch_gradient_n(const GradArgs &a, dim3 grid, hipStream_t st, bool tgv, bool log)
 {
         if(tgv) {
-                if(log) { hipLaunchKernelGGL((k_gradient_march<NCH, true, true, kCPL>), grid, dim3(256), 0, st, a); }
-                else { hipLaunchKernelGGL((k_gradient_march<NCH, true, false, kCPL>), grid, dim3(256), 0, st, a); }
+                if(log) { hipLaunchKernelGGL((k_gradient<NCH, true, true>), grid, dim3(256), 0, st, a); }
+                else { hipLaunchKernelGGL((k_gradient<NCH, true, false>), grid, dim3(256), 0, st, a); }
         } else {
-                if(log) { hipLaunchKernelGGL((k_gradient_march<NCH, false, true, kCPL>), grid, dim3(256), 0, st, a); }
-                else { hipLaunchKernelGGL((k_gradient_march<NCH, false, false, kCPL>), grid, dim3(256), 0, st, a); }
+                if(log) { hipLaunchKernelGGL((k_gradient<NCH, false, true>), grid, dim3(256), 0, st, a); }
+                else { hipLaunchKernelGGL((k_gradient<NCH, false, false>), grid, dim3(256), 0, st, a); }
         }
 }
 
@@ -481,7 +478,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 }
         }
         // reductions: tile rows are counted on the canvas, the band owns a contiguous range
-        s->ntx = (W + kStripW - 1) / kStripW;
+        s->ntx = (W + kStripCols - 1) / kStripCols;
         s->nseg = (s->rows + kRPW - 1) / kRPW;
         s->ntr_local = (s->rows + kTY - 1) / kTY;
         s->ntr_global = (H + kTY - 1) / kTY;
@@ -754,6 +751,27 @@ int j2p_dct8x8_blocks(int device, float *blocks, size_t n, int inverse)
         if(e != hipSuccess) { rc = fail(e == hipErrorOutOfMemory ? J2P_ENOMEM : J2P_EDEVICE, "dct8x8_blocks: %s", hipGetErrorString(e)); }
         (void)hipFree(db);
         return rc;
+}
+
+int j2p_math_selftest(int device, size_t n, unsigned seed, unsigned long long *div_mismatches,
+                      unsigned long long *sqrt_mismatches)
+{
+        int ndev = 0;
+        if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { return fail(J2P_EDEVICE, "no HIP device available"); }
+        DeviceGuard guard(device);
+        if(!guard.ok) { return fail(J2P_EDEVICE, "hipSetDevice(%d) failed", device); }
+        unsigned long long *dm = nullptr, hm[2] = {0, 0};
+        HIP_TRY(hipMalloc(&dm, sizeof(hm)));
+        hipError_t e = hipMemset(dm, 0, sizeof(hm));
+        if(e == hipSuccess) {
+                hipLaunchKernelGGL(k_math_selftest, dim3(4096), dim3(256), 0, nullptr, n, seed, dm);
+                e = hipMemcpy(hm, dm, sizeof(hm), hipMemcpyDeviceToHost);
+        }
+        (void)hipFree(dm);
+        if(e != hipSuccess) { return fail(J2P_EDEVICE, "math_selftest: %s", hipGetErrorString(e)); }
+        if(div_mismatches) { *div_mismatches = hm[0]; }
+        if(sqrt_mismatches) { *sqrt_mismatches = hm[1]; }
+        return J2P_OK;
 }
 
 }  // extern "C"

@@ -29,6 +29,14 @@ def test_dct_blocks_bit_exact(lib, oracle):
     assert bit_equal(j.dct8x8_blocks(b, inverse=True), oracle.dct_blocks(b, inverse=True))
 
 
+def test_fast_division_and_sqrt_are_ieee(lib):
+    """the gradient kernel's shared-reciprocal division and its square root must agree bit for
+    bit with `/` and sqrtf() over the operand range the kernel screens for"""
+    import jpeg2png_amd as j
+    for seed in (1, 2, 3):
+        assert j.math_selftest(1 << 26, seed=seed) == (0, 0)
+
+
 def test_decode_plane_bit_exact(lib, oracle):
     import jpeg2png_amd as j
     from jpeg2png_amd import synth
