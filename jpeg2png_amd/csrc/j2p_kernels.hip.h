@@ -154,7 +154,8 @@ struct Geo {
         unsigned W, H;      // canvas
         unsigned row0;      // first canvas row of the band
         unsigned rows;      // band rows
-        unsigned ntx;       // gradient tiles per tile row
+        unsigned ntx;       // gradient strips (wavefronts) per row of strips
+        unsigned rpw;       // rows per gradient strip (multiple of kTY)
 };
 
 struct GradArgs {
@@ -286,7 +287,6 @@ __device__ __forceinline__ v2f sqrt_fast(v2f x)
         return r;
 }
 
-constexpr int kRPW = 32;          // rows per wavefront strip (multiple of kTY)
 constexpr int kStripCols = 124;   // output columns per wavefront strip
 
 template <int NCH, bool TGV>
@@ -382,8 +382,9 @@ __global__ __launch_bounds__(256, (NCH == 1 ? 5 : NCH == 2 ? 3 : 2)) void k_grad
         if(wcol >= (int)a.geo.ntx) { return; }
         const int W = (int)a.geo.W, H = (int)a.geo.H;
         const int rows = (int)a.geo.rows, row0 = (int)a.geo.row0;
-        const int t0 = (int)blockIdx.y * kRPW;                 // band-local target rows [t0, t1)
-        const int t1 = t0 + kRPW < rows ? t0 + kRPW : rows;
+        const int rpw = (int)a.geo.rpw;
+        const int t0 = (int)blockIdx.y * rpw;                  // band-local target rows [t0, t1)
+        const int t1 = t0 + rpw < rows ? t0 + rpw : rows;
         const int xl = wcol * kStripCols - 2 + lane * 2;       // canvas column of .x (even; W is even too)
 
         const bool pair_in = xl >= 0 && xl < W;                // both columns in the image, or neither
@@ -420,8 +421,23 @@ __global__ __launch_bounds__(256, (NCH == 1 ? 5 : NCH == 2 ? 3 : 2)) void k_grad
                 }
         };
 
+        // prob-gradient state of one target row (compute.c:53-66: replicated over the sample's footprint)
+        auto load_p = [&](int lt, v2f (&pv)[NCH]) {
+                const int gt = row0 + lt;
+#pragma unroll
+                for(int c = 0; c < NCH; c++) {
+                        const ChanDev &k = a.ch[c];
+                        pv[c] = v2f{0.f, 0.f};
+                        if(k.prob_on && pair_own && lt < t1 && (unsigned)gt < k.ch * k.hs && (unsigned)xl < k.cw * k.ws) {
+                                const float *prow = k.pg + (size_t)((unsigned)gt / k.hs - k.crow0) * k.cw;
+                                if(k.ws == 1) { pv[c] = *reinterpret_cast<const v2f *>(prow + xl); }
+                                else { pv[c] = v2f{prow[(unsigned)xl / k.ws], prow[(unsigned)(xl + 1) / k.ws]}; }
+                        }
+                }
+        };
+
         // ring of three row slots
-        v2f Y[3][NCH], GX[3][NCH], GY[3][NCH];
+        v2f Y[3][NCH], GX[3][NCH], GY[3][NCH], PV[3][NCH];
         bool bad[3];
         SourceTerms<NCH, TGV> S[3];
         {
@@ -447,6 +463,7 @@ __global__ __launch_bounds__(256, (NCH == 1 ? 5 : NCH == 2 ? 3 : 2)) void k_grad
                 const bool prev_bad = bad[P2];                 // row r-1, about to be overwritten by the prefetch
                 // prefetch y[r+2] for the next trip; past the halo nothing is needed (maps to a row < 0)
                 load_y(r + 2 <= t1 + 1 ? r + 2 : -(int)kHalo - 1 - row0, Y[P2], bad[P2]);
+                if(r >= t0) { load_p(r, PV[P]); }              // target row of the NEXT trip
                 SourceTerms<NCH, TGV> &s = S[P];
                 diffs(gr, Y[P], Y[P1], GX[P], GY[P]);
                 if(gr >= 0 && gr < H) {                        // wave-uniform
@@ -472,18 +489,11 @@ __global__ __launch_bounds__(256, (NCH == 1 ? 5 : NCH == 2 ? 3 : 2)) void k_grad
                 const int t = r - 1;
                 if(t >= t0) {
                         const SourceTerms<NCH, TGV> &up = S[P1], &mid = S[P2];
-                        const int gt = row0 + t;
 #pragma unroll
                         for(int c = 0; c < NCH; c++) {
                                 const ChanDev &k = a.ch[c];
                                 v2f g = v2f{0.f, 0.f};
-                                if(k.prob_on && pair_own && (unsigned)gt < k.ch * k.hs && (unsigned)xl < k.cw * k.ws) {
-                                        const float *prow = k.pg + (size_t)((unsigned)gt / k.hs - k.crow0) * k.cw;
-                                        v2f pv;
-                                        if(k.ws == 1) { pv = *reinterpret_cast<const v2f *>(prow + xl); }
-                                        else { pv = v2f{prow[(unsigned)xl / k.ws], prow[(unsigned)(xl + 1) / k.ws]}; }
-                                        g += k.p_alpha * pv;
-                                }
+                                if(k.prob_on) { g += k.p_alpha * PV[P2][c]; }   // loaded one trip ago
                                 g += up.tvy[c];                  // TV from (x, t-1)
                                 g += mid.tvxL[c];                // TV from (x-1, t)
                                 g += mid.tvo[c];                 // TV own
@@ -613,6 +623,16 @@ __global__ __launch_bounds__(256) void k_log_sums(const double *part_tv, unsigne
 // Phase B: step + projection.  One wavefront = one strip of 8 coefficient
 // blocks (64 coefficient columns x 8 coefficient rows); a lane owns one
 // coefficient column for the column passes and one block row for the row passes.
+//
+// The three divisions of this phase — g/||g|| (compute.c:213), (cos-dq)/q^2
+// (compute.c:49) and, when logging, (cos-dq)/q (compute_simd_step.c:22) — have
+// a wave-uniform or per-coefficient-position denominator, so the refined
+// reciprocal of the IEEE division sequence is computed once (per wave / per
+// table entry) and every quotient costs five packed fma.  As in phase A the
+// short sequence equals `/` bit for bit whenever the compiler's version would
+// not rescale: denominators in [2^-20, 2^26], numerators 0 or in [2^-100, 2^61)
+// (then quotients are normal and every residual is exact).  Numerators are
+// screened per wavefront, denominators per launch; anything else takes `/`.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float stepped(const ChanDev &k, ptrdiff_t off, float factor, float step, float norm)
 {
@@ -622,19 +642,47 @@ __device__ __forceinline__ float stepped(const ChanDev &k, ptrdiff_t off, float 
         return y;
 }
 
+// numerator screen of the short division: 0 < |x| < 2^-100, |x| >= 2^61, or NaN
+__device__ __forceinline__ bool num_suspect(v2f x)
+{
+        const v2f lo = x * 0x1p-26f, hi = x * 0x1p67f;
+        constexpr int kDenorm = 0x090, kInfNan = 0x207;
+        return __builtin_amdgcn_classf(lo.x, kDenorm) | __builtin_amdgcn_classf(lo.y, kDenorm) |
+               __builtin_amdgcn_classf(hi.x, kInfNan) | __builtin_amdgcn_classf(hi.y, kInfNan);
+}
+__device__ __forceinline__ bool den_ok(float d) { return d >= 0x1p-20f && d <= 0x1p26f; }
+__device__ __forceinline__ float div_prepare1(float d)
+{
+        const float r = __builtin_amdgcn_rcpf(d);
+        return __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r);
+}
+
 template <bool LOG>
 __global__ __launch_bounds__(256) void k_project(ProjArgs a)
 {
         __shared__ __attribute__((aligned(16))) float tp[4 * kTpWave];
-        __shared__ __attribute__((aligned(16))) float qs[64];
+        __shared__ __attribute__((aligned(16))) float qs[64];    // q
+        __shared__ __attribute__((aligned(16))) float qq[64];    // q*q
+        __shared__ __attribute__((aligned(16))) float rqq[64];   // refined 1/(q*q)
+        __shared__ __attribute__((aligned(16))) float rq[64];    // refined 1/q   (log only)
+        __shared__ int q_fast;
 
         const int c = (int)blockIdx.z;
         const ChanDev &k = a.ch[c];
         const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-        if(threadIdx.x < 64) { qs[threadIdx.x] = k.q[threadIdx.x]; }
+        if(threadIdx.x < 64) {
+                const float q = k.q[threadIdx.x];
+                qs[threadIdx.x] = q;
+                qq[threadIdx.x] = q * q;
+                rqq[threadIdx.x] = div_prepare1(q * q);
+                rq[threadIdx.x] = div_prepare1(q);
+                const bool ok = den_ok(q * q) && den_ok(q);
+                const unsigned long long all_ok = __builtin_amdgcn_ballot_w64(ok);
+                if(threadIdx.x == 0) { q_fast = all_ok == ~0ull; }
+        }
         __syncthreads();
 
-        const unsigned W = a.geo.W, H = a.geo.H;
+        const unsigned W = a.geo.W;
         const unsigned ws = k.ws, hs = k.hs;
         const unsigned strips_x = (W + 64 * ws - 1) / (64 * ws);      // strips across the canvas
         const unsigned brows = (a.geo.rows + 8 * hs - 1) / (8 * hs);  // block rows in the band
@@ -649,9 +697,47 @@ __global__ __launch_bounds__(256) void k_project(ProjArgs a)
         const bool covered = cx < k.cw && cy0 < k.ch;                 // block-granular: cw, ch multiples of 8
         const unsigned ly0 = by * 8 * hs;                             // band-local canvas row
         const bool direct = ws == 1 && hs == 1;
+        // wave-uniform: the whole 64 x 8 strip is inside the canvas and projected
+        const bool full = direct && sx * 64 + 64 <= k.cw && sx * 64 + 64 <= W && cy0 < k.ch && ly0 + 8 <= a.geo.rows;
 
         float v[8];
-        if(direct) {
+        if(full) {
+                // all 24 loads in flight before the first use
+                float gv[8], xcv[8], xpv[8];
+                const size_t base = (size_t)ly0 * W + cx;
+#pragma unroll
+                for(int r = 0; r < 8; r++) {
+                        gv[r] = k.grad[base + (size_t)r * W];
+                        xcv[r] = k.xcur[base + (size_t)r * W];
+                        xpv[r] = k.xprev[base + (size_t)r * W];
+                }
+                v2f y2[4], g2[4];
+                bool sus = false;
+#pragma unroll
+                for(int p = 0; p < 4; p++) {
+                        const v2f xc = v2f{xcv[2 * p], xcv[2 * p + 1]}, xp = v2f{xpv[2 * p], xpv[2 * p + 1]};
+                        g2[p] = v2f{gv[2 * p], gv[2 * p + 1]};
+                        y2[p] = xc + a.factor * (xc - xp);                  // compute.c:435
+                        sus |= num_suspect(g2[p]);
+                }
+                if(norm != 0.f) {                                           // compute.c:212
+                        if(den_ok(norm) && __builtin_amdgcn_ballot_w64(sus) == 0) {
+                                const v2f nn = v2f{norm, norm};
+                                const float rn1 = div_prepare1(norm);
+                                const v2f rn = v2f{rn1, rn1};
+#pragma unroll
+                                for(int p = 0; p < 4; p++) { y2[p] = y2[p] - a.step * div_shared(g2[p], nn, rn); }
+                        } else {
+#pragma unroll
+                                for(int p = 0; p < 4; p++) { y2[p] = y2[p] - a.step * v2f{g2[p].x / norm, g2[p].y / norm}; }
+                        }
+                }
+#pragma unroll
+                for(int p = 0; p < 4; p++) {
+                        v[2 * p] = y2[p].x;
+                        v[2 * p + 1] = y2[p].y;
+                }
+        } else if(direct) {
                 const bool inside = cx < W;
 #pragma unroll
                 for(int r = 0; r < 8; r++) {
@@ -681,8 +767,10 @@ __global__ __launch_bounds__(256) void k_project(ProjArgs a)
                 }
         }
         float mean_old[8];
+        if(!direct) {
 #pragma unroll
-        for(int r = 0; r < 8; r++) { mean_old[r] = v[r]; }
+                for(int r = 0; r < 8; r++) { mean_old[r] = v[r]; }
+        }
 
         // ---- forward DCT: columns pass (lane = column), transpose, rows pass (lane = block row) ----
         fdct8(v);
@@ -696,29 +784,59 @@ __global__ __launch_bounds__(256) void k_project(ProjArgs a)
         float e[8];
         double dist = 0.;
         {
-                short dd[8];
+                int4 raw = make_int4(0, 0, 0, 0);
                 if(bcov) {
                         const size_t blk = (size_t)(cy0 / 8 - k.crow0 / 8) * (k.cw / 8) + bx;
-                        const int4 raw = *reinterpret_cast<const int4 *>(k.d + blk * 64 + rr * 8);
-                        dd[0] = (short)(raw.x & 0xffff); dd[1] = (short)(raw.x >> 16);
-                        dd[2] = (short)(raw.y & 0xffff); dd[3] = (short)(raw.y >> 16);
-                        dd[4] = (short)(raw.z & 0xffff); dd[5] = (short)(raw.z >> 16);
-                        dd[6] = (short)(raw.w & 0xffff); dd[7] = (short)(raw.w >> 16);
-                } else {
-#pragma unroll
-                        for(int u = 0; u < 8; u++) { dd[u] = 0; }
+                        raw = *reinterpret_cast<const int4 *>(k.d + blk * 64 + rr * 8);
                 }
+                const int rw[4] = {raw.x, raw.y, raw.z, raw.w};
+                v2f t2[4], q2[4];
+                bool sus = false;
 #pragma unroll
-                for(int u = 0; u < 8; u++) {
-                        const float q = qs[rr * 8 + u];
-                        const float df = (float)dd[u];
-                        const float lo = (df - 0.5f) * q, hi = (df + 0.5f) * q;
-                        float x = v[u];
-                        x = x > hi ? hi : (x < lo ? lo : x);
-                        v[u] = x;
-                        const float t = x - df * q;
-                        if(LOG) { const float tq = t / q; dist += (double)(tq * tq); }   // compute_simd_step.c:22-26
-                        e[u] = t / (q * q);
+                for(int p = 0; p < 4; p++) {
+                        // two int16 per dword: low half = even coefficient
+                        const v2f df = v2f{(float)(short)(rw[p] & 0xffff), (float)(rw[p] >> 16)};
+                        const v2f q = *reinterpret_cast<const v2f *>(&qs[rr * 8 + 2 * p]);
+                        const v2f lo = (df - 0.5f) * q, hi = (df + 0.5f) * q;
+                        v2f x = v2f{v[2 * p], v[2 * p + 1]};
+                        x = v2f{x.x > hi.x ? hi.x : (x.x < lo.x ? lo.x : x.x), x.y > hi.y ? hi.y : (x.y < lo.y ? lo.y : x.y)};
+                        v[2 * p] = x.x;
+                        v[2 * p + 1] = x.y;
+                        t2[p] = x - df * q;
+                        q2[p] = q;
+                        sus |= num_suspect(t2[p]);
+                }
+                if(k.prob_on) {
+                        if(q_fast && __builtin_amdgcn_ballot_w64(sus) == 0) {
+#pragma unroll
+                                for(int p = 0; p < 4; p++) {
+                                        const v2f d2 = *reinterpret_cast<const v2f *>(&qq[rr * 8 + 2 * p]);
+                                        const v2f r2 = *reinterpret_cast<const v2f *>(&rqq[rr * 8 + 2 * p]);
+                                        const v2f ev = div_shared(t2[p], d2, r2);
+                                        e[2 * p] = ev.x;
+                                        e[2 * p + 1] = ev.y;
+                                        if(LOG) {                                    // compute_simd_step.c:22-26
+                                                const v2f r1 = *reinterpret_cast<const v2f *>(&rq[rr * 8 + 2 * p]);
+                                                const v2f tq = div_shared(t2[p], q2[p], r1);
+                                                const v2f sq = tq * tq;
+                                                dist += (double)sq.x;
+                                                dist += (double)sq.y;
+                                        }
+                                }
+                        } else {
+#pragma unroll
+                                for(int p = 0; p < 4; p++) {
+                                        const v2f d2 = q2[p] * q2[p];
+                                        e[2 * p] = t2[p].x / d2.x;
+                                        e[2 * p + 1] = t2[p].y / d2.y;
+                                        if(LOG) {
+                                                const v2f tq = v2f{t2[p].x / q2[p].x, t2[p].y / q2[p].y};
+                                                const v2f sq = tq * tq;
+                                                dist += (double)sq.x;
+                                                dist += (double)sq.y;
+                                        }
+                                }
+                        }
                 }
         }
 

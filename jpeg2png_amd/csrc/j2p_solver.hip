@@ -74,6 +74,7 @@ struct j2p_solver {
         int cur = 0;             // xbuf[cur] is x_k
         bool grad_done = false;
         // reductions
+        unsigned rpw = 32;
         unsigned ntx = 0, nseg = 0, ntr_local = 0, ntr_global = 0, first_tr = 0;   // strips per row, row segments
         double *part_g2 = nullptr;       // [c][ntr_local][ntx]
         double *rowsum_local = nullptr;  // [ntr_local][c]
@@ -143,6 +144,7 @@ Geo geo_of(const j2p_solver *s)
         g.row0 = s->row0;
         g.rows = s->rows;
         g.ntx = s->ntx;
+        g.rpw = s->rpw;
         return g;
 }
 
@@ -479,7 +481,14 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         }
         // reductions: tile rows are counted on the canvas, the band owns a contiguous range
         s->ntx = (W + kStripCols - 1) / kStripCols;
-        s->nseg = (s->rows + kRPW - 1) / kRPW;
+        {
+                // rows per gradient strip: a multiple of the 16-row partial granularity
+                const char *env = getenv("J2P_RPW");
+                unsigned rpw = env ? (unsigned)atoi(env) : 32u;
+                if(rpw < (unsigned)kTY) { rpw = kTY; }
+                s->rpw = rpw / kTY * kTY;
+        }
+        s->nseg = (s->rows + s->rpw - 1) / s->rpw;
         s->ntr_local = (s->rows + kTY - 1) / kTY;
         s->ntr_global = (H + kTY - 1) / kTY;
         s->first_tr = row0 / kTY;

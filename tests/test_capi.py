@@ -1,0 +1,114 @@
+"""CPU tests of the C-ABI boundary: the library builds for gfx950 without a GPU, loads, and
+exports every symbol the public headers declare; without a device the product path fails
+loudly instead of falling back."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for h in ("jpeg2png_amd.h", "jpeg2png_amd_compute.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        for m in re.finditer(r"^\s*(?:const\s+)?(?:int|void|char)\s*\*?\s*(j2p_\w+|compute)\s*\(", text, flags=re.M):
+            names.add(m.group(1))
+    return names
+
+
+def test_headers_and_binding_list_agree():
+    import jpeg2png_amd
+    assert declared_symbols() == set(jpeg2png_amd.C_ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"{name} is declared in include/ but not exported"
+
+
+def test_exported_symbols_have_c_linkage(lib):
+    import jpeg2png_amd
+    out = subprocess.run(["nm", "-D", "--defined-only", jpeg2png_amd.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    assert declared_symbols() <= exported
+
+
+def test_version_and_error_strings(lib):
+    assert b"gfx950" in lib.j2p_version()
+    assert isinstance(lib.j2p_last_error(), bytes)
+
+
+def has_gpu():
+    import jpeg2png_amd
+    try:
+        return jpeg2png_amd.device_count() > 0
+    except Exception:
+        return False
+
+
+def test_no_gpu_means_loud_failure(lib):
+    """the product path has no CPU fallback"""
+    if has_gpu():
+        pytest.skip("a GPU is present")
+    import jpeg2png_amd as j
+    from jpeg2png_amd import synth
+    p = synth.make_planes(16, 16, "444", 50, seed=1, y_only=True)[0]
+    p.fdata = np.zeros((16, 16), np.float32)
+    with pytest.raises(j.J2PError, match="no HIP device|no CPU fallback"):
+        j.Solver([p], 0.3, [0.001], 4)
+    with pytest.raises(j.J2PError):
+        j.decode_plane(p)
+    with pytest.raises(j.J2PError):
+        j.dct8x8_blocks(np.zeros((1, 64), np.float32))
+
+
+def test_argument_validation_happens_before_device_use(lib):
+    import jpeg2png_amd as j
+    from jpeg2png_amd import synth
+    p = synth.make_planes(16, 16, "444", 50, seed=1, y_only=True)[0]
+    p.fdata = np.zeros((16, 16), np.float32)
+    bad = synth.Plane(12, 16, 1, 1, p.data, p.quant_table, p.fdata)       # not a multiple of 8 (box.c:6-7)
+    with pytest.raises(j.J2PError, match="multiple of 8"):
+        j.Solver([bad], 0.3, [0.001], 4)
+    zq = synth.Plane(16, 16, 1, 1, p.data, np.zeros(64, np.uint16), p.fdata)   # jpeg.c:41-45
+    with pytest.raises(j.J2PError, match="quantization table"):
+        j.Solver([zq], 0.3, [0.001], 4)
+    with pytest.raises(j.J2PError, match="nchannel"):
+        j.Solver([p, p, p, p], 0.3, [0.001] * 4, 4)
+
+
+def test_missing_library_raises(monkeypatch, tmp_path):
+    import jpeg2png_amd as j
+    monkeypatch.setattr(j, "_lib", None)
+    monkeypatch.setattr(j, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(j.J2PError, match="missing"):
+        j.load_library()
+
+
+def test_drop_in_compute_struct_layout(lib):
+    """struct coef of include/jpeg2png_amd_compute.h must match the reference's layout
+    (jpeg2png.h:7-20): 4 unsigned, two pointers, 64 uint16 = 160 bytes on LP64."""
+    src = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "jpeg2png_amd_compute.h"
+    int main(void) {
+        printf("%zu %zu %zu %zu %zu %zu\n", sizeof(struct coef), offsetof(struct coef, w_samp),
+               offsetof(struct coef, data), offsetof(struct coef, fdata), offsetof(struct coef, quant_table),
+               sizeof(struct logger));
+        return 0;
+    }'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()
+    assert [int(x) for x in out] == [160, 12, 16, 24, 32, 24]
