@@ -45,7 +45,7 @@ def build(force=False, verbose=False):
     cmds = [
         [gcc, "-std=c11", "-O2", "-fPIC", "-Wall", "-Wextra", "-ffp-contract=off", "-I", INCLUDE,
          "-c", os.path.join(CSRC, "compute_host.c"), "-o", obj],
-        [hipcc, *HIP_FLAGS, "-I", INCLUDE, "-I", CSRC, "-c",
+        [hipcc, *HIP_FLAGS, *os.environ.get("J2P_CXXFLAGS", "").split(), "-I", INCLUDE, "-I", CSRC, "-c",
          os.path.join(CSRC, "j2p_solver.hip"), "-o", hobj],
         [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", hobj, obj, "-lpthread", "-o", LIB],
     ]

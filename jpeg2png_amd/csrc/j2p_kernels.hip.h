@@ -374,8 +374,11 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
         }
 }
 
+#ifndef J2P_GRAD_WAVES1
+#define J2P_GRAD_WAVES1 4      // waves per SIMD the 1-channel gradient kernel is register-limited to
+#endif
 template <int NCH, bool TGV, bool LOG>
-__global__ __launch_bounds__(256, (NCH == 1 ? 5 : NCH == 2 ? 3 : 2)) void k_gradient(GradArgs a)
+__global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : 2)) void k_gradient(GradArgs a)
 {
         const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
         const int wcol = (int)blockIdx.x * 4 + wave;
@@ -394,21 +397,26 @@ __global__ __launch_bounds__(256, (NCH == 1 ? 5 : NCH == 2 ? 3 : 2)) void k_grad
         const v2f m_gx = v2f{in_f, xl + 1 >= W - 1 ? 0.f : in_f};   // gx = 0 on the last column (compute.c:79)
         const v2f m_hx = v2f{xl == 0 ? 0.f : in_f, in_f};           // gxx, gyx = 0 on the first column
 
-        // FISTA point of one row for this lane's columns (compute.c:433-439); 0 outside the image
+        // FISTA point of one row for this lane's columns (compute.c:433-439); 0 outside the image.
+        // Lanes left/right of the image read a clamped (valid) address and are zeroed by m_in, so
+        // the only branch is the wave-uniform "row inside the image".
+        const int xl_c = xl < 0 ? 0 : (xl > W - 2 ? W - 2 : xl);
+        const v2f m_in = v2f{in_f, in_f};
         auto load_y = [&](int lr, v2f (&y)[NCH], bool &suspect) {
                 const int gr = row0 + lr;
-                const bool rin = gr >= 0 && gr < H && pair_in;
-                const ptrdiff_t off = (ptrdiff_t)lr * W + xl;
+                const ptrdiff_t off = (ptrdiff_t)lr * W + xl_c;
                 suspect = false;
+                if(gr >= 0 && gr < H) {
 #pragma unroll
-                for(int c = 0; c < NCH; c++) {
-                        v2f xc = v2f{0.f, 0.f}, xp = v2f{0.f, 0.f};
-                        if(rin) {
-                                xc = *reinterpret_cast<const v2f *>(a.ch[c].xcur + off);
-                                xp = *reinterpret_cast<const v2f *>(a.ch[c].xprev + off);
+                        for(int c = 0; c < NCH; c++) {
+                                const v2f xc = *reinterpret_cast<const v2f *>(a.ch[c].xcur + off);
+                                const v2f xp = *reinterpret_cast<const v2f *>(a.ch[c].xprev + off);
+                                y[c] = (xc + a.factor * (xc - xp)) * m_in;
+                                suspect |= y_suspect(y[c]);
                         }
-                        y[c] = xc + a.factor * (xc - xp);
-                        suspect |= y_suspect(y[c]);
+                } else {
+#pragma unroll
+                        for(int c = 0; c < NCH; c++) { y[c] = v2f{0.f, 0.f}; }
                 }
         };
         // forward differences of row gr given rows gr and gr+1 (compute.c:79,81)
@@ -466,9 +474,11 @@ __global__ __launch_bounds__(256, (NCH == 1 ? 5 : NCH == 2 ? 3 : 2)) void k_grad
                 if(r >= t0) { load_p(r, PV[P]); }              // target row of the NEXT trip
                 SourceTerms<NCH, TGV> &s = S[P];
                 diffs(gr, Y[P], Y[P1], GX[P], GY[P]);
-                if(gr >= 0 && gr < H) {                        // wave-uniform
+                {
+                        // A row above or below the image needs no special case: its y is 0, m_gy zeroes
+                        // its gy, and hy = 0 zeroes its gxy/gyy, so every term comes out 0.
                         const bool log_row = LOG && pair_own && r >= t0 && r < t1;
-                        const float hy = gr == 0 ? 0.f : in_f;  // gxy, gyy = 0 on the first row
+                        const float hy = gr <= 0 || gr >= H ? 0.f : in_f;  // gxy, gyy = 0 on the first row (compute.c:141-143)
                         const v2f m_hy = v2f{hy, hy};
                         if(__builtin_amdgcn_ballot_w64(prev_bad | bad[P] | bad[P1]) == 0) {
                                 source_terms<NCH, TGV, LOG, true>(GX[P], GY[P], GX[P2], GY[P2], m_hx, m_hy, a.a_tv, a.a_tgv,
@@ -476,13 +486,6 @@ __global__ __launch_bounds__(256, (NCH == 1 ? 5 : NCH == 2 ? 3 : 2)) void k_grad
                         } else {
                                 source_terms<NCH, TGV, LOG, false>(GX[P], GY[P], GX[P2], GY[P2], m_hx, m_hy, a.a_tv, a.a_tgv,
                                                                    log_row, tv_acc, tv2_acc, s);
-                        }
-                } else {
-                        // a row above or below the image contributes nothing
-#pragma unroll
-                        for(int c = 0; c < NCH; c++) {
-                                s.tvxL[c] = s.tvo[c] = s.tvy[c] = v2f{0.f, 0.f};
-                                if(TGV) { s.AL[c] = s.AR[c] = s.O[c] = s.B[c] = s.CL[c] = s.CR[c] = v2f{0.f, 0.f}; }
                         }
                 }
                 // ---- target row t = r-1: rows t-1, t, t+1 live in slots P1, P2, P ----
@@ -593,6 +596,26 @@ __global__ __launch_bounds__(256) void k_norm_finish(const double *rowsum_all, u
         for(unsigned i = threadIdx.x; i < P; i += 256) { buf[i] = i < nrows_global ? src[(size_t)i * nch] : 0.; }
         const double s = tree_sum_lds(buf, nrows_global, P);
         if(threadIdx.x == 0) { norm[blockIdx.x] = sqrtf((float)s); }
+}
+
+// whole-canvas solver: both levels in one launch (one block per channel), same arithmetic
+__global__ __launch_bounds__(256) void k_norm_whole(const double *part, unsigned ntx, unsigned nrows, unsigned nch, float *norm)
+{
+        extern __shared__ __attribute__((aligned(16))) float smem[];
+        double *buf = reinterpret_cast<double *>(smem);
+        const unsigned c = blockIdx.x;
+        unsigned P = 1;
+        while(P < nrows) { P <<= 1; }
+        for(unsigned r = threadIdx.x; r < P; r += 256) {
+                double s = 0.;
+                if(r < nrows) {
+                        const double *p = part + ((size_t)c * nrows + r) * ntx;
+                        for(unsigned t = 0; t < ntx; t++) { s += p[t]; }
+                }
+                buf[r] = s;
+        }
+        const double s = tree_sum_lds(buf, nrows, P);
+        if(threadIdx.x == 0) { norm[c] = sqrtf((float)s); }
 }
 
 // log sums: tv / tv2 from the gradient tiles and per-channel prob distance from the

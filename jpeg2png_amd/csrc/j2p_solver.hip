@@ -74,7 +74,7 @@ struct j2p_solver {
         int cur = 0;             // xbuf[cur] is x_k
         bool grad_done = false;
         // reductions
-        unsigned rpw = 32;
+        unsigned rpw = 16;
         unsigned ntx = 0, nseg = 0, ntr_local = 0, ntr_global = 0, first_tr = 0;   // strips per row, row segments
         double *part_g2 = nullptr;       // [c][ntr_local][ntx]
         double *rowsum_local = nullptr;  // [ntr_local][c]
@@ -220,9 +220,11 @@ int do_phase_gradient(j2p_solver *s, bool log)
         default: launch_gradient_n<3>(a, grid, s->stream, tgv, log); break;
         }
         mark(s);
-        const unsigned nrs = s->ntr_local * s->nch;
-        hipLaunchKernelGGL(k_rowsums, dim3((nrs + 255) / 256), dim3(256), 0, s->stream,
-                           (const double *)s->part_g2, s->rowsum_local, s->ntx, s->ntr_local, s->nch);
+        if(!s->whole) {
+                const unsigned nrs = s->ntr_local * s->nch;
+                hipLaunchKernelGGL(k_rowsums, dim3((nrs + 255) / 256), dim3(256), 0, s->stream,
+                                   (const double *)s->part_g2, s->rowsum_local, s->ntx, s->ntr_local, s->nch);
+        }
         HIP_TRY(hipGetLastError());
         s->grad_done = true;
         return J2P_OK;
@@ -233,8 +235,13 @@ int do_phase_project(j2p_solver *s, bool log)
         if(!s->grad_done) { return fail(J2P_ESTATE, "phase_project called before phase_gradient"); }
         unsigned P = 1;
         while(P < s->ntr_global) { P <<= 1; }
-        hipLaunchKernelGGL(k_norm_finish, dim3(s->nch), dim3(256), P * sizeof(double), s->stream,
-                           (const double *)s->rowsum_all, s->ntr_global, s->nch, s->norm);
+        if(s->whole) {
+                hipLaunchKernelGGL(k_norm_whole, dim3(s->nch), dim3(256), P * sizeof(double), s->stream,
+                                   (const double *)s->part_g2, s->ntx, s->ntr_local, s->nch, s->norm);
+        } else {
+                hipLaunchKernelGGL(k_norm_finish, dim3(s->nch), dim3(256), P * sizeof(double), s->stream,
+                                   (const double *)s->rowsum_all, s->ntr_global, s->nch, s->norm);
+        }
         ProjArgs a;
         unsigned max_strips = 0;
         for(unsigned c = 0; c < s->nch; c++) {
@@ -484,7 +491,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         {
                 // rows per gradient strip: a multiple of the 16-row partial granularity
                 const char *env = getenv("J2P_RPW");
-                unsigned rpw = env ? (unsigned)atoi(env) : 32u;
+                unsigned rpw = env ? (unsigned)atoi(env) : 16u;
                 if(rpw < (unsigned)kTY) { rpw = kTY; }
                 s->rpw = rpw / kTY * kTY;
         }
