@@ -182,6 +182,16 @@ def main():
         else:
             kern, dur_ms, bpp = "k_project", p_ms, BYTES_PROJECT
         achieved = band_px * bpp / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+        # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/, corrected as
+        # MI355X_MICROARCH.md prescribes); only meaningful for the N=1 workload they were taken on
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if n_gpus == 1 and not a.size and os.path.exists(pmc):
+            with open(pmc) as f:
+                summ = json.load(f)
+            for name, v in summ.items():
+                if isinstance(v, dict) and name.startswith("j2p::" + kern) and "hbm_bytes_per_launch" in v:
+                    traffic, traffic_src = v["hbm_bytes_per_launch"], "profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE)"
         out = {
             "metric": "Mpixel-iterations/sec on 4K Y-plane", "value": round(value, 1),
             "unit": "Mpixel-iterations/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
@@ -190,7 +200,8 @@ def main():
             "config": {"workload": workload, "iterations_per_step": its, "weight": WEIGHT, "pweight": PWEIGHT,
                        "parallelism": "single GPU" if n_gpus == 1 else f"row-tiled x{n_gpus}, RCCL halo + norm all-gather"},
             "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": band_px * bpp,
                          "avg_launch_ms": {"k_gradient": round(g_ms, 4), "k_project": round(p_ms, 4)},
                          "event_samples": samples,

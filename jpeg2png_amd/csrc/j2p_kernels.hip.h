@@ -558,17 +558,28 @@ __global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : 2
 // a function of the GLOBAL array only, so the value does not depend on how many
 // GPUs produced the rows.
 // ---------------------------------------------------------------------------
+// level 1: the strips of one row of tiles.  Eight interleaved running sums (so that the
+// loads pipeline), combined pairwise — a fixed function of the array, whoever evaluates it.
+__device__ __forceinline__ double strip_sum(const double *p, unsigned n)
+{
+        double s[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+        unsigned t = 0;
+        for(; t + 8 <= n; t += 8) {
+#pragma unroll
+                for(int j = 0; j < 8; j++) { s[j] += p[t + j]; }
+        }
+        for(unsigned j = 0; t + j < n; j++) { s[j] += p[t + j]; }
+        return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
 __global__ __launch_bounds__(256) void k_rowsums(const double *part, double *rowsum, unsigned ntx, unsigned nrows_local, unsigned nch)
 {
-        // part: [c][local tile row][tile col] -> rowsum: [local tile row][c]  (tile-row major, so that
+        // part: [c][local tile row][strip] -> rowsum: [local tile row][c]  (tile-row major, so that
         // concatenating the bands of consecutive GPUs yields the global array)
         const unsigned i = blockIdx.x * 256 + threadIdx.x;
         if(i >= nrows_local * nch) { return; }
         const unsigned c = i / nrows_local, r = i % nrows_local;
-        const double *p = part + (size_t)i * ntx;
-        double s = 0.;
-        for(unsigned t = 0; t < ntx; t++) { s += p[t]; }
-        rowsum[(size_t)r * nch + c] = s;
+        rowsum[(size_t)r * nch + c] = strip_sum(part + (size_t)i * ntx, ntx);
 }
 
 constexpr int kMaxTileRows = 4096;   // canvas height <= 65536 (JPEG limit) / kTY
@@ -607,12 +618,7 @@ __global__ __launch_bounds__(256) void k_norm_whole(const double *part, unsigned
         unsigned P = 1;
         while(P < nrows) { P <<= 1; }
         for(unsigned r = threadIdx.x; r < P; r += 256) {
-                double s = 0.;
-                if(r < nrows) {
-                        const double *p = part + ((size_t)c * nrows + r) * ntx;
-                        for(unsigned t = 0; t < ntx; t++) { s += p[t]; }
-                }
-                buf[r] = s;
+                buf[r] = r < nrows ? strip_sum(part + ((size_t)c * nrows + r) * ntx, ntx) : 0.;
         }
         const double s = tree_sum_lds(buf, nrows, P);
         if(threadIdx.x == 0) { norm[c] = sqrtf((float)s); }
