@@ -182,3 +182,129 @@ def test_band_split_matches_whole(lib, oracle):
         for s in bands:
             s.close()
     assert bit_equal(got, want)
+
+
+def test_drop_in_compute_from_c(lib, oracle, tmp_path):
+    """the C `compute()` with the reference's signature, called from a C host program that
+    provides logger_log / progressbar_inc like jpeg2png.c does: planes, canvas size rewrite,
+    one log row and one progress tick per iteration (compute.c:428,272,449-452,455-461)."""
+    import os
+    import struct
+    import subprocess
+    import jpeg2png_amd as j
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "dropin"
+    subprocess.run(["gcc", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "dropin_main.c"),
+                    "-o", str(exe), j.LIB_PATH, "-Wl,-rpath," + os.path.dirname(j.LIB_PATH)], check=True)
+    planes = make_case(72, 40, "420", 10, seed=31)
+    its, weight, pw = 37, 0.3, [0.001, 0.001, 0.001]       # 37: not a multiple of the host chunk size
+    blob = struct.pack("<IIf3f", len(planes), its, weight, *pw)
+    for p in planes:
+        blob += struct.pack("<4I", p.w, p.h, p.w_samp, p.h_samp)
+        blob += np.ascontiguousarray(p.data, np.int16).tobytes() + np.ascontiguousarray(p.fdata, np.float32).tobytes()
+        blob += np.ascontiguousarray(p.quant_table, np.uint16).tobytes()
+    (tmp_path / "in.bin").write_bytes(blob)
+    subprocess.run([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "log.csv")], check=True)
+    want, want_log = oracle.oracle_compute(planes, weight, pw, its, log=True)
+    raw = (tmp_path / "out.bin").read_bytes()
+    ticks = struct.unpack_from("<I", raw, 0)[0]
+    assert ticks == its
+    off = 4
+    cw, ch = oracle.canvas_size(planes)
+    for c in range(len(planes)):
+        w, h = struct.unpack_from("<II", raw, off)
+        off += 8
+        assert (w, h) == (cw, ch)
+        got = np.frombuffer(raw, np.float32, w * h, off).reshape(h, w)
+        off += 4 * w * h
+        assert bit_equal(got, want[c])
+    rows = np.loadtxt(tmp_path / "log.csv", delimiter=",", skiprows=1, usecols=(2, 3, 4, 5, 6), ndmin=2)
+    assert rows.shape == (its, 5)
+    assert np.array_equal(rows[:, 0], np.arange(its))
+    np.testing.assert_allclose(rows[:, 1:], want_log, rtol=0, atol=1e-6 * max(1.0, np.abs(want_log).max()))
+
+
+def test_drop_in_compute_dies_like_the_reference(lib, tmp_path):
+    """precondition violations end in `jpeg2png: <message>` + exit(EXIT_FAILURE) (utils.c:20-28)"""
+    import os
+    import struct
+    import subprocess
+    import jpeg2png_amd as j
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "dropin"
+    subprocess.run(["gcc", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "dropin_main.c"),
+                    "-o", str(exe), j.LIB_PATH, "-Wl,-rpath," + os.path.dirname(j.LIB_PATH)], check=True)
+    blob = struct.pack("<IIf3f", 1, 3, 0.3, 0.001, 0, 0) + struct.pack("<4I", 8, 8, 1, 1)
+    blob += np.zeros(64, np.int16).tobytes() + np.zeros(64, np.float32).tobytes() + np.zeros(64, np.uint16).tobytes()
+    (tmp_path / "in.bin").write_bytes(blob)          # all-zero quant table: invalid (jpeg.c:41-45)
+    r = subprocess.run([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "o"), str(tmp_path / "l")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1
+    assert r.stderr.startswith("jpeg2png: ")
+
+
+def test_tiled_engine_on_one_gpu(lib, oracle):
+    """the row-tiling driver's HIP engine: device memory aliased as torch tensors, two bands on
+    one GPU exchanging halos / partials through those tensors, and a world-size-1 RCCL group
+    driving RowTiledSolver end to end.  Both must reproduce the whole-canvas solver bit for bit."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import jpeg2png_amd as j
+    from jpeg2png_amd import tiled
+    W, H, its = 160, 128, 5
+    planes = make_case(W, H, "444", 10, seed=41, y_only=True)
+    with j.Solver(planes, 0.3, [0.001], its) as whole:
+        whole.run(its)
+        want = whole.download(0)
+
+    def band_planes(r0, r1):
+        p = planes[0]
+        d = p.data.reshape(p.h // 8, -1)[r0 // 8:r1 // 8].reshape(-1)
+        return [j.Plane(p.w, p.h, 1, 1, d, p.quant_table, p.fdata[r0:r1])]
+
+    # (a) two engines, exchanges done by hand through the aliased tensors
+    bands = [(0, 64), (64, 128)]
+    eng = [tiled.HipBandEngine(band_planes(*b), 0.3, [0.001], its, b, 0) for b in bands]
+    try:
+        def halo_swap():
+            h0, h1 = eng[0].halo(), eng[1].halo()
+            with eng[0].stream_context():
+                torch.cuda.synchronize()
+                h1["recv_top"][0].copy_(h0["send_bottom"][0])
+                h0["recv_bottom"][0].copy_(h1["send_top"][0])
+                torch.cuda.synchronize()
+        halo_swap()
+        for e in eng:
+            e.commit_initial_halo()
+        for _ in range(its):
+            for e in eng:
+                e.phase_gradient()
+            torch.cuda.synchronize()
+            allp = torch.cat([e.partials_local for e in eng])
+            for e in eng:
+                e.partials_all.copy_(allp)
+            torch.cuda.synchronize()
+            for e in eng:
+                e.phase_project()
+            halo_swap()
+        got = np.concatenate([e.download(0) for e in eng], axis=0)
+    finally:
+        for e in eng:
+            e.close()
+    assert bit_equal(got, want)
+
+    # (b) the real driver over a 1-rank RCCL group
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29731")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        e = tiled.HipBandEngine(band_planes(0, H), 0.3, [0.001], its, (0, H), 0)
+        drv = tiled.RowTiledSolver(e)
+        drv.start()
+        drv.iterate(its)
+        got1 = e.download(0)
+        e.close()
+    finally:
+        dist.destroy_process_group()
+    assert bit_equal(got1, want)
