@@ -176,6 +176,7 @@ struct ProjArgs {
         const float *norm;  // [c] ||g||  (compute.c:210)
         double *part_prob;  // [c][strip]  (LOG only)
         unsigned strips_per_chan;   // stride of part_prob
+        unsigned chan_of_z[kMaxCh]; // channel handled by blockIdx.z (channels are launched grouped by sampling)
 };
 
 // rows per norm partial: the granularity of the GPU-count invariant reduction (J2P_TILE_ROWS)
@@ -292,7 +293,7 @@ constexpr int kStripCols = 124;   // output columns per wavefront strip
 template <int NCH, bool TGV>
 struct SourceTerms {
         v2f tvxL[NCH], tvo[NCH], tvy[NCH];                        // TV: from (x-1), own, to the row below
-        v2f AL[NCH], AR[NCH], O[NCH], B[NCH], CL[NCH], CR[NCH];   // TGV2
+        v2f A[NCH], O[NCH], B[NCH], CL[NCH], CR[NCH];             // TGV2 (A is shifted left/right at its use)
 };
 
 template <bool FAST>
@@ -334,6 +335,7 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
         const v2f r1 = FAST ? div_prepare(d1) : d1;
 #pragma unroll
         for(int c = 0; c < NCH; c++) {
+                if(NCH > 1) { __builtin_amdgcn_sched_barrier(0); }   // one channel at a time: bounds the live ranges
                 s.tvxL[c] = left_of(div_pair<FAST>(a1 * gx[c], d1, r1));
                 s.tvy[c] = div_pair<FAST>(a1 * gy[c], d1, r1);
                 s.tvo[c] = div_pair<FAST>(a1 * -(gx[c] + gy[c]), d1, r1);
@@ -361,13 +363,13 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
                 const v2f r2 = FAST ? div_prepare(d2) : d2;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
+                        if(NCH > 1) { __builtin_amdgcn_sched_barrier(0); }
                         // a2 * (expr / n2): division first (compute.c:165-182)
                         const v2f tA = a2 * div_pair<FAST>(sy[c] + xx[c], d2, r2);        // to (x-1,y), (x+1,y)
                         s.B[c] = a2 * div_pair<FAST>(yy[c] + sy[c], d2, r2);              // to (x,y-1), (x,y+1)
                         const v2f tC = a2 * div_pair<FAST>(-sy[c], d2, r2);               // to (x+1,y-1), (x-1,y+1)
                         s.O[c] = a2 * div_pair<FAST>(-(2.f * xx[c] + 2.f * sy[c] + 2.f * yy[c]), d2, r2);
-                        s.AL[c] = left_of(tA);
-                        s.AR[c] = right_of(tA);
+                        s.A[c] = tA;
                         s.CL[c] = left_of(tC);
                         s.CR[c] = right_of(tC);
                 }
@@ -503,9 +505,9 @@ __global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : 2
                                 if(TGV) {
                                         g += up.B[c];            // (x,   t-1)
                                         g += up.CR[c];           // (x+1, t-1)
-                                        g += mid.AL[c];          // (x-1, t)
+                                        g += left_of(mid.A[c]);  // (x-1, t)
                                         g += mid.O[c];           // own
-                                        g += mid.AR[c];          // (x+1, t)
+                                        g += right_of(mid.A[c]); // (x+1, t)
                                         g += s.CL[c];            // (x-1, t+1)
                                         g += s.B[c];             // (x,   t+1)
                                 }
@@ -686,7 +688,105 @@ __device__ __forceinline__ float div_prepare1(float d)
         return __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r);
 }
 
-template <bool LOG>
+
+// Phase B front/back end for a SUBSAMPLED channel whose 64 x 8 coefficient strip lies wholly
+// inside the canvas: lane = coefficient column = WS canvas columns, 8*HS canvas rows.
+// Keeps the stepped pixels in registers between the block-mean (compute.c:348-360) and the
+// add-back of the new mean onto the residual (compute.c:361-368, 390-402).
+template <int WS, int HS>
+struct SubTile {
+        float f[8 * HS][WS];
+};
+
+template <int WS, int HS>
+__device__ __forceinline__ void sub_load_step_mean(const ChanDev &k, size_t base /* (row, col) of the lane's first pixel */,
+                                                   unsigned W, float factor, float step, float norm,
+                                                   SubTile<WS, HS> &t, float (&mean)[8])
+{
+        typedef float vws __attribute__((ext_vector_type(WS)));
+        const bool have_norm = norm != 0.f;                                   // compute.c:212
+        const bool fast = den_ok(norm);
+        const float rn = fast ? div_prepare1(norm) : 0.f;
+#pragma unroll
+        for(int half = 0; half < 2; half++) {
+                // half the rows at a time: bounds the registers held by loads in flight
+                vws gv[4 * HS], xc[4 * HS], xp[4 * HS];
+#pragma unroll
+                for(int i = 0; i < 4 * HS; i++) {
+                        const size_t off = base + (size_t)(half * 4 * HS + i) * W;
+                        gv[i] = *reinterpret_cast<const vws *>(k.grad + off);
+                        xc[i] = *reinterpret_cast<const vws *>(k.xcur + off);
+                        xp[i] = *reinterpret_cast<const vws *>(k.xprev + off);
+                }
+                bool sus = false;
+                if(WS == 2) {
+#pragma unroll
+                        for(int i = 0; i < 4 * HS; i++) { sus |= num_suspect(v2f{gv[i][0], gv[i][WS - 1]}); }
+                } else {
+#pragma unroll
+                        for(int i = 0; i < 4 * HS; i += 2) { sus |= num_suspect(v2f{gv[i][0], gv[i + 1][0]}); }
+                }
+                const bool use_fast = fast && __builtin_amdgcn_ballot_w64(sus) == 0;
+#pragma unroll
+                for(int i = 0; i < 4 * HS; i++) {
+                        vws y = xc[i] + factor * (xc[i] - xp[i]);                 // compute.c:435
+                        if(have_norm) {
+                                vws q;
+                                if(use_fast) {
+                                        if(WS == 2) {
+                                                const v2f qq = div_shared(v2f{gv[i][0], gv[i][WS - 1]}, v2f{norm, norm}, v2f{rn, rn});
+                                                q[0] = qq.x;
+                                                q[WS - 1] = qq.y;
+                                        } else {
+                                                const v2f qq = div_shared(v2f{gv[i][0], 0.f}, v2f{norm, norm}, v2f{rn, rn});
+                                                q[0] = qq.x;
+                                        }
+                                } else {
+#pragma unroll
+                                        for(int j = 0; j < WS; j++) { q[j] = gv[i][j] / norm; }
+                                }
+                                y = y - step * q;                                     // compute.c:213
+                        }
+#pragma unroll
+                        for(int j = 0; j < WS; j++) { t.f[half * 4 * HS + i][j] = y[j]; }
+                }
+        }
+#pragma unroll
+        for(int r = 0; r < 8; r++) {
+                float m = 0.f;
+#pragma unroll
+                for(int sy = 0; sy < HS; sy++) {
+#pragma unroll
+                        for(int sx = 0; sx < WS; sx++) { m += t.f[r * HS + sy][sx]; }
+                }
+                mean[r] = m / (float)(WS * HS);
+        }
+}
+
+template <int WS, int HS>
+__device__ __forceinline__ void sub_store_residual(const ChanDev &k, size_t base, unsigned W, const SubTile<WS, HS> &t,
+                                                   const float (&mean_old)[8], const float (&mean_new)[8])
+{
+        typedef float vws __attribute__((ext_vector_type(WS)));
+#pragma unroll
+        for(int r = 0; r < 8; r++) {
+#pragma unroll
+                for(int sy = 0; sy < HS; sy++) {
+                        vws o;
+#pragma unroll
+                        for(int sx = 0; sx < WS; sx++) {
+                                const float res = t.f[r * HS + sy][sx] - mean_old[r];     // compute.c:365
+                                o[sx] = res + mean_new[r];                                // compute.c:398
+                        }
+                        *reinterpret_cast<vws *>(k.xprev + base + (size_t)(r * HS + sy) * W) = o;
+                }
+        }
+}
+
+// WS, HS: the subsampling this instantiation has a register-resident fast path for
+// (1,1 = full-resolution channel; 0,0 = any other sampling, generic path only).  Strips that
+// stick out of the canvas or of the channel's coverage always take the generic path.
+template <bool LOG, int WS, int HS>
 __global__ __launch_bounds__(256) void k_project(ProjArgs a)
 {
         __shared__ __attribute__((aligned(16))) float tp[4 * kTpWave];
@@ -696,7 +796,7 @@ __global__ __launch_bounds__(256) void k_project(ProjArgs a)
         __shared__ __attribute__((aligned(16))) float rq[64];    // refined 1/q   (log only)
         __shared__ int q_fast;
 
-        const int c = (int)blockIdx.z;
+        const int c = (int)a.chan_of_z[blockIdx.z];
         const ChanDev &k = a.ch[c];
         const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
         if(threadIdx.x < 64) {
@@ -727,10 +827,20 @@ __global__ __launch_bounds__(256) void k_project(ProjArgs a)
         const unsigned ly0 = by * 8 * hs;                             // band-local canvas row
         const bool direct = ws == 1 && hs == 1;
         // wave-uniform: the whole 64 x 8 strip is inside the canvas and projected
-        const bool full = direct && sx * 64 + 64 <= k.cw && sx * 64 + 64 <= W && cy0 < k.ch && ly0 + 8 <= a.geo.rows;
+        const bool full = WS == 1 && HS == 1 && direct && sx * 64 + 64 <= k.cw && sx * 64 + 64 <= W && cy0 < k.ch &&
+                          ly0 + 8 <= a.geo.rows;
+
+        // subsampled channel, strip wholly inside canvas and coverage: register-resident fast path
+        constexpr bool kSub = WS * HS > 1;
+        const bool fullsub = kSub && ws == (unsigned)WS && hs == (unsigned)HS && sx * 64 + 64 <= k.cw &&
+                             (sx * 64 + 64) * ws <= W && cy0 + 8 <= k.ch && ly0 + 8 * hs <= a.geo.rows;
+        const size_t sub_base = (size_t)ly0 * W + (size_t)cx * ws;
+        SubTile<(kSub ? WS : 1), (kSub ? HS : 1)> tile;
 
         float v[8];
-        if(full) {
+        if(fullsub) {
+                sub_load_step_mean<(kSub ? WS : 1), (kSub ? HS : 1)>(k, sub_base, W, a.factor, a.step, norm, tile, v);
+        } else if(full) {
                 // all 24 loads in flight before the first use
                 float gv[8], xcv[8], xpv[8];
                 const size_t base = (size_t)ly0 * W + cx;
@@ -884,7 +994,9 @@ __global__ __launch_bounds__(256) void k_project(ProjArgs a)
         } else {
                 // back to lane = coefficient column, then add the new mean onto the residual (compute.c:365,398)
                 transpose8(v, scratch, lane);
-                if(covered) {
+                if(fullsub) {
+                        sub_store_residual<(kSub ? WS : 1), (kSub ? HS : 1)>(k, sub_base, W, tile, mean_old, v);
+                } else if(covered) {
 #pragma unroll 1
                         for(int r = 0; r < 8; r++) {
                                 for(unsigned sy = 0; sy < hs; sy++) {

@@ -243,14 +243,7 @@ int do_phase_project(j2p_solver *s, bool log)
                                    (const double *)s->rowsum_all, s->ntr_global, s->nch, s->norm);
         }
         ProjArgs a;
-        unsigned max_strips = 0;
-        for(unsigned c = 0; c < s->nch; c++) {
-                a.ch[c] = chan_dev(s, c);
-                const ChanHost &h = s->ch[c];
-                const unsigned strips_x = (s->W + 64 * h.ws - 1) / (64 * h.ws);
-                const unsigned brows = (s->rows + 8 * h.hs - 1) / (8 * h.hs);
-                if(strips_x * brows > max_strips) { max_strips = strips_x * brows; }
-        }
+        for(unsigned c = 0; c < s->nch; c++) { a.ch[c] = chan_dev(s, c); }
         a.geo = geo_of(s);
         a.factor = s->factor;
         const float radius = sqrtf((float)s->H * (float)s->W) / 2;             // compute.c:425
@@ -258,10 +251,33 @@ int do_phase_project(j2p_solver *s, bool log)
         a.norm = s->norm;
         a.part_prob = s->part_prob;
         a.strips_per_chan = s->strips_stride;
-        dim3 grid((max_strips + 3) / 4, 1, s->nch);
         mark(s);
-        if(log) { hipLaunchKernelGGL((k_project<true>), grid, dim3(256), 0, s->stream, a); }
-        else { hipLaunchKernelGGL((k_project<false>), grid, dim3(256), 0, s->stream, a); }
+        // one launch per sampling class present (usually: luma 1x1, both chroma 2x2)
+        bool done[kMaxCh] = {false, false, false};
+        for(unsigned c0 = 0; c0 < s->nch; c0++) {
+                if(done[c0]) { continue; }
+                const unsigned ws = s->ch[c0].ws, hs = s->ch[c0].hs;
+                unsigned nz = 0;
+                for(unsigned c = c0; c < s->nch; c++) {
+                        if(!done[c] && s->ch[c].ws == ws && s->ch[c].hs == hs) {
+                                a.chan_of_z[nz++] = c;
+                                done[c] = true;
+                        }
+                }
+                const unsigned strips = ((s->W + 64 * ws - 1) / (64 * ws)) * ((s->rows + 8 * hs - 1) / (8 * hs));
+                dim3 grid((strips + 3) / 4, 1, nz);
+#define J2P_LAUNCH_PROJECT(WS_, HS_)                                                               \
+        do {                                                                                       \
+                if(log) { hipLaunchKernelGGL((k_project<true, WS_, HS_>), grid, dim3(256), 0, s->stream, a); }  \
+                else { hipLaunchKernelGGL((k_project<false, WS_, HS_>), grid, dim3(256), 0, s->stream, a); }    \
+        } while(0)
+                if(ws == 1 && hs == 1) { J2P_LAUNCH_PROJECT(1, 1); }
+                else if(ws == 2 && hs == 2) { J2P_LAUNCH_PROJECT(2, 2); }
+                else if(ws == 2 && hs == 1) { J2P_LAUNCH_PROJECT(2, 1); }
+                else if(ws == 1 && hs == 2) { J2P_LAUNCH_PROJECT(1, 2); }
+                else { J2P_LAUNCH_PROJECT(0, 0); }
+#undef J2P_LAUNCH_PROJECT
+        }
         mark(s);
         HIP_TRY(hipGetLastError());
         s->cur ^= 1;        // SWAP(fdata, fista) of compute.c:438: the buffer just written is x_{k+1}

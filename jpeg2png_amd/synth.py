@@ -134,7 +134,7 @@ def make_planes(W, H, subsampling="444", quality=10, seed=1234, y_only=False, ro
     cb = -0.168736 * r - 0.331264 * g + 0.5 * b
     cr = 0.5 * r - 0.418688 * g - 0.081312 * b
     qc = quant_table("chroma", quality)
-    s = {"444": (1, 1), "420": (2, 2), "422": (2, 1), "440": (1, 2)}[subsampling]
+    s = {"444": (1, 1), "420": (2, 2), "422": (2, 1), "440": (1, 2), "411": (4, 1), "410": (4, 2)}[subsampling]
     for p in (cb, cr):
         if s != (1, 1):
             hh, ww = p.shape

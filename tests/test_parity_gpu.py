@@ -57,6 +57,11 @@ CASES = [
     ("rgb420_padded", 40, 20, "420", 10, False, 0.3, 0.001, 10),
     ("rgb422", 80, 48, "422", 50, False, 0.3, 0.001, 6),
     ("rgb440", 48, 80, "440", 50, False, 0.3, 0.001, 6),
+    ("rgb411", 96, 40, "411", 50, False, 0.3, 0.001, 6),
+    ("rgb410_wide", 544, 48, "410", 25, False, 0.3, 0.001, 5),
+    ("rgb420_wide", 400, 72, "420", 10, False, 0.3, 0.001, 8),
+    ("rgb422_wide", 328, 40, "422", 10, False, 0.3, 0.001, 6),
+    ("rgb440_wide", 200, 136, "440", 10, False, 0.3, 0.001, 6),
     ("y_512_50", 512, 512, "444", 10, True, 0.3, 0.001, 50),
 ]
 
