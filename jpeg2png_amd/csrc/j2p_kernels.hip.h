@@ -146,6 +146,7 @@ struct ChanDev {
         unsigned cw, ch;    // coefficient plane size (whole image)
         unsigned ws, hs;    // subsampling
         unsigned crow0;     // first coefficient row held in d / pg  (= row0 / hs clipped)
+        unsigned crows;     // coefficient rows held (pg always has at least one row allocated)
         float p_alpha;      // pweight*2*255*sqrtf(2)  (compute.c:245)
         int prob_on;        // pweight != 0
 };
@@ -261,6 +262,24 @@ __device__ __forceinline__ v2f div_shared(v2f x, v2f d, v2f r)
         const v2f q1 = pk_fma(pk_fma(-d, q0, x), r, q0);
         return pk_fma(pk_fma(-d, q1, x), r, q1);
 }
+// the same for N numerators over one denominator, written breadth-first so that the N
+// independent fma chains are interleaved instead of issued back to back
+template <int N>
+__device__ __forceinline__ void div_shared_n(const v2f (&x)[N], v2f d, v2f r, v2f (&q)[N])
+{
+        v2f q0[N], e0[N], q1[N], e1[N];
+#pragma unroll
+        for(int i = 0; i < N; i++) { q0[i] = x[i] * r; }
+#pragma unroll
+        for(int i = 0; i < N; i++) { e0[i] = pk_fma(-d, q0[i], x[i]); }
+#pragma unroll
+        for(int i = 0; i < N; i++) { q1[i] = pk_fma(e0[i], r, q0[i]); }
+#pragma unroll
+        for(int i = 0; i < N; i++) { e1[i] = pk_fma(-d, q1[i], x[i]); }
+#pragma unroll
+        for(int i = 0; i < N; i++) { q[i] = pk_fma(e1[i], r, q1[i]); }
+}
+
 // true when a loaded pixel is outside the range for which the fast paths are exact:
 // 0 < |y| < 2^-20 (y * 2^-106 is subnormal), |y| >= 2^41 (y * 2^87 overflows), or NaN
 __device__ __forceinline__ bool y_suspect(v2f y)
@@ -289,6 +308,11 @@ __device__ __forceinline__ v2f sqrt_fast(v2f x)
 }
 
 constexpr int kStripCols = 124;   // output columns per wavefront strip
+#ifndef J2P_RING
+#define J2P_RING 4
+#endif
+constexpr int kRing = J2P_RING;   // row slots = hand-unroll factor of the marching loop (1 channel; 3 otherwise: registers);
+                                  // rows are fetched (slots - 2) trips ahead
 
 template <int NCH, bool TGV>
 struct SourceTerms {
@@ -302,11 +326,15 @@ __device__ __forceinline__ v2f sqrt_pair(v2f x)
         if(FAST) { return sqrt_fast(x); }
         return v2f{sqrtf(x.x), sqrtf(x.y)};
 }
-template <bool FAST>
-__device__ __forceinline__ v2f div_pair(v2f x, v2f d, v2f r)
+template <bool FAST, int N>
+__device__ __forceinline__ void div_n(const v2f (&x)[N], v2f d, v2f r, v2f (&q)[N])
 {
-        if(FAST) { return div_shared(x, d, r); }
-        return v2f{x.x / d.x, x.y / d.y};
+        if(FAST) {
+                div_shared_n<N>(x, d, r, q);
+        } else {
+#pragma unroll
+                for(int i = 0; i < N; i++) { q[i] = v2f{x[i].x / d.x, x[i].y / d.y}; }
+        }
 }
 
 // Source terms of one image row for a lane's column pair.  gx,gy: forward differences of
@@ -336,9 +364,12 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
 #pragma unroll
         for(int c = 0; c < NCH; c++) {
                 if(NCH > 1) { __builtin_amdgcn_sched_barrier(0); }   // one channel at a time: bounds the live ranges
-                s.tvxL[c] = left_of(div_pair<FAST>(a1 * gx[c], d1, r1));
-                s.tvy[c] = div_pair<FAST>(a1 * gy[c], d1, r1);
-                s.tvo[c] = div_pair<FAST>(a1 * -(gx[c] + gy[c]), d1, r1);
+                const v2f num[3] = {a1 * gx[c], a1 * gy[c], a1 * -(gx[c] + gy[c])};
+                v2f q[3];
+                div_n<FAST, 3>(num, d1, r1, q);
+                s.tvxL[c] = left_of(q[0]);
+                s.tvy[c] = q[1];
+                s.tvo[c] = q[2];
         }
         // ---- TGV2 (compute.c:136-183) ----
         if(TGV) {
@@ -365,10 +396,13 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
                 for(int c = 0; c < NCH; c++) {
                         if(NCH > 1) { __builtin_amdgcn_sched_barrier(0); }
                         // a2 * (expr / n2): division first (compute.c:165-182)
-                        const v2f tA = a2 * div_pair<FAST>(sy[c] + xx[c], d2, r2);        // to (x-1,y), (x+1,y)
-                        s.B[c] = a2 * div_pair<FAST>(yy[c] + sy[c], d2, r2);              // to (x,y-1), (x,y+1)
-                        const v2f tC = a2 * div_pair<FAST>(-sy[c], d2, r2);               // to (x+1,y-1), (x-1,y+1)
-                        s.O[c] = a2 * div_pair<FAST>(-(2.f * xx[c] + 2.f * sy[c] + 2.f * yy[c]), d2, r2);
+                        const v2f num[4] = {sy[c] + xx[c], yy[c] + sy[c], -sy[c], -(2.f * xx[c] + 2.f * sy[c] + 2.f * yy[c])};
+                        v2f q[4];
+                        div_n<FAST, 4>(num, d2, r2, q);
+                        const v2f tA = a2 * q[0];                                       // to (x-1,y), (x+1,y)
+                        s.B[c] = a2 * q[1];                                             // to (x,y-1), (x,y+1)
+                        const v2f tC = a2 * q[2];                                       // to (x+1,y-1), (x-1,y+1)
+                        s.O[c] = a2 * q[3];                                             // own
                         s.A[c] = tA;
                         s.CL[c] = left_of(tC);
                         s.CR[c] = right_of(tC);
@@ -379,8 +413,11 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
 #ifndef J2P_GRAD_WAVES1
 #define J2P_GRAD_WAVES1 4      // waves per SIMD the 1-channel gradient kernel is register-limited to
 #endif
+#ifndef J2P_GRAD_WAVES3
+#define J2P_GRAD_WAVES3 2
+#endif
 template <int NCH, bool TGV, bool LOG>
-__global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : 2)) void k_gradient(GradArgs a)
+__global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : J2P_GRAD_WAVES3)) void k_gradient(GradArgs a)
 {
         const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
         const int wcol = (int)blockIdx.x * 4 + wave;
@@ -399,26 +436,32 @@ __global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : 2
         const v2f m_gx = v2f{in_f, xl + 1 >= W - 1 ? 0.f : in_f};   // gx = 0 on the last column (compute.c:79)
         const v2f m_hx = v2f{xl == 0 ? 0.f : in_f, in_f};           // gxx, gyx = 0 on the first column
 
-        // FISTA point of one row for this lane's columns (compute.c:433-439); 0 outside the image.
-        // Lanes left/right of the image read a clamped (valid) address and are zeroed by m_in, so
-        // the only branch is the wave-uniform "row inside the image".
+        // Rows are fetched kRing-2 loop trips before they are needed: `fetch_row` only issues the
+        // loads of x_k / x_{k-1} (raw values stay in the ring), `make_y` turns them into the FISTA
+        // point (compute.c:433-439) when the row is first used.  All loads are UNCONDITIONAL —
+        // lanes left/right of the image and rows above/below it read a clamped, valid address and
+        // are zeroed by a mask afterwards — so the loop body is straight-line code and the compiler
+        // can keep the younger loads in flight (counted s_waitcnt) instead of draining them.
         const int xl_c = xl < 0 ? 0 : (xl > W - 2 ? W - 2 : xl);
-        const v2f m_in = v2f{in_f, in_f};
-        auto load_y = [&](int lr, v2f (&y)[NCH], bool &suspect) {
+        const int lr_lo = -(row0 < (int)kHalo ? row0 : (int)kHalo);                      // first readable band-local row
+        const int lr_hi = rows - 1 + (H - row0 - rows < (int)kHalo ? H - row0 - rows : (int)kHalo);
+        auto fetch_row = [&](int lr, v2f (&rc)[NCH], v2f (&rp)[NCH]) {
+                const int lc = lr < lr_lo ? lr_lo : (lr > lr_hi ? lr_hi : lr);
+                const ptrdiff_t off = (ptrdiff_t)lc * W + xl_c;
+#pragma unroll
+                for(int c = 0; c < NCH; c++) {
+                        rc[c] = *reinterpret_cast<const v2f *>(a.ch[c].xcur + off);
+                        rp[c] = *reinterpret_cast<const v2f *>(a.ch[c].xprev + off);
+                }
+        };
+        auto make_y = [&](int lr, const v2f (&rc)[NCH], const v2f (&rp)[NCH], v2f (&y)[NCH], bool &suspect) {
                 const int gr = row0 + lr;
-                const ptrdiff_t off = (ptrdiff_t)lr * W + xl_c;
+                const float m = gr >= 0 && gr < H ? in_f : 0.f;   // 0 outside the image
                 suspect = false;
-                if(gr >= 0 && gr < H) {
 #pragma unroll
-                        for(int c = 0; c < NCH; c++) {
-                                const v2f xc = *reinterpret_cast<const v2f *>(a.ch[c].xcur + off);
-                                const v2f xp = *reinterpret_cast<const v2f *>(a.ch[c].xprev + off);
-                                y[c] = (xc + a.factor * (xc - xp)) * m_in;
-                                suspect |= y_suspect(y[c]);
-                        }
-                } else {
-#pragma unroll
-                        for(int c = 0; c < NCH; c++) { y[c] = v2f{0.f, 0.f}; }
+                for(int c = 0; c < NCH; c++) {
+                        y[c] = (rc[c] + a.factor * (rc[c] - rp[c])) * m;
+                        suspect |= y_suspect(y[c]);
                 }
         };
         // forward differences of row gr given rows gr and gr+1 (compute.c:79,81)
@@ -431,33 +474,56 @@ __global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : 2
                 }
         };
 
-        // prob-gradient state of one target row (compute.c:53-66: replicated over the sample's footprint)
+        // prob-gradient state of one target row (compute.c:53-66: replicated over the sample's
+        // footprint).  Loaded unconditionally from a clamped address; `pmask` (per lane) and the row
+        // test at the point of use decide whether it contributes.  A channel with pweight == 0 has an
+        // all-zero state buffer, so it needs no special case.
+        v2f p_scale[NCH];
+        int p_col[NCH][2];
+#pragma unroll
+        for(int c = 0; c < NCH; c++) {
+                const ChanDev &k = a.ch[c];
+                const bool on = k.prob_on && pair_own && (unsigned)xl < k.cw * k.ws;
+                p_scale[c] = on ? v2f{k.p_alpha, k.p_alpha} : v2f{0.f, 0.f};
+                const unsigned cmax = k.cw - 1;
+                const unsigned c0 = (unsigned)xl_c / k.ws, c1 = (unsigned)(xl_c + 1) / k.ws;
+                p_col[c][0] = (int)(c0 > cmax ? cmax : c0);
+                p_col[c][1] = (int)(c1 > cmax ? cmax : c1);
+        }
         auto load_p = [&](int lt, v2f (&pv)[NCH]) {
-                const int gt = row0 + lt;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
                         const ChanDev &k = a.ch[c];
-                        pv[c] = v2f{0.f, 0.f};
-                        if(k.prob_on && pair_own && lt < t1 && (unsigned)gt < k.ch * k.hs && (unsigned)xl < k.cw * k.ws) {
-                                const float *prow = k.pg + (size_t)((unsigned)gt / k.hs - k.crow0) * k.cw;
-                                if(k.ws == 1) { pv[c] = *reinterpret_cast<const v2f *>(prow + xl); }
-                                else { pv[c] = v2f{prow[(unsigned)xl / k.ws], prow[(unsigned)(xl + 1) / k.ws]}; }
-                        }
+                        // coefficient row of canvas row lt, clamped into the rows this band holds
+                        int gt = row0 + (lt < 0 ? 0 : (lt > rows - 1 ? rows - 1 : lt));
+                        unsigned cr = (unsigned)gt / k.hs;
+                        const unsigned cr_hi = k.crow0 + (k.crows ? k.crows - 1 : 0);
+                        cr = cr < k.crow0 ? k.crow0 : (cr > cr_hi ? cr_hi : cr);
+                        const float *prow = k.pg + (size_t)(cr - k.crow0) * k.cw;
+                        if(k.ws == 1) { pv[c] = *reinterpret_cast<const v2f *>(prow + p_col[c][0]); }
+                        else { pv[c] = v2f{prow[p_col[c][0]], prow[p_col[c][1]]}; }
                 }
         };
 
-        // ring of three row slots
-        v2f Y[3][NCH], GX[3][NCH], GY[3][NCH], PV[3][NCH];
-        bool bad[3];
-        SourceTerms<NCH, TGV> S[3];
+        // rings of kRing row slots, slot = (row - (t0-1)) mod kRing = phase of the trip that owns the row
+        constexpr int R = NCH == 1 ? kRing : 3;
+        v2f RC[R][NCH], RP[R][NCH], Y[R][NCH], GX[R][NCH], GY[R][NCH], PV[R][NCH];
+        bool bad[R];
+        SourceTerms<NCH, TGV> S[R];
         {
-                v2f ym[NCH];
+                // rows t0-2, t0-1, t0 are needed at once; rows up to t0+R-3 are put in flight
+                v2f mc[NCH], mp[NCH], ym[NCH];
                 bool bm;
-                load_y(t0 - 2, ym, bm);
-                load_y(t0 - 1, Y[0], bad[0]);
-                load_y(t0, Y[1], bad[1]);
-                bad[0] |= bm;                                  // row t0-2 only feeds the first trip
-                diffs(row0 + t0 - 2, ym, Y[0], GX[2], GY[2]);
+                fetch_row(t0 - 2, mc, mp);
+                fetch_row(t0 - 1, RC[0], RP[0]);
+#pragma unroll
+                for(int i = 1; i <= R - 2; i++) { fetch_row(t0 - 1 + i, RC[i], RP[i]); }
+#pragma unroll
+                for(int i = 1; i <= R - 3; i++) { load_p(t0 - 1 + i, PV[i]); }
+                make_y(t0 - 2, mc, mp, ym, bm);
+                make_y(t0 - 1, RC[0], RP[0], Y[0], bad[0]);
+                bad[R - 1] = bm;                               // slot of row t0-2
+                diffs(row0 + t0 - 2, ym, Y[0], GX[R - 1], GY[R - 1]);
         }
         double g2[NCH];
 #pragma unroll
@@ -468,12 +534,14 @@ __global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : 2
 
         // one trip: source terms of row r into slot P, then target row r-1
         auto trip = [&](auto phase, int r) {
-                constexpr int P = decltype(phase)::value, P1 = (P + 1) % 3, P2 = (P + 2) % 3;
+                constexpr int P = decltype(phase)::value, P1 = (P + 1) % R, PM1 = (P + R - 1) % R, PM2 = (P + R - 2) % R;
                 const int gr = row0 + r;
-                const bool prev_bad = bad[P2];                 // row r-1, about to be overwritten by the prefetch
-                // prefetch y[r+2] for the next trip; past the halo nothing is needed (maps to a row < 0)
-                load_y(r + 2 <= t1 + 1 ? r + 2 : -(int)kHalo - 1 - row0, Y[P2], bad[P2]);
-                if(r >= t0) { load_p(r, PV[P]); }              // target row of the NEXT trip
+                // put row r+R-1 in flight (its slot held row r-1, whose raw values are dead), and the
+                // prob state of target row r+R-2; then finish row r+1, fetched R-2 trips ago
+                fetch_row(r + R - 1, RC[PM1], RP[PM1]);
+                load_p(r + R - 2, PV[PM2]);
+                make_y(r + 1, RC[P1], RP[P1], Y[P1], bad[P1]);
+                const bool prev_bad = bad[PM1];
                 SourceTerms<NCH, TGV> &s = S[P];
                 diffs(gr, Y[P], Y[P1], GX[P], GY[P]);
                 {
@@ -483,22 +551,23 @@ __global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : 2
                         const float hy = gr <= 0 || gr >= H ? 0.f : in_f;  // gxy, gyy = 0 on the first row (compute.c:141-143)
                         const v2f m_hy = v2f{hy, hy};
                         if(__builtin_amdgcn_ballot_w64(prev_bad | bad[P] | bad[P1]) == 0) {
-                                source_terms<NCH, TGV, LOG, true>(GX[P], GY[P], GX[P2], GY[P2], m_hx, m_hy, a.a_tv, a.a_tgv,
+                                source_terms<NCH, TGV, LOG, true>(GX[P], GY[P], GX[PM1], GY[PM1], m_hx, m_hy, a.a_tv, a.a_tgv,
                                                                   log_row, tv_acc, tv2_acc, s);
                         } else {
-                                source_terms<NCH, TGV, LOG, false>(GX[P], GY[P], GX[P2], GY[P2], m_hx, m_hy, a.a_tv, a.a_tgv,
+                                source_terms<NCH, TGV, LOG, false>(GX[P], GY[P], GX[PM1], GY[PM1], m_hx, m_hy, a.a_tv, a.a_tgv,
                                                                    log_row, tv_acc, tv2_acc, s);
                         }
                 }
-                // ---- target row t = r-1: rows t-1, t, t+1 live in slots P1, P2, P ----
+                // ---- target row t = r-1: rows t-1, t, t+1 live in slots PM2, PM1, P ----
                 const int t = r - 1;
                 if(t >= t0) {
-                        const SourceTerms<NCH, TGV> &up = S[P1], &mid = S[P2];
+                        const SourceTerms<NCH, TGV> &up = S[PM2], &mid = S[PM1];
+                        const int gt = row0 + t;
 #pragma unroll
                         for(int c = 0; c < NCH; c++) {
                                 const ChanDev &k = a.ch[c];
                                 v2f g = v2f{0.f, 0.f};
-                                if(k.prob_on) { g += k.p_alpha * PV[P2][c]; }   // loaded one trip ago
+                                if((unsigned)gt < k.ch * k.hs) { g += p_scale[c] * PV[PM1][c]; }   // row t, fetched R-1 trips ago
                                 g += up.tvy[c];                  // TV from (x, t-1)
                                 g += mid.tvxL[c];                // TV from (x-1, t)
                                 g += mid.tvo[c];                 // TV own
@@ -533,12 +602,20 @@ __global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : 2
                 }
         };
 
-        for(int r = t0 - 1; r <= t1; r += 3) {
+        for(int r = t0 - 1; r <= t1; r += R) {
                 trip(std::integral_constant<int, 0>{}, r);
                 if(r + 1 > t1) { break; }
                 trip(std::integral_constant<int, 1>{}, r + 1);
                 if(r + 2 > t1) { break; }
                 trip(std::integral_constant<int, 2>{}, r + 2);
+                if(R > 3) {
+                        if(r + 3 > t1) { break; }
+                        trip(std::integral_constant<int, 3 % R>{}, r + 3);
+                }
+                if(R > 4) {
+                        if(r + 4 > t1) { break; }
+                        trip(std::integral_constant<int, 4 % R>{}, r + 4);
+                }
         }
         if(LOG) {
 #pragma unroll

@@ -131,6 +131,7 @@ ChanDev chan_dev(const j2p_solver *s, unsigned c)
         k.ws = h.ws;
         k.hs = h.hs;
         k.crow0 = h.crow0;
+        k.crows = h.crows;
         k.p_alpha = h.pweight * 2 * 255 * sqrtf(2);       // compute.c:245
         k.prob_on = h.pweight != 0.f;
         return k;
@@ -461,10 +462,10 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 CREATE_TRY(hipMalloc(&h.grad, (size_t)s->rows * W * sizeof(float)));
                 CREATE_TRY(hipMalloc(&h.q, 64 * sizeof(float)));
                 CREATE_TRY(hipMalloc(&h.decoded, (size_t)h.frows * h.cw * sizeof(float)));
-                if(h.crows) {
-                        CREATE_TRY(hipMalloc(&h.pg, (size_t)h.crows * h.cw * sizeof(float)));
-                        CREATE_TRY(hipMalloc(&h.d, (size_t)h.crows * h.cw * sizeof(int16_t)));
-                }
+                // the prob state always has at least one (zero) row: the gradient kernel reads it unconditionally
+                CREATE_TRY(hipMalloc(&h.pg, (size_t)(h.crows ? h.crows : 1) * h.cw * sizeof(float)));
+                CREATE_TRY(hipMemset(h.pg, 0, (size_t)(h.crows ? h.crows : 1) * h.cw * sizeof(float)));
+                if(h.crows) { CREATE_TRY(hipMalloc(&h.d, (size_t)h.crows * h.cw * sizeof(int16_t))); }
                 float qf[64];
                 for(int j = 0; j < 64; j++) { qf[j] = (float)p.quant_table[j]; }
                 CREATE_TRY(hipMemcpy(h.q, qf, sizeof(qf), hipMemcpyHostToDevice));
