@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--iterations", type=int, default=0, help="override iterations per solve (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timing-every", type=int, default=4, help="HIP-event sample stride (iterations)")
+    ap.add_argument("--force-tiled", action="store_true", help="run the row-tiled path even with one rank (debug)")
     return ap.parse_args()
 
 
@@ -95,7 +96,8 @@ def main():
     j.build()
     torch.cuda.set_device(local_rank)
 
-    if n_gpus == 1:
+    tiled_mode = n_gpus > 1 or a.force_tiled
+    if not tiled_mode:
         W = a.size or 4096
         H = W
         its = a.iterations or 500
@@ -117,7 +119,10 @@ def main():
     else:
         import torch.distributed as dist
         from jpeg2png_amd import tiled
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         W = a.size or 16384
         rows_per_gpu = 2048 if not a.size else max(64, a.size // 8 // 16 * 16)
         H = rows_per_gpu * n_gpus
@@ -146,7 +151,7 @@ def main():
         reset()
 
     def barrier():
-        if n_gpus > 1:
+        if tiled_mode:
             import torch.distributed as dist
             dist.barrier()
 
@@ -167,7 +172,7 @@ def main():
     elapsed = time.perf_counter() - t0
     g_ms, p_ms, samples = eng.kernel_times()
 
-    if n_gpus > 1:
+    if tiled_mode:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -186,7 +191,7 @@ def main():
         # MI355X_MICROARCH.md prescribes); only meaningful for the N=1 workload they were taken on
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if n_gpus == 1 and not a.size and os.path.exists(pmc):
+        if not tiled_mode and not a.size and os.path.exists(pmc):
             with open(pmc) as f:
                 summ = json.load(f)
             for name, v in summ.items():
@@ -198,7 +203,7 @@ def main():
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "iterations_per_step": its, "weight": WEIGHT, "pweight": PWEIGHT,
-                       "parallelism": "single GPU" if n_gpus == 1 else f"row-tiled x{n_gpus}, RCCL halo + norm all-gather"},
+                       "parallelism": "single GPU" if not tiled_mode else f"row-tiled x{n_gpus}, RCCL halo + norm all-gather"},
             "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
@@ -207,10 +212,10 @@ def main():
                          "event_samples": samples,
                          "iteration_frac_38B": round(38.0 * value * 1e6 / n_gpus / 1e9 / HBM_PEAK_GBS, 4)},
         }
-        if n_gpus == 1 and not a.no_cpu_baseline:
+        if not tiled_mode and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, seed)
         print(json.dumps(out), flush=True)
-    if n_gpus > 1:
+    if tiled_mode:
         import torch.distributed as dist
         dist.destroy_process_group()
 

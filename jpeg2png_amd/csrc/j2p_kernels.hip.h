@@ -357,9 +357,12 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
                 tv += (double)(a_tv * n1.x);
                 tv += (double)(a_tv * n1.y);
         }
-        // a pixel with zero norm contributes nothing (compute.c:97): divide by 1, scale by 0
-        const v2f d1 = v2f{n1.x == 0.f ? 1.f : n1.x, n1.y == 0.f ? 1.f : n1.y};
-        const v2f a1 = v2f{n1.x == 0.f ? 0.f : a_tv, n1.y == 0.f ? 0.f : a_tv};
+        // A pixel with zero norm contributes nothing (compute.c:97).  Screened path: n == 0 implies
+        // every numerator is exactly 0 (no square can underflow), so any positive divisor gives 0.
+        // Unscreened path: divide by 1, scale by 0.
+        const v2f d1 = FAST ? v2f{fmaxf(n1.x, 0x1p-60f), fmaxf(n1.y, 0x1p-60f)}
+                            : v2f{n1.x == 0.f ? 1.f : n1.x, n1.y == 0.f ? 1.f : n1.y};
+        const v2f a1 = FAST ? v2f{a_tv, a_tv} : v2f{n1.x == 0.f ? 0.f : a_tv, n1.y == 0.f ? 0.f : a_tv};
         const v2f r1 = FAST ? div_prepare(d1) : d1;
 #pragma unroll
         for(int c = 0; c < NCH; c++) {
@@ -389,8 +392,10 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
                         tv2 += (double)(a_tgv * n2.x);
                         tv2 += (double)(a_tgv * n2.y);
                 }
-                const v2f d2 = v2f{n2.x == 0.f ? 1.f : n2.x, n2.y == 0.f ? 1.f : n2.y};
-                const v2f a2 = v2f{n2.x == 0.f ? 0.f : a_tgv, n2.y == 0.f ? 0.f : a_tgv};   // compute.c:158
+                const v2f d2 = FAST ? v2f{fmaxf(n2.x, 0x1p-60f), fmaxf(n2.y, 0x1p-60f)}
+                                    : v2f{n2.x == 0.f ? 1.f : n2.x, n2.y == 0.f ? 1.f : n2.y};
+                const v2f a2 = FAST ? v2f{a_tgv, a_tgv}
+                                    : v2f{n2.x == 0.f ? 0.f : a_tgv, n2.y == 0.f ? 0.f : a_tgv};   // compute.c:158
                 const v2f r2 = FAST ? div_prepare(d2) : d2;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
