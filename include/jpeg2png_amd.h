@@ -157,6 +157,17 @@ int j2p_decode_plane(int device, unsigned w, unsigned h, const int16_t *data,
  * dct8x8s / idct8x8s of ooura/dct.c:98 / :34 — exposed for the parity tests */
 int j2p_dct8x8_blocks(int device, float *blocks, size_t n, int inverse);
 
+/* The colour conversion of the PNG writer on the device (png.c:37-62: YCbCr -> RGB, clamp,
+ * 8/16-bit samples, crop to w x h) including the luma +128 fix-up of jpeg2png.c:156-159,
+ * from the current iterates of three (solver, channel) pairs on one device — the same solver
+ * three times after a joint compute(), three solvers after `-s`.  out_host receives h*w*3
+ * bytes (bits == 8) or h*w*6 bytes, big-endian samples (bits == 16), ready for libpng rows. */
+typedef struct j2p_plane_ref {
+        j2p_solver *solver;
+        unsigned channel;
+} j2p_plane_ref;
+int j2p_planes_to_rgb(const j2p_plane_ref planes[3], unsigned w, unsigned h, unsigned bits, uint8_t *out_host);
+
 /* test hook: compares the kernels' fast division / square root (the compiler's IEEE
  * sequences without range scaling) with `/` and sqrtf() on n pseudo-random operand pairs
  * inside the range the kernels screen for; both counters must come back 0 */

@@ -59,7 +59,7 @@ C_ABI_SYMBOLS = [
     "j2p_solver_reset", "j2p_solver_run", "j2p_solver_phase_gradient", "j2p_solver_phase_project",
     "j2p_solver_exchange_info", "j2p_solver_commit_initial_halo", "j2p_solver_download",
     "j2p_solver_plane_ptr", "j2p_solver_sync", "j2p_solver_kernel_times", "j2p_solver_enable_timing",
-    "j2p_decode_plane", "j2p_dct8x8_blocks", "j2p_math_selftest",
+    "j2p_decode_plane", "j2p_dct8x8_blocks", "j2p_math_selftest", "j2p_planes_to_rgb",
     "compute", "j2p_compute",
 ]
 

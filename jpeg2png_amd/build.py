@@ -61,5 +61,36 @@ def build(force=False, verbose=False):
     return LIB
 
 
+CLI = os.path.join(HERE, "jpeg2png_gpu")
+
+
+def build_cli(force=False, verbose=False, prefix=None):
+    """Build the command-line driver cli/jpeg2png_gpu.c (needs libjpeg + libpng headers; this image
+    ships them under /opt/conda).  Returns the path, or None when the libraries are not available."""
+    prefix = prefix or os.environ.get("J2P_IMG_PREFIX", "/opt/conda")
+    src = os.path.join(ROOT, "cli", "jpeg2png_gpu.c")
+    if not (os.path.exists(os.path.join(prefix, "include", "jpeglib.h")) and os.path.exists(os.path.join(prefix, "include", "png.h"))):
+        return None
+    lib = build(force=False, verbose=verbose)
+    if not force and not _newer(CLI, [src, lib, os.path.join(INCLUDE, "jpeg2png_amd.h")]):
+        return CLI
+    gcc = shutil.which("gcc") or "gcc"
+    plib = os.path.join(prefix, "lib")
+    # the image libraries are named by full path and found at run time through RUNPATH (direct
+    # dependencies only), so that the HIP runtime keeps resolving libstdc++ from the system
+    cmd = [gcc, "-std=c11", "-O2", "-Wall", "-Wextra", "-I", INCLUDE, "-I", os.path.join(prefix, "include"), src, "-o", CLI,
+           lib, os.path.join(plib, "libjpeg.so"), os.path.join(plib, "libpng16.so"), os.path.join(plib, "libz.so"), "-lpthread",
+           "-Wl,--enable-new-dtags", "-Wl,-rpath-link,/usr/lib/x86_64-linux-gnu:/opt/rocm/lib",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + plib]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("CLI build failed")
+    return CLI
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_cli(force="--force" in sys.argv, verbose=True))

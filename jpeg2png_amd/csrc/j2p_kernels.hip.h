@@ -1197,6 +1197,46 @@ __global__ __launch_bounds__(256) void k_dct_blocks(float *blocks, size_t nblock
 }
 
 // ---------------------------------------------------------------------------
+// YCbCr -> RGB of the PNG writer (png.c:37-62) with the luma +128 fix-up of
+// jpeg2png.c:156-159, cropped to the image size.  The reference evaluates the
+// colour matrix in double, narrows to float for the clamp, scales by
+// (1 << bits) / 256 in float and truncates to unsigned; the same here.
+// out: 3 bytes per pixel (bits == 8) or 6 bytes, big-endian samples (bits == 16).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned to_sample(double v, float bitfactor)
+{
+        float x = (float)v;
+        x = (double)x > 255. ? 255.f : ((double)x < 0. ? 0.f : x);      // CLAMP(x, 0., 255.), png.c:15-17
+        return (unsigned)(x * bitfactor);
+}
+
+__global__ __launch_bounds__(256) void k_to_rgb(const float *yp, unsigned ys, const float *cbp, unsigned cbs, const float *crp,
+                                                unsigned crs, unsigned w, unsigned h, unsigned bits, uint8_t *out)
+{
+        const size_t n = (size_t)w * h;
+        const float bitfactor = (float)((double)(1 << bits) / 256.);
+        for(size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+                const unsigned x = (unsigned)(i % w), y = (unsigned)(i / w);
+                const float yi = (float)((double)yp[(size_t)y * ys + x] + 128.);   // jpeg2png.c:158
+                const float cbi = cbp[(size_t)y * cbs + x], cri = crp[(size_t)y * crs + x];
+                const unsigned r = to_sample((double)yi + 1.402 * (double)cri, bitfactor);
+                const unsigned g = to_sample((double)yi - 0.34414 * (double)cbi - 0.71414 * (double)cri, bitfactor);
+                const unsigned b = to_sample((double)yi + 1.772 * (double)cbi, bitfactor);
+                if(bits == 8) {
+                        uint8_t *o = out + i * 3;
+                        o[0] = (uint8_t)(r & 0xff);
+                        o[1] = (uint8_t)(g & 0xff);
+                        o[2] = (uint8_t)(b & 0xff);
+                } else {
+                        uint8_t *o = out + i * 6;
+                        o[0] = (uint8_t)((r >> 8) & 0xff); o[1] = (uint8_t)(r & 0xff);
+                        o[2] = (uint8_t)((g >> 8) & 0xff); o[3] = (uint8_t)(g & 0xff);
+                        o[4] = (uint8_t)((b >> 8) & 0xff); o[5] = (uint8_t)(b & 0xff);
+                }
+        }
+}
+
+// ---------------------------------------------------------------------------
 // Self-test of the fast division / square root against the compiler's IEEE forms
 // on n pseudo-random operand pairs inside the screened range (tests/ only).
 // ---------------------------------------------------------------------------

@@ -786,6 +786,40 @@ int j2p_dct8x8_blocks(int device, float *blocks, size_t n, int inverse)
         return rc;
 }
 
+int j2p_planes_to_rgb(const j2p_plane_ref planes[3], unsigned w, unsigned h, unsigned bits, uint8_t *out_host)
+{
+        if(!planes || !out_host) { return fail(J2P_EINVAL, "NULL argument"); }
+        if(bits != 8 && bits != 16) { return fail(J2P_EINVAL, "bits must be 8 or 16 (png.c:22)"); }
+        if(w == 0 || h == 0) { return fail(J2P_EINVAL, "empty image"); }
+        const float *ptr[3];
+        unsigned stride[3];
+        for(int i = 0; i < 3; i++) {
+                j2p_solver *s = planes[i].solver;
+                if(!s || planes[i].channel >= s->nch) { return fail(J2P_EINVAL, "plane %d: bad solver/channel", i); }
+                if(!s->whole) { return fail(J2P_ESTATE, "to_rgb needs whole-canvas solvers"); }
+                if(s->device != planes[0].solver->device) { return fail(J2P_EINVAL, "planes live on different devices"); }
+                if(s->W < w || s->H < h) { return fail(J2P_EINVAL, "plane %d: canvas %ux%u smaller than the image %ux%u", i, s->W, s->H, w, h); }
+                if(s->grad_done) { return fail(J2P_ESTATE, "to_rgb between the two phases of an iteration"); }
+                ptr[i] = s->ch[planes[i].channel].xbuf[s->cur] + (size_t)kHalo * s->W;
+                stride[i] = s->W;
+        }
+        j2p_solver *s0 = planes[0].solver;
+        DeviceGuard guard(s0->device);
+        for(int i = 1; i < 3; i++) {
+                if(planes[i].solver != s0) { HIP_TRY(hipStreamSynchronize(planes[i].solver->stream)); }
+        }
+        const size_t bytes = (size_t)w * h * (bits == 8 ? 3 : 6);
+        uint8_t *dout = nullptr;
+        HIP_TRY(hipMalloc(&dout, bytes));
+        hipLaunchKernelGGL(k_to_rgb, dim3(2048), dim3(256), 0, s0->stream, ptr[0], stride[0], ptr[1], stride[1], ptr[2], stride[2],
+                           w, h, bits, dout);
+        hipError_t e = hipMemcpyAsync(out_host, dout, bytes, hipMemcpyDeviceToHost, s0->stream);
+        if(e == hipSuccess) { e = hipStreamSynchronize(s0->stream); }
+        (void)hipFree(dout);
+        if(e != hipSuccess) { return fail(J2P_EDEVICE, "planes_to_rgb: %s", hipGetErrorString(e)); }
+        return J2P_OK;
+}
+
 int j2p_math_selftest(int device, size_t n, unsigned seed, unsigned long long *div_mismatches,
                       unsigned long long *sqrt_mismatches)
 {

@@ -1,0 +1,127 @@
+"""The command-line driver cli/jpeg2png_gpu.c: option handling on the CPU, and on the GPU an
+end-to-end comparison with the UNMODIFIED reference program (oracle/_ref/jpeg2png_ref, built by
+`make -C oracle ref-cli` from /root/reference): same JPEG in, byte-identical PNG out."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_CLI = os.path.join(ROOT, "oracle", "_ref", "jpeg2png_ref")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    sys.path.insert(0, ROOT)
+    from jpeg2png_amd.build import build_cli
+    exe = build_cli()
+    if exe is None:
+        pytest.skip("libjpeg / libpng headers not available")
+    return exe
+
+
+def make_jpeg(path, w, h, quality, subsampling, seed):
+    from PIL import Image
+    from jpeg2png_amd import synth
+    rgb = synth.synth_rgb(w, h, seed).astype(np.uint8)
+    Image.fromarray(rgb, "RGB").save(path, "JPEG", quality=quality, subsampling=subsampling)
+
+
+def run(exe, *args):
+    return subprocess.run([exe, *args], capture_output=True, text=True)
+
+
+def test_version_exits_with_failure_like_the_reference(cli):
+    r = run(cli, "-V")
+    assert r.returncode == 1 and "version" in r.stdout            # jpeg2png.c:195-198
+
+
+def test_usage_without_arguments(cli):
+    r = run(cli)
+    assert r.returncode == 1 and r.stdout.startswith("usage:")
+
+
+@pytest.mark.parametrize("args,msg", [
+    (["x.jpg", "-w", "abc"], "invalid weight"),
+    (["x.jpg", "-w", "1,2,3"], "different weights are only possible when using separated components"),
+    (["x.jpg", "-i", "1,2,3"], "different iteration counts are only possible when using separated components"),
+    (["x.jpg", "-i", "x"], "invalid number of iterations"),
+    (["x.jpg", "-p", "x"], "invalid probability weight"),
+    (["x.jpg", "-t", "0"], "invalid number of threads"),
+    (["a.jpg", "b.jpg", "-o", "a.png"], "must give output file names for all input files or none"),
+    (["/nonexistent/x.jpg"], "could not open input file `/nonexistent/x.jpg`"),
+])
+def test_option_errors_match_the_reference_messages(cli, args, msg):
+    r = run(cli, *args)
+    assert r.returncode == 1
+    assert r.stderr.strip() == "jpeg2png: " + msg
+
+
+def test_refuses_to_overwrite_default_output(cli, tmp_path):
+    jpg = tmp_path / "pic.jpg"
+    make_jpeg(jpg, 32, 24, 50, 0, 1)
+    (tmp_path / "pic.png").write_bytes(b"x")
+    r = run(cli, str(jpg))
+    assert r.returncode == 1 and "not overwriting output file" in r.stderr      # jpeg2png.c:303-307
+
+
+def test_rejects_greyscale_jpeg(cli, tmp_path):
+    from PIL import Image
+    jpg = tmp_path / "grey.jpg"
+    Image.fromarray(np.zeros((16, 16), np.uint8), "L").save(jpg, "JPEG")
+    r = run(cli, str(jpg), "-q", "-o", str(tmp_path / "o.png"))
+    assert r.returncode == 1 and r.stderr.strip() == "jpeg2png: only 3 component jpegs are supported"   # jpeg.c:34
+
+
+CASES = [
+    ("420_joint", 200, 136, 10, 2, ["-i", "12"]),
+    ("444_joint_16bit", 96, 64, 25, 0, ["-i", "8", "-1"]),
+    ("420_separate", 160, 120, 10, 2, ["-s", "-i", "10,6,4", "-w", "0.3,0.1,0"]),
+    ("422_tv_only", 120, 72, 50, 1, ["-i", "6", "-w", "0", "-p", "0.002"]),
+    ("odd_size_420", 101, 67, 10, 2, ["-i", "7"]),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_png_identical_to_reference_program(cli, tmp_path, case):
+    if not os.path.exists(REF_CLI):
+        pytest.skip("oracle/_ref/jpeg2png_ref not built (needs /root/reference)")
+    name, w, h, q, sub, flags = case
+    jpg = tmp_path / "in.jpg"
+    make_jpeg(jpg, w, h, q, sub, seed=len(name))
+    ref_png, gpu_png = tmp_path / "ref.png", tmp_path / "gpu.png"
+    ref_csv, gpu_csv = tmp_path / "ref.csv", tmp_path / "gpu.csv"
+    r = run(REF_CLI, str(jpg), "-o", str(ref_png), "-q", "-c", str(ref_csv), "-t", "1", *flags)
+    assert r.returncode == 0, r.stderr
+    g = run(cli, str(jpg), "-o", str(gpu_png), "-q", "-c", str(gpu_csv), *flags)
+    assert g.returncode == 0, g.stderr
+    assert ref_png.read_bytes() == gpu_png.read_bytes()
+    ref_rows = np.loadtxt(ref_csv, delimiter=",", skiprows=1, usecols=(1, 2, 3, 4, 5, 6), ndmin=2)
+    gpu_rows = np.loadtxt(gpu_csv, delimiter=",", skiprows=1, usecols=(1, 2, 3, 4, 5, 6), ndmin=2)
+    ref_rows = ref_rows[np.lexsort((ref_rows[:, 1], ref_rows[:, 0]))]
+    gpu_rows = gpu_rows[np.lexsort((gpu_rows[:, 1], gpu_rows[:, 0]))]
+    assert ref_rows.shape == gpu_rows.shape
+    np.testing.assert_allclose(gpu_rows, ref_rows, rtol=0, atol=2e-6 * max(1.0, np.abs(ref_rows).max()))
+
+
+@pytest.mark.gpu
+def test_multiple_files_and_default_names(cli, tmp_path):
+    if not os.path.exists(REF_CLI):
+        pytest.skip("oracle/_ref/jpeg2png_ref not built (needs /root/reference)")
+    names = []
+    for i in range(3):
+        p = tmp_path / f"img{i}.jpeg"
+        make_jpeg(p, 64 + 16 * i, 48, 10, 2, seed=10 + i)
+        names.append(str(p))
+    g = run(cli, *names, "-i", "5", "-t", "2")
+    assert g.returncode == 0, g.stderr
+    for i in range(3):
+        out = tmp_path / f"img{i}.png"
+        assert out.exists()
+        ref = tmp_path / f"ref{i}.png"
+        r = run(REF_CLI, names[i], "-o", str(ref), "-q", "-i", "5")
+        assert r.returncode == 0
+        assert out.read_bytes() == ref.read_bytes()
