@@ -67,7 +67,7 @@ _lib = None
 
 
 def build(force=False, verbose=False):
-    from .build import build as _build
+    from .buildlib import build as _build
     return _build(force=force, verbose=verbose)
 
 
@@ -77,7 +77,7 @@ def load_library():
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
-        raise J2PError(f"{LIB_PATH} is missing: run `python -m jpeg2png_amd.build` "
+        raise J2PError(f"{LIB_PATH} is missing: run `python -m jpeg2png_amd.buildlib` "
                        "(the HIP extension is the only implementation; there is no fallback)")
     lib = ctypes.CDLL(LIB_PATH)   # RTLD_LOCAL: our `compute` must not interpose other libraries' symbols
     lib.j2p_version.restype = ctypes.c_char_p

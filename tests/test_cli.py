@@ -15,7 +15,7 @@ REF_CLI = os.path.join(ROOT, "oracle", "_ref", "jpeg2png_ref")
 @pytest.fixture(scope="module")
 def cli():
     sys.path.insert(0, ROOT)
-    from jpeg2png_amd.build import build_cli
+    from jpeg2png_amd.buildlib import build_cli
     exe = build_cli()
     if exe is None:
         pytest.skip("libjpeg / libpng headers not available")
