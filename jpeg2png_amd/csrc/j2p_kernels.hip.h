@@ -415,17 +415,98 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
         }
 }
 
+
+// The same for ONE channel of a jointly optimised image whose other channels live in the other
+// wavefronts of the workgroup (J wavefronts = J channels, same strip).  Only the two norms couple
+// the channels (compute.c:84-89, 148-152): every wavefront publishes the squares of its own
+// differences, and after one barrier every wavefront adds them up in the reference's order
+// ((((0 + gx0^2) + gy0^2) + gx1^2) + ... ; per-channel Hessian terms likewise), so all of them
+// hold bit-identical norms and the rest of the work stays private to the channel.
+// `xchg` is a double-buffered LDS area: [2][J][64 lanes][3] float2.
+template <int J, bool TGV, bool LOG, bool FAST>
+__device__ __forceinline__ void source_terms_joint(int cidx, int lane, int parity, v2f *xchg, v2f gx, v2f gy, v2f gxp, v2f gyp,
+                                                   v2f m_hx, v2f m_hy, float a_tv, float a_tgv, bool log_row, double &tv,
+                                                   double &tv2, SourceTerms<1, TGV> &s)
+{
+        v2f xx = v2f{0.f, 0.f}, sy = xx, yy = xx, tq = xx;
+        if(TGV) {
+                xx = (gx - left_of(gx)) * m_hx;
+                const v2f gyx = (gy - left_of(gy)) * m_hx;
+                const v2f gxy = (gx - gxp) * m_hy;
+                yy = (gy - gyp) * m_hy;
+                sy = (gxy + gyx) * 0.5f;
+                tq = xx * xx + 2.f * (sy * sy) + yy * yy;
+        }
+        v2f *mine = xchg + ((size_t)(parity * J + cidx) * 64 + lane) * 3;
+        mine[0] = gx * gx;
+        mine[1] = gy * gy;
+        mine[2] = tq;
+        __syncthreads();
+        v2f n1 = v2f{0.f, 0.f}, n2 = v2f{0.f, 0.f};
+#pragma unroll
+        for(int c = 0; c < J; c++) {
+                const v2f *o = xchg + ((size_t)(parity * J + c) * 64 + lane) * 3;
+                n1 += o[0];
+                n1 += o[1];
+                n2 += o[2];
+        }
+        n1 = sqrt_pair<FAST>(n1);
+        if(LOG && log_row) {
+                tv += (double)(a_tv * n1.x);
+                tv += (double)(a_tv * n1.y);
+        }
+        const v2f d1 = FAST ? v2f{fmaxf(n1.x, 0x1p-60f), fmaxf(n1.y, 0x1p-60f)}
+                            : v2f{n1.x == 0.f ? 1.f : n1.x, n1.y == 0.f ? 1.f : n1.y};
+        const v2f a1 = FAST ? v2f{a_tv, a_tv} : v2f{n1.x == 0.f ? 0.f : a_tv, n1.y == 0.f ? 0.f : a_tv};
+        const v2f r1 = FAST ? div_prepare(d1) : d1;
+        {
+                const v2f num[3] = {a1 * gx, a1 * gy, a1 * -(gx + gy)};
+                v2f q[3];
+                div_n<FAST, 3>(num, d1, r1, q);
+                s.tvxL[0] = left_of(q[0]);
+                s.tvy[0] = q[1];
+                s.tvo[0] = q[2];
+        }
+        if(TGV) {
+                n2 = sqrt_pair<FAST>(n2);
+                if(LOG && log_row) {
+                        tv2 += (double)(a_tgv * n2.x);
+                        tv2 += (double)(a_tgv * n2.y);
+                }
+                const v2f d2 = FAST ? v2f{fmaxf(n2.x, 0x1p-60f), fmaxf(n2.y, 0x1p-60f)}
+                                    : v2f{n2.x == 0.f ? 1.f : n2.x, n2.y == 0.f ? 1.f : n2.y};
+                const v2f a2 = FAST ? v2f{a_tgv, a_tgv} : v2f{n2.x == 0.f ? 0.f : a_tgv, n2.y == 0.f ? 0.f : a_tgv};
+                const v2f r2 = FAST ? div_prepare(d2) : d2;
+                const v2f num[4] = {sy + xx, yy + sy, -sy, -(2.f * xx + 2.f * sy + 2.f * yy)};
+                v2f q[4];
+                div_n<FAST, 4>(num, d2, r2, q);
+                const v2f tC = a2 * q[2];
+                s.A[0] = a2 * q[0];
+                s.B[0] = a2 * q[1];
+                s.O[0] = a2 * q[3];
+                s.CL[0] = left_of(tC);
+                s.CR[0] = right_of(tC);
+        }
+}
+
 #ifndef J2P_GRAD_WAVES1
 #define J2P_GRAD_WAVES1 4      // waves per SIMD the 1-channel gradient kernel is register-limited to
 #endif
 #ifndef J2P_GRAD_WAVES3
 #define J2P_GRAD_WAVES3 2
 #endif
-template <int NCH, bool TGV, bool LOG>
-__global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : J2P_GRAD_WAVES3)) void k_gradient(GradArgs a)
+// NCH channels are handled inside one wavefront (J == 1, workgroup = 4 strips), or — for a
+// jointly optimised image — J wavefronts of a workgroup take one channel each of the same strip
+// and only exchange their norm contributions through LDS (J > 1, NCH == 1).
+template <int NCH, bool TGV, bool LOG, int J = 1>
+__global__ __launch_bounds__((J == 1 ? 256 : 64 * J), (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : J2P_GRAD_WAVES3))
+void k_gradient(GradArgs a)
 {
+        static_assert(J == 1 || NCH == 1, "channel-per-wavefront mode keeps one channel per wavefront");
+        __shared__ __attribute__((aligned(16))) v2f xchg[J == 1 ? 1 : 2 * J * 64 * 3];
         const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-        const int wcol = (int)blockIdx.x * 4 + wave;
+        const int wcol = J == 1 ? (int)blockIdx.x * 4 + wave : (int)blockIdx.x;
+        const int cbase = J == 1 ? 0 : wave;                    // first channel of this wavefront
         if(wcol >= (int)a.geo.ntx) { return; }
         const int W = (int)a.geo.W, H = (int)a.geo.H;
         const int rows = (int)a.geo.rows, row0 = (int)a.geo.row0;
@@ -455,8 +536,8 @@ __global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : J
                 const ptrdiff_t off = (ptrdiff_t)lc * W + xl_c;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
-                        rc[c] = *reinterpret_cast<const v2f *>(a.ch[c].xcur + off);
-                        rp[c] = *reinterpret_cast<const v2f *>(a.ch[c].xprev + off);
+                        rc[c] = *reinterpret_cast<const v2f *>(a.ch[cbase + c].xcur + off);
+                        rp[c] = *reinterpret_cast<const v2f *>(a.ch[cbase + c].xprev + off);
                 }
         };
         auto make_y = [&](int lr, const v2f (&rc)[NCH], const v2f (&rp)[NCH], v2f (&y)[NCH], bool &suspect) {
@@ -487,7 +568,7 @@ __global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : J
         int p_col[NCH][2];
 #pragma unroll
         for(int c = 0; c < NCH; c++) {
-                const ChanDev &k = a.ch[c];
+                const ChanDev &k = a.ch[cbase + c];
                 const bool on = k.prob_on && pair_own && (unsigned)xl < k.cw * k.ws;
                 p_scale[c] = on ? v2f{k.p_alpha, k.p_alpha} : v2f{0.f, 0.f};
                 const unsigned cmax = k.cw - 1;
@@ -498,7 +579,7 @@ __global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : J
         auto load_p = [&](int lt, v2f (&pv)[NCH]) {
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
-                        const ChanDev &k = a.ch[c];
+                        const ChanDev &k = a.ch[cbase + c];
                         // coefficient row of canvas row lt, clamped into the rows this band holds
                         int gt = row0 + (lt < 0 ? 0 : (lt > rows - 1 ? rows - 1 : lt));
                         unsigned cr = (unsigned)gt / k.hs;
@@ -552,10 +633,21 @@ __global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : J
                 {
                         // A row above or below the image needs no special case: its y is 0, m_gy zeroes
                         // its gy, and hy = 0 zeroes its gxy/gyy, so every term comes out 0.
-                        const bool log_row = LOG && pair_own && r >= t0 && r < t1;
+                        const bool log_row = LOG && pair_own && r >= t0 && r < t1 && cbase == 0;
                         const float hy = gr <= 0 || gr >= H ? 0.f : in_f;  // gxy, gyy = 0 on the first row (compute.c:141-143)
                         const v2f m_hy = v2f{hy, hy};
-                        if(__builtin_amdgcn_ballot_w64(prev_bad | bad[P] | bad[P1]) == 0) {
+                        if(J > 1) {
+                                const int parity = (r - t0 + 1) & 1;
+                                if(__builtin_amdgcn_ballot_w64(prev_bad | bad[P] | bad[P1]) == 0) {
+                                        source_terms_joint<J, TGV, LOG, true>(cbase, lane, parity, xchg, GX[P][0], GY[P][0], GX[PM1][0],
+                                                                              GY[PM1][0], m_hx, m_hy, a.a_tv, a.a_tgv, log_row,
+                                                                              tv_acc, tv2_acc, reinterpret_cast<SourceTerms<1, TGV> &>(s));
+                                } else {
+                                        source_terms_joint<J, TGV, LOG, false>(cbase, lane, parity, xchg, GX[P][0], GY[P][0], GX[PM1][0],
+                                                                               GY[PM1][0], m_hx, m_hy, a.a_tv, a.a_tgv, log_row,
+                                                                               tv_acc, tv2_acc, reinterpret_cast<SourceTerms<1, TGV> &>(s));
+                                }
+                        } else if(__builtin_amdgcn_ballot_w64(prev_bad | bad[P] | bad[P1]) == 0) {
                                 source_terms<NCH, TGV, LOG, true>(GX[P], GY[P], GX[PM1], GY[PM1], m_hx, m_hy, a.a_tv, a.a_tgv,
                                                                   log_row, tv_acc, tv2_acc, s);
                         } else {
@@ -570,7 +662,7 @@ __global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : J
                         const int gt = row0 + t;
 #pragma unroll
                         for(int c = 0; c < NCH; c++) {
-                                const ChanDev &k = a.ch[c];
+                                const ChanDev &k = a.ch[cbase + c];
                                 v2f g = v2f{0.f, 0.f};
                                 if((unsigned)gt < k.ch * k.hs) { g += p_scale[c] * PV[PM1][c]; }   // row t, fetched R-1 trips ago
                                 g += up.tvy[c];                  // TV from (x, t-1)
@@ -600,7 +692,7 @@ __global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : J
                                         double v = g2[c];
 #pragma unroll
                                         for(int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); }
-                                        if(lane == 0) { a.part_g2[c * nparts + (size_t)(t / kTY) * ntiles_row + wcol] = v; }
+                                        if(lane == 0) { a.part_g2[(cbase + c) * nparts + (size_t)(t / kTY) * ntiles_row + wcol] = v; }
                                         g2[c] = 0.;
                                 }
                         }
@@ -628,7 +720,7 @@ __global__ __launch_bounds__(256, (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : J
                         tv_acc += __shfl_down(tv_acc, off, 64);
                         tv2_acc += __shfl_down(tv2_acc, off, 64);
                 }
-                if(lane == 0) {
+                if(lane == 0 && cbase == 0) {
                         const size_t w = (size_t)blockIdx.y * ntiles_row + wcol;
                         a.part_tv[2 * w] = tv_acc;
                         a.part_tv[2 * w + 1] = tv2_acc;

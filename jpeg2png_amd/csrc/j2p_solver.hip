@@ -149,15 +149,18 @@ Geo geo_of(const j2p_solver *s)
         return g;
 }
 
-template <int NCH>
-void launch_gradient_n(const GradArgs &a, dim3 grid, hipStream_t st, bool tgv, bool log)
+template <int NCH, int J>
+void launch_gradient_n(const GradArgs &a, unsigned ntx, unsigned nseg, hipStream_t st, bool tgv, bool log)
 {
+        // J == 1: 4 strips per 256-thread workgroup; J > 1: one strip per workgroup of J wavefronts
+        const dim3 grid = J == 1 ? dim3((ntx + 3) / 4, nseg) : dim3(ntx, nseg);
+        const dim3 block = J == 1 ? dim3(256) : dim3(64 * J);
         if(tgv) {
-                if(log) { hipLaunchKernelGGL((k_gradient<NCH, true, true>), grid, dim3(256), 0, st, a); }
-                else { hipLaunchKernelGGL((k_gradient<NCH, true, false>), grid, dim3(256), 0, st, a); }
+                if(log) { hipLaunchKernelGGL((k_gradient<NCH, true, true, J>), grid, block, 0, st, a); }
+                else { hipLaunchKernelGGL((k_gradient<NCH, true, false, J>), grid, block, 0, st, a); }
         } else {
-                if(log) { hipLaunchKernelGGL((k_gradient<NCH, false, true>), grid, dim3(256), 0, st, a); }
-                else { hipLaunchKernelGGL((k_gradient<NCH, false, false>), grid, dim3(256), 0, st, a); }
+                if(log) { hipLaunchKernelGGL((k_gradient<NCH, false, true, J>), grid, block, 0, st, a); }
+                else { hipLaunchKernelGGL((k_gradient<NCH, false, false, J>), grid, block, 0, st, a); }
         }
 }
 
@@ -213,12 +216,22 @@ int do_phase_gradient(j2p_solver *s, bool log)
         a.part_g2 = s->part_g2;
         a.part_tv = s->part_tv;
         const bool tgv = s->weight != 0.f;
-        dim3 grid((s->ntx + 3) / 4, s->nseg);
         mark(s);
+        // joint images: one wavefront per channel (norms exchanged through LDS) gives three times the
+        // wavefronts and wins up to ~9 Mpixel; above that all channels in one wavefront is as fast
+        // (measured crossover ~3072^2).  J2P_JOINT_INWAVE=0/1 forces either.
+        const char *jenv = getenv("J2P_JOINT_INWAVE");
+        const bool inwave = jenv ? atoi(jenv) != 0 : (size_t)s->W * s->H >= ((size_t)9 << 20);
         switch(s->nch) {
-        case 1: launch_gradient_n<1>(a, grid, s->stream, tgv, log); break;
-        case 2: launch_gradient_n<2>(a, grid, s->stream, tgv, log); break;
-        default: launch_gradient_n<3>(a, grid, s->stream, tgv, log); break;
+        case 1: launch_gradient_n<1, 1>(a, s->ntx, s->nseg, s->stream, tgv, log); break;
+        case 2:
+                if(inwave) { launch_gradient_n<2, 1>(a, s->ntx, s->nseg, s->stream, tgv, log); }
+                else { launch_gradient_n<1, 2>(a, s->ntx, s->nseg, s->stream, tgv, log); }
+                break;
+        default:
+                if(inwave) { launch_gradient_n<3, 1>(a, s->ntx, s->nseg, s->stream, tgv, log); }
+                else { launch_gradient_n<1, 3>(a, s->ntx, s->nseg, s->stream, tgv, log); }
+                break;
         }
         mark(s);
         if(!s->whole) {

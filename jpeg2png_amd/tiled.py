@@ -128,6 +128,7 @@ class RowTiledSolver:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self._ops = {}
         self.up = self.rank - 1 if self.rank > 0 else None
         self.down = self.rank + 1 if self.rank < self.world - 1 else None
         counts = torch.zeros(self.world, dtype=torch.int64)
@@ -165,14 +166,22 @@ class RowTiledSolver:
         if self.world == 1:
             return
         h = self.e.halo()
-        ops = []
-        for c in range(self.e.nch):
-            if self.up is not None:
-                ops.append(dist.P2POp(dist.isend, h["send_top"][c], self.up, self.group))
-                ops.append(dist.P2POp(dist.irecv, h["recv_top"][c], self.up, self.group))
-            if self.down is not None:
-                ops.append(dist.P2POp(dist.isend, h["send_bottom"][c], self.down, self.group))
-                ops.append(dist.P2POp(dist.irecv, h["recv_bottom"][c], self.down, self.group))
+        key = tuple(t.data_ptr() for k in ("send_top", "recv_top", "send_bottom", "recv_bottom") for t in h[k])
+        ops = self._ops.get(key)
+        if ops is None:
+            # one grouped send/recv per neighbour and channel; built once per iterate buffer (the
+            # iterate ping-pongs between two buffers, so there are two op lists)
+            ops = []
+            for c in range(self.e.nch):
+                if self.up is not None:
+                    ops.append(dist.P2POp(dist.isend, h["send_top"][c], self.up, self.group))
+                    ops.append(dist.P2POp(dist.irecv, h["recv_top"][c], self.up, self.group))
+                if self.down is not None:
+                    ops.append(dist.P2POp(dist.isend, h["send_bottom"][c], self.down, self.group))
+                    ops.append(dist.P2POp(dist.irecv, h["recv_bottom"][c], self.down, self.group))
+            self._ops[key] = (ops, h)     # keep the views alive
+        else:
+            ops = ops[0]
         for w in dist.batch_isend_irecv(ops):
             w.wait()
 

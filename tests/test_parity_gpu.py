@@ -313,3 +313,47 @@ def test_tiled_engine_on_one_gpu(lib, oracle):
     finally:
         dist.destroy_process_group()
     assert bit_equal(got1, want)
+
+
+def test_out_of_range_operands_take_the_ieee_path(lib, oracle):
+    """the kernels' short division / sqrt sequences are only used inside a screened operand range;
+    inputs outside it (tiny and huge pixel values, a 16-bit quantisation table whose q*q exceeds
+    2^26) must fall back to the plain IEEE forms and still match the oracle bit for bit"""
+    import jpeg2png_amd as j
+    planes = make_case(136, 72, "420", 10, seed=77)
+    rng = np.random.default_rng(5)
+    for p in planes:
+        f = p.fdata
+        idx = rng.integers(0, f.size, 40)
+        f.reshape(-1)[idx[:10]] = 1e-30          # 0 < |y| < 2^-20: differences far below 2^-44
+        f.reshape(-1)[idx[10:20]] = -3e-39       # subnormal
+        f.reshape(-1)[idx[20:30]] = 7e-8
+        f.reshape(-1)[idx[30:]] = 3e13           # > 2^41
+    q = planes[1].quant_table.copy()
+    q[5:9] = [9000, 20000, 30000, 12345]         # q*q > 2^26: phase B's table path must switch off
+    # (q >= 32768 is avoided: there the reference's own SSE2 and C builds disagree, see DESIGN.md)
+    planes[1].quant_table = q
+    for joint in (True, False):
+        sel = planes if joint else planes[1:2]
+        pws = [0.001] * len(sel)
+        want, want_log = oracle.oracle_compute(sel, 0.3, pws, 6, log=True)
+        got = copy.deepcopy(sel)
+        got_log = j.compute(got, 0.3, pws, 6, log=True)
+        for c in range(len(sel)):
+            assert np.isfinite(want[c]).all()
+            assert bit_equal(got[c].fdata, want[c]), f"joint={joint} channel {c}"
+        np.testing.assert_allclose(got_log, want_log, rtol=1e-9, atol=1e-9)
+
+
+def test_both_joint_modes_agree(lib, oracle, monkeypatch):
+    """channels-in-one-wavefront and one-wavefront-per-channel gradient kernels are two schedules of
+    the same arithmetic"""
+    import jpeg2png_amd as j
+    planes = make_case(264, 88, "420", 10, seed=88)
+    want, _ = oracle.oracle_compute(planes, 0.3, [0.001] * 3, 7)
+    for mode in ("0", "1"):
+        monkeypatch.setenv("J2P_JOINT_INWAVE", mode)
+        got = copy.deepcopy(planes)
+        j.compute(got, 0.3, [0.001] * 3, 7)
+        for c in range(3):
+            assert bit_equal(got[c].fdata, want[c]), f"mode {mode} channel {c}"
