@@ -174,6 +174,10 @@ int j2p_planes_to_rgb(const j2p_plane_ref planes[3], unsigned w, unsigned h, uns
 int j2p_math_selftest(int device, size_t n, unsigned seed, unsigned long long *div_mismatches,
                       unsigned long long *sqrt_mismatches);
 
+/* test hook: the two packed square-root sequences of the gradient kernel against sqrtf() on EVERY
+ * float in [2^-100, 2^127) (about 1.9e9 values); both counters must come back 0 */
+int j2p_sqrt_exhaustive(int device, unsigned long long *rsq_mismatches, unsigned long long *fast_mismatches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,7 +59,7 @@ C_ABI_SYMBOLS = [
     "j2p_solver_reset", "j2p_solver_run", "j2p_solver_phase_gradient", "j2p_solver_phase_project",
     "j2p_solver_exchange_info", "j2p_solver_commit_initial_halo", "j2p_solver_download",
     "j2p_solver_plane_ptr", "j2p_solver_sync", "j2p_solver_kernel_times", "j2p_solver_enable_timing",
-    "j2p_decode_plane", "j2p_dct8x8_blocks", "j2p_math_selftest", "j2p_planes_to_rgb",
+    "j2p_decode_plane", "j2p_dct8x8_blocks", "j2p_math_selftest", "j2p_planes_to_rgb", "j2p_sqrt_exhaustive",
     "compute", "j2p_compute",
 ]
 
@@ -143,6 +143,15 @@ def math_selftest(n, seed=1, device=0):
     d, q = ctypes.c_ulonglong(), ctypes.c_ulonglong()
     _check(load_library().j2p_math_selftest(device, n, seed, ctypes.byref(d), ctypes.byref(q)))
     return d.value, q.value
+
+
+def sqrt_exhaustive(device=0):
+    """(rsq-sequence mismatches, sqrt-sequence mismatches) vs sqrtf() over every float in [2^-100, 2^127)."""
+    a, b = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+    lib = load_library()
+    lib.j2p_sqrt_exhaustive.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
+    _check(lib.j2p_sqrt_exhaustive(device, ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
 
 
 class Solver:

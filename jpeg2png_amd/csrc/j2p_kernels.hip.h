@@ -320,11 +320,30 @@ struct SourceTerms {
         v2f A[NCH], O[NCH], B[NCH], CL[NCH], CR[NCH];             // TGV2 (A is shifted left/right at its use)
 };
 
-template <bool FAST>
+// sqrtf for 2^-100 <= x < 2^127 through the reciprocal square root: the compiler's own expansion
+// for the flush-denormal mode (one v_rsq_f32, then a coupled Newton step on sqrt and 1/(2 sqrt)
+// and a final residual correction), all packed.  Correctly rounded on that whole range — checked
+// EXHAUSTIVELY against sqrtf() by j2p_sqrt_exhaustive (every float, GPU test).  Not valid for 0.
+__device__ __forceinline__ v2f sqrt_rsq(v2f x)
+{
+        const v2f r = v2f{__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)};
+        v2f s = x * r;
+        v2f h = r * 0.5f;
+        const v2f e = pk_fma(-h, s, v2f{0.5f, 0.5f});
+        h = pk_fma(h, e, h);
+        s = pk_fma(s, e, s);
+        const v2f d = pk_fma(-s, s, x);
+        return pk_fma(d, h, s);
+}
+
+// EXACT: result must be sqrtf(x) including x == 0 (the log sums read the norm itself);
+// otherwise only a positive divisor is needed when x == 0 (every numerator is 0 then)
+template <bool FAST, bool EXACT_ZERO>
 __device__ __forceinline__ v2f sqrt_pair(v2f x)
 {
-        if(FAST) { return sqrt_fast(x); }
-        return v2f{sqrtf(x.x), sqrtf(x.y)};
+        if(!FAST) { return v2f{sqrtf(x.x), sqrtf(x.y)}; }
+        if(EXACT_ZERO) { return sqrt_fast(x); }
+        return sqrt_rsq(v2f{fmaxf(x.x, 0x1p-100f), fmaxf(x.y, 0x1p-100f)});
 }
 template <bool FAST, int N>
 __device__ __forceinline__ void div_n(const v2f (&x)[N], v2f d, v2f r, v2f (&q)[N])
@@ -352,7 +371,7 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
                 n1 += gx[c] * gx[c];
                 n1 += gy[c] * gy[c];
         }
-        n1 = sqrt_pair<FAST>(n1);
+        n1 = sqrt_pair<FAST, LOG>(n1);
         if(LOG && log_row) {
                 tv += (double)(a_tv * n1.x);
                 tv += (double)(a_tv * n1.y);
@@ -387,7 +406,7 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
                         sy[c] = (gxy + gyx) * 0.5f;                     // (g_xy + g_yx) / 2.
                         n2 += xx[c] * xx[c] + 2.f * (sy[c] * sy[c]) + yy[c] * yy[c];
                 }
-                n2 = sqrt_pair<FAST>(n2);
+                n2 = sqrt_pair<FAST, LOG>(n2);
                 if(LOG && log_row) {
                         tv2 += (double)(a_tgv * n2.x);
                         tv2 += (double)(a_tgv * n2.y);
@@ -450,7 +469,7 @@ __device__ __forceinline__ void source_terms_joint(int cidx, int lane, int parit
                 n1 += o[1];
                 n2 += o[2];
         }
-        n1 = sqrt_pair<FAST>(n1);
+        n1 = sqrt_pair<FAST, LOG>(n1);
         if(LOG && log_row) {
                 tv += (double)(a_tv * n1.x);
                 tv += (double)(a_tv * n1.y);
@@ -468,7 +487,7 @@ __device__ __forceinline__ void source_terms_joint(int cidx, int lane, int parit
                 s.tvo[0] = q[2];
         }
         if(TGV) {
-                n2 = sqrt_pair<FAST>(n2);
+                n2 = sqrt_pair<FAST, LOG>(n2);
                 if(LOG && log_row) {
                         tv2 += (double)(a_tgv * n2.x);
                         tv2 += (double)(a_tgv * n2.y);
@@ -1369,6 +1388,25 @@ __global__ __launch_bounds__(256) void k_math_selftest(size_t n, unsigned seed, 
         }
         if(bad_div) { atomicAdd(&mism[0], bad_div); }
         if(bad_sqrt) { atomicAdd(&mism[1], bad_sqrt); }
+}
+
+// every float in [2^-100, 2^127): sqrt_rsq and sqrt_fast against sqrtf()
+__global__ __launch_bounds__(256) void k_sqrt_exhaustive(unsigned long long *mism /* [2] */)
+{
+        constexpr unsigned lo = 27u << 23, hi = 254u << 23;          // biased exponents 27 .. 253
+        unsigned long long bad_rsq = 0, bad_fast = 0;
+        for(unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; 2 * i + 1 < (unsigned long long)(hi - lo);
+            i += (unsigned long long)gridDim.x * 256) {
+                const v2f x = v2f{__builtin_bit_cast(float, (unsigned)(lo + 2 * i)), __builtin_bit_cast(float, (unsigned)(lo + 2 * i + 1))};
+                const v2f want = v2f{sqrtf(x.x), sqrtf(x.y)};
+                const v2f a = sqrt_rsq(x), b = sqrt_fast(x);
+                bad_rsq += (__builtin_bit_cast(unsigned, a.x) != __builtin_bit_cast(unsigned, want.x)) +
+                           (__builtin_bit_cast(unsigned, a.y) != __builtin_bit_cast(unsigned, want.y));
+                bad_fast += (__builtin_bit_cast(unsigned, b.x) != __builtin_bit_cast(unsigned, want.x)) +
+                            (__builtin_bit_cast(unsigned, b.y) != __builtin_bit_cast(unsigned, want.y));
+        }
+        if(bad_rsq) { atomicAdd(&mism[0], bad_rsq); }
+        if(bad_fast) { atomicAdd(&mism[1], bad_fast); }
 }
 
 }  // namespace j2p

@@ -854,4 +854,24 @@ int j2p_math_selftest(int device, size_t n, unsigned seed, unsigned long long *d
         return J2P_OK;
 }
 
+int j2p_sqrt_exhaustive(int device, unsigned long long *rsq_mismatches, unsigned long long *fast_mismatches)
+{
+        int ndev = 0;
+        if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { return fail(J2P_EDEVICE, "no HIP device available"); }
+        DeviceGuard guard(device);
+        if(!guard.ok) { return fail(J2P_EDEVICE, "hipSetDevice(%d) failed", device); }
+        unsigned long long *dm = nullptr, hm[2] = {0, 0};
+        HIP_TRY(hipMalloc(&dm, sizeof(hm)));
+        hipError_t e = hipMemset(dm, 0, sizeof(hm));
+        if(e == hipSuccess) {
+                hipLaunchKernelGGL(k_sqrt_exhaustive, dim3(8192), dim3(256), 0, nullptr, dm);
+                e = hipMemcpy(hm, dm, sizeof(hm), hipMemcpyDeviceToHost);
+        }
+        (void)hipFree(dm);
+        if(e != hipSuccess) { return fail(J2P_EDEVICE, "sqrt_exhaustive: %s", hipGetErrorString(e)); }
+        if(rsq_mismatches) { *rsq_mismatches = hm[0]; }
+        if(fast_mismatches) { *fast_mismatches = hm[1]; }
+        return J2P_OK;
+}
+
 }  // extern "C"

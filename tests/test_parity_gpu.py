@@ -37,6 +37,12 @@ def test_fast_division_and_sqrt_are_ieee(lib):
         assert j.math_selftest(1 << 26, seed=seed) == (0, 0)
 
 
+def test_square_roots_exhaustively(lib):
+    """both packed sqrt sequences equal sqrtf() on every float of the screened range"""
+    import jpeg2png_amd as j
+    assert j.sqrt_exhaustive() == (0, 0)
+
+
 def test_decode_plane_bit_exact(lib, oracle):
     import jpeg2png_amd as j
     from jpeg2png_amd import synth
