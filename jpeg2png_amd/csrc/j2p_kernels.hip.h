@@ -551,7 +551,9 @@ void k_gradient(GradArgs a)
         const int lr_lo = -(row0 < (int)kHalo ? row0 : (int)kHalo);                      // first readable band-local row
         const int lr_hi = rows - 1 + (H - row0 - rows < (int)kHalo ? H - row0 - rows : (int)kHalo);
         auto fetch_row = [&](int lr, v2f (&rc)[NCH], v2f (&rp)[NCH]) {
-                const int lc = lr < lr_lo ? lr_lo : (lr > lr_hi ? lr_hi : lr);
+                // rows past the strip's last needed row (t1+1) re-read that row: a cache hit, not HBM traffic
+                const int lm = lr > t1 + 1 ? t1 + 1 : lr;
+                const int lc = lm < lr_lo ? lr_lo : (lm > lr_hi ? lr_hi : lm);
                 const ptrdiff_t off = (ptrdiff_t)lc * W + xl_c;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
@@ -600,7 +602,7 @@ void k_gradient(GradArgs a)
                 for(int c = 0; c < NCH; c++) {
                         const ChanDev &k = a.ch[cbase + c];
                         // coefficient row of canvas row lt, clamped into the rows this band holds
-                        int gt = row0 + (lt < 0 ? 0 : (lt > rows - 1 ? rows - 1 : lt));
+                        const int gt = row0 + (lt < 0 ? 0 : (lt > t1 - 1 ? t1 - 1 : lt));   // past the strip: re-read its last row
                         unsigned cr = (unsigned)gt / k.hs;
                         const unsigned cr_hi = k.crow0 + (k.crows ? k.crows - 1 : 0);
                         cr = cr < k.crow0 ? k.crow0 : (cr > cr_hi ? cr_hi : cr);
