@@ -363,3 +363,30 @@ def test_both_joint_modes_agree(lib, oracle, monkeypatch):
         j.compute(got, 0.3, [0.001] * 3, 7)
         for c in range(3):
             assert bit_equal(got[c].fdata, want[c]), f"mode {mode} channel {c}"
+
+
+def test_concurrent_calls_are_independent(lib, oracle):
+    """compute() is entered concurrently by the reference's `-s` and multi-file OpenMP regions
+    (jpeg2png.c:147,330): six simultaneous calls from six host threads must each return the
+    oracle's planes"""
+    import threading
+    import jpeg2png_amd as j
+    cases = [make_case(96 + 8 * i, 64, "420" if i % 2 else "444", 10, seed=50 + i) for i in range(6)]
+    wants = [oracle.oracle_compute(p, 0.3, [0.001] * 3, 9)[0] for p in cases]
+    gots = [copy.deepcopy(p) for p in cases]
+    errs = []
+
+    def work(i):
+        try:
+            j.compute(gots[i], 0.3, [0.001] * 3, 9)
+        except Exception as e:     # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs
+    for i in range(6):
+        for c in range(3):
+            assert bit_equal(gots[i][c].fdata, wants[i][c]), f"call {i} channel {c}"
