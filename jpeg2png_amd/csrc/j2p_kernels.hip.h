@@ -524,13 +524,24 @@ void k_gradient(GradArgs a)
         static_assert(J == 1 || NCH == 1, "channel-per-wavefront mode keeps one channel per wavefront");
         __shared__ __attribute__((aligned(16))) v2f xchg[J == 1 ? 1 : 2 * J * 64 * 3];
         const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-        const int wcol = J == 1 ? (int)blockIdx.x * 4 + wave : (int)blockIdx.x;
+        // XCD-aware order (speed only): workgroup b runs on XCD b % 8, so give every XCD a contiguous,
+        // row-major run of (segment, strip-group) pairs — vertically adjacent strips then meet in one
+        // L2 and their shared halo rows are fetched from HBM once.  Bijective for any grid size.
+        unsigned bx = blockIdx.x, bseg = blockIdx.y;
+        {
+                const unsigned nwg = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+                const unsigned xcd = b & 7, q = nwg >> 3, rem = nwg & 7;
+                const unsigned l = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
+                bx = l % gridDim.x;
+                bseg = l / gridDim.x;
+        }
+        const int wcol = J == 1 ? (int)bx * 4 + wave : (int)bx;
         const int cbase = J == 1 ? 0 : wave;                    // first channel of this wavefront
         if(wcol >= (int)a.geo.ntx) { return; }
         const int W = (int)a.geo.W, H = (int)a.geo.H;
         const int rows = (int)a.geo.rows, row0 = (int)a.geo.row0;
         const int rpw = (int)a.geo.rpw;
-        const int t0 = (int)blockIdx.y * rpw;                  // band-local target rows [t0, t1)
+        const int t0 = (int)bseg * rpw;                        // band-local target rows [t0, t1)
         const int t1 = t0 + rpw < rows ? t0 + rpw : rows;
         const int xl = wcol * kStripCols - 2 + lane * 2;       // canvas column of .x (even; W is even too)
 
@@ -742,7 +753,7 @@ void k_gradient(GradArgs a)
                         tv2_acc += __shfl_down(tv2_acc, off, 64);
                 }
                 if(lane == 0 && cbase == 0) {
-                        const size_t w = (size_t)blockIdx.y * ntiles_row + wcol;
+                        const size_t w = (size_t)bseg * ntiles_row + wcol;
                         a.part_tv[2 * w] = tv_acc;
                         a.part_tv[2 * w + 1] = tv2_acc;
                 }
