@@ -543,10 +543,14 @@ void k_gradient(GradArgs a)
         const int rpw = (int)a.geo.rpw;
         const int t0 = (int)bseg * rpw;                        // band-local target rows [t0, t1)
         const int t1 = t0 + rpw < rows ? t0 + rpw : rows;
-        const int xl = wcol * kStripCols - 2 + lane * 2;       // canvas column of .x (even; W is even too)
+        // Strip i loads columns [124 i, 124 i + 128); lanes 0 and 63 are halo — except at the image's
+        // left and right edges, where the neighbour beyond the edge contributes nothing anyway, so the
+        // first strip also owns its lane 0 and the last strip its lane 63: n strips cover 124 n + 4
+        // columns (33 strips for W = 4096).
+        const int xl = wcol * kStripCols + lane * 2;           // canvas column of .x (even; W is even too)
 
         const bool pair_in = xl >= 0 && xl < W;                // both columns in the image, or neither
-        const bool pair_own = pair_in && lane >= 1 && lane <= 62;
+        const bool pair_own = pair_in && (lane >= 1 || wcol == 0) && (lane <= 62 || xl + 2 >= W);
         // per-lane constant masks (1.f / 0.f), multiplied instead of selected: v*1 is exact, v*0 = +-0
         const float in_f = pair_in ? 1.f : 0.f;
         const v2f m_gx = v2f{in_f, xl + 1 >= W - 1 ? 0.f : in_f};   // gx = 0 on the last column (compute.c:79)

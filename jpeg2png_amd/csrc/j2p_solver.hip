@@ -517,7 +517,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 }
         }
         // reductions: tile rows are counted on the canvas, the band owns a contiguous range
-        s->ntx = (W + kStripCols - 1) / kStripCols;
+        s->ntx = W <= 4 ? 1 : (W - 4 + kStripCols - 1) / kStripCols;   // n strips cover 124 n + 4 columns
         {
                 // rows per gradient strip: a multiple of the 16-row partial granularity
                 const char *env = getenv("J2P_RPW");
