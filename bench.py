@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=0, help="override plane width (debug)")
+    ap.add_argument("--height", type=int, default=0, help="override plane height (debug, single GPU)")
     ap.add_argument("--iterations", type=int, default=0, help="override iterations per solve (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timing-every", type=int, default=4, help="HIP-event sample stride (iterations)")
@@ -99,7 +100,7 @@ def main():
     tiled_mode = n_gpus > 1 or a.force_tiled
     if not tiled_mode:
         W = a.size or 4096
-        H = W
+        H = a.height or W
         its = a.iterations or 500
         seed = 1234 + 3
         workload = f"{W}x{H} Y-only Q10 -i {its} (BASELINE configs[2])"

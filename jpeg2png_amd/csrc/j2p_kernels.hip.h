@@ -157,6 +157,7 @@ struct Geo {
         unsigned rows;      // band rows
         unsigned ntx;       // gradient strips (wavefronts) per row of strips
         unsigned rpw;       // rows per gradient strip (multiple of kTY)
+        const unsigned *seg_row;   // [nseg + 1] first band-local row of every row segment (multiples of kTY)
 };
 
 struct GradArgs {
@@ -535,14 +536,13 @@ void k_gradient(GradArgs a)
                 bx = l % gridDim.x;
                 bseg = l / gridDim.x;
         }
-        const int wcol = J == 1 ? (int)bx * 4 + wave : (int)bx;
+        const int wcol = J == 1 ? (int)bx * (int)(blockDim.x >> 6) + wave : (int)bx;   // J == 1: blockDim.x / 64 strips per workgroup
         const int cbase = J == 1 ? 0 : wave;                    // first channel of this wavefront
         if(wcol >= (int)a.geo.ntx) { return; }
         const int W = (int)a.geo.W, H = (int)a.geo.H;
         const int rows = (int)a.geo.rows, row0 = (int)a.geo.row0;
-        const int rpw = (int)a.geo.rpw;
-        const int t0 = (int)bseg * rpw;                        // band-local target rows [t0, t1)
-        const int t1 = t0 + rpw < rows ? t0 + rpw : rows;
+        const int t0 = (int)a.geo.seg_row[bseg];               // band-local target rows [t0, t1)
+        const int t1 = (int)a.geo.seg_row[bseg + 1];
         // Strip i loads columns [124 i, 124 i + 128); lanes 0 and 63 are halo — except at the image's
         // left and right edges, where the neighbour beyond the edge contributes nothing anyway, so the
         // first strip also owns its lane 0 and the last strip its lane 63: n strips cover 124 n + 4

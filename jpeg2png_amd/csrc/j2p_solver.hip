@@ -75,6 +75,7 @@ struct j2p_solver {
         bool grad_done = false;
         // reductions
         unsigned rpw = 16;
+        unsigned *seg_row = nullptr;     // device: [nseg + 1] segment start rows
         unsigned ntx = 0, nseg = 0, ntr_local = 0, ntr_global = 0, first_tr = 0;   // strips per row, row segments
         double *part_g2 = nullptr;       // [c][ntr_local][ntx]
         double *rowsum_local = nullptr;  // [ntr_local][c]
@@ -146,6 +147,7 @@ Geo geo_of(const j2p_solver *s)
         g.rows = s->rows;
         g.ntx = s->ntx;
         g.rpw = s->rpw;
+        g.seg_row = s->seg_row;
         return g;
 }
 
@@ -153,8 +155,9 @@ template <int NCH, int J>
 void launch_gradient_n(const GradArgs &a, unsigned ntx, unsigned nseg, hipStream_t st, bool tgv, bool log)
 {
         // J == 1: 4 strips per 256-thread workgroup; J > 1: one strip per workgroup of J wavefronts
-        const dim3 grid = J == 1 ? dim3((ntx + 3) / 4, nseg) : dim3(ntx, nseg);
-        const dim3 block = J == 1 ? dim3(256) : dim3(64 * J);
+        static const unsigned wpb = getenv("J2P_GRAD_WPB") ? (unsigned)atoi(getenv("J2P_GRAD_WPB")) : 4u;   // strips per workgroup
+        const dim3 grid = J == 1 ? dim3((ntx + wpb - 1) / wpb, nseg) : dim3(ntx, nseg);
+        const dim3 block = J == 1 ? dim3(64 * wpb) : dim3(64 * J);
         if(tgv) {
                 if(log) { hipLaunchKernelGGL((k_gradient<NCH, true, true, J>), grid, block, 0, st, a); }
                 else { hipLaunchKernelGGL((k_gradient<NCH, true, false, J>), grid, block, 0, st, a); }
@@ -361,6 +364,7 @@ void j2p_solver_destroy(j2p_solver *s)
                 (void)hipFree(h.decoded);
         }
         (void)hipFree(s->part_g2);
+        (void)hipFree(s->seg_row);
         (void)hipFree(s->rowsum_local);
         if(s->rowsum_all != s->rowsum_local) { (void)hipFree(s->rowsum_all); }
         (void)hipFree(s->norm);
@@ -525,7 +529,35 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 if(rpw < (unsigned)kTY) { rpw = kTY; }
                 s->rpw = rpw / kTY * kTY;
         }
-        s->nseg = (s->rows + s->rpw - 1) / s->rpw;
+        {
+                // Row segments of the gradient kernel: uniform segments of rpw rows.  J2P_NLONG=n makes the
+                // first n segments (spread over the 8 XCD bands) twice as long — an experiment knob: mixing
+                // wavefront lengths did not shorten the kernel's tail on MI355X.  Segment
+                // boundaries stay multiples of kTY, so the norm partials — and the results — do not depend
+                // on this choice.
+                const unsigned units = (s->rows + s->rpw - 1) / s->rpw;       // uniform segments
+                const char *env = getenv("J2P_NLONG");
+                unsigned nlong_total = env ? (unsigned)atoi(env) : 0u;
+                if(nlong_total * 2 > units) { nlong_total = units / 2; }
+                std::vector<unsigned> seg;
+                seg.push_back(0);
+                const unsigned bands = units >= 64 ? 8 : 1;
+                unsigned u = 0;
+                for(unsigned b = 0; b < bands; b++) {
+                        const unsigned u_end = (unsigned)((unsigned long long)units * (b + 1) / bands);
+                        unsigned nl = nlong_total / bands + (b < nlong_total % bands ? 1 : 0);
+                        while(u < u_end) {
+                                unsigned take = (nl > 0 && u + 2 <= u_end) ? 2 : 1;
+                                if(take == 2) { nl--; }
+                                u += take;
+                                const unsigned row = u * s->rpw;
+                                seg.push_back(row < s->rows ? row : s->rows);
+                        }
+                }
+                s->nseg = (unsigned)seg.size() - 1;
+                CREATE_TRY(hipMalloc(&s->seg_row, seg.size() * sizeof(unsigned)));
+                CREATE_TRY(hipMemcpy(s->seg_row, seg.data(), seg.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        }
         s->ntr_local = (s->rows + kTY - 1) / kTY;
         s->ntr_global = (H + kTY - 1) / kTY;
         s->first_tr = row0 / kTY;
