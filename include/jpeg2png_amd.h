@@ -113,6 +113,16 @@ int j2p_solver_run(j2p_solver *s, unsigned n, j2p_log_row *rows);
 int j2p_solver_phase_gradient(j2p_solver *s);
 int j2p_solver_phase_project(j2p_solver *s);
 
+/* phase_gradient in two parts, to hide the halo exchange behind compute: the INTERIOR part
+ * (every 16-row segment except the band's first and last) reads no halo row and can be issued
+ * straight after phase_project; the EDGES part needs the neighbours' rows and may go to another
+ * stream (NULL = the solver's).  Once the solver's stream has been made to wait for the EDGES
+ * part, j2p_solver_phase_rowsums() finishes the phase (partials_local is valid after it). */
+#define J2P_GRADIENT_INTERIOR 1
+#define J2P_GRADIENT_EDGES    2
+int j2p_solver_phase_gradient_part(j2p_solver *s, int part, void *stream);
+int j2p_solver_phase_rowsums(j2p_solver *s);
+
 /* Device addresses the caller needs for the exchanges (all on the solver's device).
  *   partials_local : nchannel * local_tile_rows doubles written by phase_gradient
  *   partials_all   : nchannel * global_tile_rows doubles read by phase_project;

@@ -57,6 +57,7 @@ C_ABI_SYMBOLS = [
     "j2p_version", "j2p_last_error", "j2p_device_count",
     "j2p_solver_create", "j2p_solver_destroy", "j2p_solver_canvas", "j2p_solver_band",
     "j2p_solver_reset", "j2p_solver_run", "j2p_solver_phase_gradient", "j2p_solver_phase_project",
+    "j2p_solver_phase_gradient_part", "j2p_solver_phase_rowsums",
     "j2p_solver_exchange_info", "j2p_solver_commit_initial_halo", "j2p_solver_download",
     "j2p_solver_plane_ptr", "j2p_solver_sync", "j2p_solver_kernel_times", "j2p_solver_enable_timing",
     "j2p_decode_plane", "j2p_dct8x8_blocks", "j2p_math_selftest", "j2p_planes_to_rgb", "j2p_sqrt_exhaustive",
@@ -87,8 +88,9 @@ def load_library():
                                       ctypes.POINTER(ctypes.c_float), ctypes.c_uint, _CBand, ctypes.c_int]
     lib.j2p_solver_destroy.argtypes = [ctypes.c_void_p]
     lib.j2p_solver_destroy.restype = None
+    lib.j2p_solver_phase_gradient_part.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     for name in ("j2p_solver_reset", "j2p_solver_phase_gradient", "j2p_solver_phase_project",
-                 "j2p_solver_sync", "j2p_solver_commit_initial_halo"):
+                 "j2p_solver_sync", "j2p_solver_commit_initial_halo", "j2p_solver_phase_rowsums"):
         getattr(lib, name).argtypes = [ctypes.c_void_p]
     lib.j2p_solver_canvas.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
     lib.j2p_solver_band.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
@@ -217,6 +219,14 @@ class Solver:
 
     def phase_project(self):
         _check(self._lib.j2p_solver_phase_project(self._h))
+
+    def phase_gradient_part(self, part, stream=None):
+        """part 1 = interior segments (no halo needed), 2 = the band's first/last segment (optionally
+        on another hipStream_t); follow part 2 with phase_rowsums() once the solver's stream waits for it."""
+        _check(self._lib.j2p_solver_phase_gradient_part(self._h, int(part), stream))
+
+    def phase_rowsums(self):
+        _check(self._lib.j2p_solver_phase_rowsums(self._h))
 
     def commit_initial_halo(self):
         _check(self._lib.j2p_solver_commit_initial_halo(self._h))

@@ -158,6 +158,7 @@ struct Geo {
         unsigned ntx;       // gradient strips (wavefronts) per row of strips
         unsigned rpw;       // rows per gradient strip (multiple of kTY)
         const unsigned *seg_row;   // [nseg + 1] first band-local row of every row segment (multiples of kTY)
+        const unsigned *seg_map;   // [gridDim.y] segments this launch processes (all, interior only, or the two edge ones)
 };
 
 struct GradArgs {
@@ -534,7 +535,7 @@ void k_gradient(GradArgs a)
                 const unsigned xcd = b & 7, q = nwg >> 3, rem = nwg & 7;
                 const unsigned l = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
                 bx = l % gridDim.x;
-                bseg = l / gridDim.x;
+                bseg = a.geo.seg_map[l / gridDim.x];
         }
         const int wcol = J == 1 ? (int)bx * (int)(blockDim.x >> 6) + wave : (int)bx;   // J == 1: blockDim.x / 64 strips per workgroup
         const int cbase = J == 1 ? 0 : wave;                    // first channel of this wavefront

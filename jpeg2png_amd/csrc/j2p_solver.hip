@@ -76,6 +76,9 @@ struct j2p_solver {
         // reductions
         unsigned rpw = 16;
         unsigned *seg_row = nullptr;     // device: [nseg + 1] segment start rows
+        unsigned *seg_map = nullptr;     // device: [nseg] identity, then [nseg - 2] interior, then [2] first/last
+        bool interior_done = false;
+        bool rowsums_pending = false;
         unsigned ntx = 0, nseg = 0, ntr_local = 0, ntr_global = 0, first_tr = 0;   // strips per row, row segments
         double *part_g2 = nullptr;       // [c][ntr_local][ntx]
         double *rowsum_local = nullptr;  // [ntr_local][c]
@@ -148,6 +151,7 @@ Geo geo_of(const j2p_solver *s)
         g.ntx = s->ntx;
         g.rpw = s->rpw;
         g.seg_row = s->seg_row;
+        g.seg_map = s->seg_map;
         return g;
 }
 
@@ -201,17 +205,31 @@ int flush_timing(j2p_solver *s)
         return J2P_OK;
 }
 
-int do_phase_gradient(j2p_solver *s, bool log)
+// part: 0 = all segments, 1 = interior segments only (they never read halo rows), 2 = the first and
+// last segment (after the halo rows have arrived).  1 then 2 make one gradient phase; `st` is the stream
+// the kernel goes to (part 2 may use a side stream so that it overlaps part 1).
+int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nullptr)
 {
         if(s->grad_done) { return fail(J2P_ESTATE, "phase_gradient called twice without phase_project"); }
-        // FISTA scalars in float, as compute.c:431-432,440
-        const float tnext = (1 + sqrtf(1 + 4 * (s->t * s->t))) / 2;
-        s->factor = (s->t - 1) / tnext;
-        s->t = tnext;
+        if(part == 2 && !s->interior_done) { return fail(J2P_ESTATE, "gradient boundary part before the interior part"); }
+        if(part != 2 && s->interior_done) { return fail(J2P_ESTATE, "gradient interior part issued twice"); }
+        if(part != 0 && s->nseg < 3) { return fail(J2P_ESTATE, "band too short to split the gradient phase"); }
+        if(!st) { st = s->stream; }
+        if(part != 2) {
+                // FISTA scalars in float, as compute.c:431-432,440
+                const float tnext = (1 + sqrtf(1 + 4 * (s->t * s->t))) / 2;
+                s->factor = (s->t - 1) / tnext;
+                s->t = tnext;
+        }
+        unsigned nseg_launch = s->nseg;
+        const unsigned *map = s->seg_map;
+        if(part == 1) { nseg_launch = s->nseg - 2; map = s->seg_map + s->nseg; }
+        if(part == 2) { nseg_launch = 2; map = s->seg_map + s->nseg + (s->nseg - 2); }
 
         GradArgs a;
         for(unsigned c = 0; c < s->nch; c++) { a.ch[c] = chan_dev(s, c); }
         a.geo = geo_of(s);
+        a.geo.seg_map = map;
         a.factor = s->factor;
         a.a_tv = (float)(1. / (double)sqrtf((float)s->nch));                    // compute.c:90
         const float alpha = s->weight / sqrtf((float)(4 / 2));                  // compute.c:258
@@ -219,37 +237,59 @@ int do_phase_gradient(j2p_solver *s, bool log)
         a.part_g2 = s->part_g2;
         a.part_tv = s->part_tv;
         const bool tgv = s->weight != 0.f;
-        mark(s);
+        if(part != 2) { mark(s); }     // event timing covers the main launch only (the edge part runs on another stream)
         // joint images: one wavefront per channel (norms exchanged through LDS) gives three times the
         // wavefronts and wins up to ~9 Mpixel; above that all channels in one wavefront is as fast
         // (measured crossover ~3072^2).  J2P_JOINT_INWAVE=0/1 forces either.
         const char *jenv = getenv("J2P_JOINT_INWAVE");
         const bool inwave = jenv ? atoi(jenv) != 0 : (size_t)s->W * s->H >= ((size_t)9 << 20);
         switch(s->nch) {
-        case 1: launch_gradient_n<1, 1>(a, s->ntx, s->nseg, s->stream, tgv, log); break;
+        case 1: launch_gradient_n<1, 1>(a, s->ntx, nseg_launch, st, tgv, log); break;
         case 2:
-                if(inwave) { launch_gradient_n<2, 1>(a, s->ntx, s->nseg, s->stream, tgv, log); }
-                else { launch_gradient_n<1, 2>(a, s->ntx, s->nseg, s->stream, tgv, log); }
+                if(inwave) { launch_gradient_n<2, 1>(a, s->ntx, nseg_launch, st, tgv, log); }
+                else { launch_gradient_n<1, 2>(a, s->ntx, nseg_launch, st, tgv, log); }
                 break;
         default:
-                if(inwave) { launch_gradient_n<3, 1>(a, s->ntx, s->nseg, s->stream, tgv, log); }
-                else { launch_gradient_n<1, 3>(a, s->ntx, s->nseg, s->stream, tgv, log); }
+                if(inwave) { launch_gradient_n<3, 1>(a, s->ntx, nseg_launch, st, tgv, log); }
+                else { launch_gradient_n<1, 3>(a, s->ntx, nseg_launch, st, tgv, log); }
                 break;
         }
-        mark(s);
-        if(!s->whole) {
+        if(part != 2) { mark(s); }
+        HIP_TRY(hipGetLastError());
+        if(part == 1) {
+                s->interior_done = true;
+                return J2P_OK;
+        }
+        s->interior_done = false;
+        if(part == 0 && !s->whole) {
                 const unsigned nrs = s->ntr_local * s->nch;
                 hipLaunchKernelGGL(k_rowsums, dim3((nrs + 255) / 256), dim3(256), 0, s->stream,
                                    (const double *)s->part_g2, s->rowsum_local, s->ntx, s->ntr_local, s->nch);
+                HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipGetLastError());
         s->grad_done = true;
+        s->rowsums_pending = part == 2 && !s->whole;
+        return J2P_OK;
+}
+
+// after a split gradient phase: per-tile-row sums on the solver's stream (the caller has made that
+// stream wait for the boundary part)
+int do_rowsums(j2p_solver *s)
+{
+        if(!s->grad_done) { return fail(J2P_ESTATE, "rowsums without a finished gradient phase"); }
+        if(!s->rowsums_pending) { return J2P_OK; }     // whole-canvas solver: folded into the norm kernel
+        const unsigned nrs = s->ntr_local * s->nch;
+        hipLaunchKernelGGL(k_rowsums, dim3((nrs + 255) / 256), dim3(256), 0, s->stream,
+                           (const double *)s->part_g2, s->rowsum_local, s->ntx, s->ntr_local, s->nch);
+        HIP_TRY(hipGetLastError());
+        s->rowsums_pending = false;
         return J2P_OK;
 }
 
 int do_phase_project(j2p_solver *s, bool log)
 {
         if(!s->grad_done) { return fail(J2P_ESTATE, "phase_project called before phase_gradient"); }
+        if(s->rowsums_pending) { return fail(J2P_ESTATE, "phase_project before j2p_solver_phase_rowsums"); }
         unsigned P = 1;
         while(P < s->ntr_global) { P <<= 1; }
         if(s->whole) {
@@ -327,6 +367,8 @@ int launch_init(j2p_solver *s)
         s->t = 1.f;
         s->cur = 0;
         s->grad_done = false;
+        s->interior_done = false;
+        s->rowsums_pending = false;
         for(unsigned c = 0; c < kMaxCh; c++) { s->carried_prob[c] = 0.; }
         s->carried_valid = true;
         return J2P_OK;
@@ -365,6 +407,7 @@ void j2p_solver_destroy(j2p_solver *s)
         }
         (void)hipFree(s->part_g2);
         (void)hipFree(s->seg_row);
+        (void)hipFree(s->seg_map);
         (void)hipFree(s->rowsum_local);
         if(s->rowsum_all != s->rowsum_local) { (void)hipFree(s->rowsum_all); }
         (void)hipFree(s->norm);
@@ -557,6 +600,14 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 s->nseg = (unsigned)seg.size() - 1;
                 CREATE_TRY(hipMalloc(&s->seg_row, seg.size() * sizeof(unsigned)));
                 CREATE_TRY(hipMemcpy(s->seg_row, seg.data(), seg.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+                // launch lists: all segments | interior segments | the two edge segments
+                std::vector<unsigned> map;
+                for(unsigned i = 0; i < s->nseg; i++) { map.push_back(i); }
+                for(unsigned i = 1; i + 1 < s->nseg; i++) { map.push_back(i); }
+                map.push_back(0);
+                map.push_back(s->nseg - 1);
+                CREATE_TRY(hipMalloc(&s->seg_map, map.size() * sizeof(unsigned)));
+                CREATE_TRY(hipMemcpy(s->seg_map, map.data(), map.size() * sizeof(unsigned), hipMemcpyHostToDevice));
         }
         s->ntr_local = (s->rows + kTY - 1) / kTY;
         s->ntr_global = (H + kTY - 1) / kTY;
@@ -614,6 +665,21 @@ int j2p_solver_phase_gradient(j2p_solver *s)
         if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
         DeviceGuard guard(s->device);
         return do_phase_gradient(s, false);
+}
+
+int j2p_solver_phase_gradient_part(j2p_solver *s, int part, void *stream)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        if(part != J2P_GRADIENT_INTERIOR && part != J2P_GRADIENT_EDGES) { return fail(J2P_EINVAL, "part must be J2P_GRADIENT_INTERIOR or J2P_GRADIENT_EDGES"); }
+        DeviceGuard guard(s->device);
+        return do_phase_gradient(s, false, part, (hipStream_t)stream);
+}
+
+int j2p_solver_phase_rowsums(j2p_solver *s)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        DeviceGuard guard(s->device);
+        return do_rowsums(s);
 }
 
 int j2p_solver_phase_project(j2p_solver *s)

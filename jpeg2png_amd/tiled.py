@@ -82,6 +82,9 @@ class HipBandEngine:
         self.partials_all = alias_tensor(e.partials_all, e.global_tile_rows * self.nch, torch.float64, self.device)
         self._halo = {}
         self._parity = 0
+        self.side = torch.cuda.Stream(device=self.device)     # edge segments of the gradient phase
+        self.comm = torch.cuda.Stream(device=self.device)     # halo exchange
+        self._edges_done = None
 
     def _views(self):
         if self._parity not in self._halo:
@@ -106,6 +109,32 @@ class HipBandEngine:
         self.solver.phase_project()
         self._parity ^= 1           # the iterate now lives in the other buffer
 
+    # -- gradient phase split in two, to overlap the halo exchange with compute ----------------
+    @property
+    def can_split(self):
+        return (self.solver.row_end - self.solver.row_begin) >= 3 * J2P_TILE_ROWS
+
+    def gradient_interior(self):
+        """all segments but the band's first and last: no halo row is read (solver stream)"""
+        self.solver.phase_gradient_part(1)
+
+    def gradient_edges(self, halo_ready=None):
+        """first/last segment on a side stream, after `halo_ready` (event recorded behind the
+        arrival of the neighbours' rows); returns nothing, finish_gradient() joins"""
+        if halo_ready is not None:
+            self.side.wait_event(halo_ready)
+        else:
+            self.side.wait_stream(self.stream)
+        self.solver.phase_gradient_part(2, ctypes.c_void_p(self.side.cuda_stream))
+        self._edges_done = self.side.record_event()
+
+    def finish_gradient(self):
+        self.stream.wait_event(self._edges_done)
+        self.solver.phase_rowsums()
+
+    def project_done_event(self):
+        return self.stream.record_event()
+
     def commit_initial_halo(self):
         self.solver.commit_initial_halo()
 
@@ -121,11 +150,18 @@ class HipBandEngine:
 
 
 class RowTiledSolver:
-    """Drives one band engine per rank through the iteration loop (compute.c:427-453)."""
+    """Drives one band engine per rank through the iteration loop (compute.c:427-453).
 
-    def __init__(self, engine, group=None):
+    overlap=True (default where the engine supports it): the halo exchange runs on its own stream
+    while the interior of the next gradient phase is already computing; only the band's first and
+    last 16-row segments wait for the neighbours' rows.  The all-gather of the norm partials stays
+    on the critical path (it is the global dependency of the algorithm)."""
+
+    def __init__(self, engine, group=None, overlap=True):
         self.e = engine
         self.group = group
+        self.overlap = bool(overlap) and getattr(engine, "can_split", False)
+        self._halo_ready = None
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self._ops = {}
@@ -191,11 +227,37 @@ class RowTiledSolver:
         with self.e.stream_context():
             self.exchange_halo()
             self.e.commit_initial_halo()
+        self._halo_ready = None            # the solver's stream itself is behind the exchange
+
+    def _exchange_halo_async(self):
+        """halo exchange on the engine's comm stream, behind everything issued so far on the
+        solver's stream; returns the event that marks the arrival of the neighbours' rows"""
+        e = self.e
+        done = e.project_done_event()
+        with torch.cuda.stream(e.comm):
+            e.comm.wait_event(done)
+            self.exchange_halo()
+            return e.comm.record_event()
 
     def iterate(self, n):
-        with self.e.stream_context():
-            for _ in range(n):
-                self.e.phase_gradient()
+        e = self.e
+        if not self.overlap:
+            with e.stream_context():
+                for _ in range(n):
+                    e.phase_gradient()
+                    self.gather_partials()
+                    e.phase_project()
+                    self.exchange_halo()
+            return
+        for _ in range(n):
+            with e.stream_context():
+                e.gradient_interior()
+            e.gradient_edges(self._halo_ready)
+            with e.stream_context():
+                e.finish_gradient()
                 self.gather_partials()
-                self.e.phase_project()
-                self.exchange_halo()
+                e.phase_project()
+            self._halo_ready = self._exchange_halo_async()
+        # leave the solver's stream consistent for whoever comes next (download, reset, ...)
+        if self._halo_ready is not None:
+            e.stream.wait_event(self._halo_ready)

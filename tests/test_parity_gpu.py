@@ -305,6 +305,49 @@ def test_tiled_engine_on_one_gpu(lib, oracle):
             e.close()
     assert bit_equal(got, want)
 
+    # (a') the same two bands with the gradient phase split (interior | edges on a side stream) and
+    #      the halo copies on a third stream, exactly the event choreography of RowTiledSolver(overlap)
+    eng = [tiled.HipBandEngine(band_planes(*b), 0.3, [0.001], its, b, 0) for b in bands]
+    try:
+        comm = torch.cuda.Stream()
+
+        def halo_swap_async():
+            done = [e.project_done_event() for e in eng]
+            with torch.cuda.stream(comm):
+                for d in done:
+                    comm.wait_event(d)
+                h0, h1 = eng[0].halo(), eng[1].halo()
+                h1["recv_top"][0].copy_(h0["send_bottom"][0], non_blocking=True)
+                h0["recv_bottom"][0].copy_(h1["send_top"][0], non_blocking=True)
+                return comm.record_event()
+        ready = halo_swap_async()
+        for e in eng:
+            e.stream.wait_event(ready)
+            e.commit_initial_halo()
+        ready = None
+        for _ in range(its):
+            for e in eng:
+                assert e.can_split
+                with e.stream_context():
+                    e.gradient_interior()
+                e.gradient_edges(ready)
+            for e in eng:
+                with e.stream_context():
+                    e.finish_gradient()
+            torch.cuda.synchronize()
+            allp = torch.cat([e.partials_local for e in eng])
+            for e in eng:
+                with e.stream_context():
+                    e.partials_all.copy_(allp)
+                    e.phase_project()
+            ready = halo_swap_async()
+        torch.cuda.synchronize()
+        got2 = np.concatenate([e.download(0) for e in eng], axis=0)
+    finally:
+        for e in eng:
+            e.close()
+    assert bit_equal(got2, want)
+
     # (b) the real driver over a 1-rank RCCL group
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29731")
@@ -312,13 +355,20 @@ def test_tiled_engine_on_one_gpu(lib, oracle):
     try:
         e = tiled.HipBandEngine(band_planes(0, H), 0.3, [0.001], its, (0, H), 0)
         drv = tiled.RowTiledSolver(e)
+        assert drv.overlap
         drv.start()
         drv.iterate(its)
         got1 = e.download(0)
+        e.reset()
+        drv2 = tiled.RowTiledSolver(e, overlap=False)
+        drv2.start()
+        drv2.iterate(its)
+        got1b = e.download(0)
         e.close()
     finally:
         dist.destroy_process_group()
     assert bit_equal(got1, want)
+    assert bit_equal(got1b, want)
 
 
 def test_out_of_range_operands_take_the_ieee_path(lib, oracle):
