@@ -19,6 +19,8 @@ def build(ref=True):
     subprocess.run(["make", "-s", "-C", _HERE, "oracle"], check=True)
     if ref:
         subprocess.run(["make", "-s", "-C", _HERE, "ref"], check=True)
+        # the whole reference program, for the end-to-end CLI test (needs libjpeg/libpng headers)
+        subprocess.run(["make", "-s", "-C", _HERE, "ref-cli"], check=False)
 
 
 class _OPlane(ctypes.Structure):
