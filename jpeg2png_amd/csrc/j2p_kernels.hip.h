@@ -228,10 +228,11 @@ __device__ __forceinline__ double block_sum(double v, double *red /* >= 4 double
 // against the neighbouring floats), written on float2 so that it issues as v_pk_fma.
 // It is bit-identical to `/` and sqrtf() whenever the compiler's version would not
 // have rescaled its operands, and that is guaranteed by screening the INPUT of the
-// whole stencil once per loaded pixel: if every y is 0 or 2^-20 <= |y| < 2^40, all
+// whole stencil once per loaded pixel: if every y is 0 or 2^-20 <= |y| < 2^41, all
 // first/second differences are multiples of 2^-44, hence 0 or >= 2^-44, their
 // squares are normal, the norms lie in [2^-43, 2^43] and no quotient is subnormal.
-// A wavefront that loads a pixel outside that range (never seen on image data)
+// A wavefront that loads a pixel outside that range (in practice: rounding noise around 0 in
+// the chroma of a flat grey area, where the all-zero coefficient blocks decode to exactly 0)
 // takes the plain `/` and sqrtf() path for the rows that pixel touches.
 // ---------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -283,13 +284,17 @@ __device__ __forceinline__ void div_shared_n(const v2f (&x)[N], v2f d, v2f r, v2
 }
 
 // true when a loaded pixel is outside the range for which the fast paths are exact:
-// 0 < |y| < 2^-20 (y * 2^-106 is subnormal), |y| >= 2^41 (y * 2^87 overflows), or NaN
+// 0 < |y| < 2^-20, |y| >= 2^41, or NaN.  Three compares per element; flat regions whose pixels
+// are rounding noise around 0 (1e-17 in the chroma of a grey area) do occur in image data, so
+// the lower bound has to hold all the way down to the subnormals.
+__device__ __forceinline__ bool in_fast_range(float v, float lo, float hi)
+{
+        const float av = __builtin_fabsf(v);
+        return (av >= lo && av < hi) || v == 0.f;
+}
 __device__ __forceinline__ bool y_suspect(v2f y)
 {
-        const v2f lo = y * 0x1p-106f, hi = y * 0x1p87f;
-        constexpr int kDenorm = 0x090, kInfNan = 0x207;
-        return __builtin_amdgcn_classf(lo.x, kDenorm) | __builtin_amdgcn_classf(lo.y, kDenorm) |
-               __builtin_amdgcn_classf(hi.x, kInfNan) | __builtin_amdgcn_classf(hi.y, kInfNan);
+        return !(in_fast_range(y.x, 0x1p-20f, 0x1p41f) && in_fast_range(y.y, 0x1p-20f, 0x1p41f));
 }
 
 // sqrtf for 0 or 2^-96 <= x < 2^126: v_sqrt_f32 is within 1 ulp; pick the correctly rounded
@@ -887,10 +892,7 @@ __device__ __forceinline__ float stepped(const ChanDev &k, ptrdiff_t off, float 
 // numerator screen of the short division: 0 < |x| < 2^-100, |x| >= 2^61, or NaN
 __device__ __forceinline__ bool num_suspect(v2f x)
 {
-        const v2f lo = x * 0x1p-26f, hi = x * 0x1p67f;
-        constexpr int kDenorm = 0x090, kInfNan = 0x207;
-        return __builtin_amdgcn_classf(lo.x, kDenorm) | __builtin_amdgcn_classf(lo.y, kDenorm) |
-               __builtin_amdgcn_classf(hi.x, kInfNan) | __builtin_amdgcn_classf(hi.y, kInfNan);
+        return !(in_fast_range(x.x, 0x1p-100f, 0x1p61f) && in_fast_range(x.y, 0x1p-100f, 0x1p61f));
 }
 __device__ __forceinline__ bool den_ok(float d) { return d >= 0x1p-20f && d <= 0x1p26f; }
 __device__ __forceinline__ float div_prepare1(float d)

@@ -401,6 +401,44 @@ def test_out_of_range_operands_take_the_ieee_path(lib, oracle):
         np.testing.assert_allclose(got_log, want_log, rtol=1e-9, atol=1e-9)
 
 
+def test_noise_around_zero_takes_the_ieee_path(lib, oracle, monkeypatch):
+    """all-zero coefficient blocks (a flat grey area: chroma 0) leave rounding noise of 1e-17 and
+    below around 0 for the first iterations — far under the 2^-20 the short division / sqrt
+    sequences are screened for, down to values whose squares are subnormal.  Such rows must take
+    the IEEE path, in both schedules of the joint gradient kernel and in the 1-channel kernel."""
+    import jpeg2png_amd as j
+    from oracle import bindings
+    planes = make_case(264, 136, "420", 10, seed=99)
+    for c, p in enumerate(planes):
+        d = p.data.reshape(p.h // 8, p.w // 8, 64)
+        if c == 0:
+            d[8:11, 14:20] = 0                   # luma flat too under part of the grey patch
+        else:
+            d[2:7, 3:13] = 0
+        p.fdata = bindings.decode_plane(p)
+    pws = [0.001] * 3
+    for its in (3, 6):
+        want, want_log = oracle.oracle_compute(planes, 0.3, pws, its, log=True)
+        if its == 3:
+            tiny = sum(int(((np.abs(w) < 2.0 ** -43) & (w != 0)).sum()) for w in want)
+            assert tiny > 1000, "the case no longer produces noise around 0"
+        for mode in ("0", "1"):
+            monkeypatch.setenv("J2P_JOINT_INWAVE", mode)
+            for log in (False, True):
+                got = copy.deepcopy(planes)
+                got_log = j.compute(got, 0.3, pws, its, log=log)
+                for c in range(3):
+                    assert bit_equal(got[c].fdata, want[c]), f"its {its} mode {mode} log {log} channel {c}"
+                if log:
+                    np.testing.assert_allclose(got_log, want_log, rtol=1e-9, atol=1e-9)
+        monkeypatch.delenv("J2P_JOINT_INWAVE")
+        for c in (0, 1):
+            want1, _ = oracle.oracle_compute(planes[c:c + 1], 0.3, [0.001], its)
+            got = copy.deepcopy(planes[c:c + 1])
+            j.compute(got, 0.3, [0.001], its)
+            assert bit_equal(got[0].fdata, want1[0]), f"its {its} separate channel {c}"
+
+
 def test_both_joint_modes_agree(lib, oracle, monkeypatch):
     """channels-in-one-wavefront and one-wavefront-per-channel gradient kernels are two schedules of
     the same arithmetic"""
@@ -440,3 +478,31 @@ def test_concurrent_calls_are_independent(lib, oracle):
     for i in range(6):
         for c in range(3):
             assert bit_equal(gots[i][c].fdata, wants[i][c]), f"call {i} channel {c}"
+
+
+@pytest.mark.parametrize("case", [("y_2048_100", 2048, 2048, "444", True, 100), ("rgb420_1080p_50", 1920, 1080, "420", False, 50)],
+                         ids=lambda c: c[0])
+def test_full_size_against_the_compiled_reference(lib, oracle, case):
+    """at realistic sizes the checker is the UNMODIFIED reference itself (oracle/_ref, a few seconds
+    of CPU): 2048x2048 Y for 100 iterations and a 1080p 4:2:0 image (padded 1920x1088 canvas, joint)
+    for 50.  Planes must clear the 80 dB bar; bit-identity is expected and reported."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    import jpeg2png_amd as j
+    from jpeg2png_amd import synth
+    name, W, H, sub, y_only, its = case
+    planes = synth.make_planes(W, H, sub, 10, seed=4321, y_only=y_only)
+    for p in planes:
+        p.fdata = j.decode_plane(p)
+    pws = [0.001] * len(planes)
+    want, want_log, _ = oracle.ref_compute(planes, 0.3, pws, its, log=True)
+    got = copy.deepcopy(planes)
+    got_log = j.compute(got, 0.3, pws, its, log=True)
+    exact = True
+    for c in range(len(planes)):
+        db = psnr(got[c].fdata, want[c])
+        assert db >= PSNR_BAR_DB, f"{name} channel {c}: PSNR {db:.1f} dB"
+        exact &= bit_equal(got[c].fdata, want[c])
+    assert exact, f"{name}: above {PSNR_BAR_DB} dB but not bit-identical (norm rounding flip?)"
+    # tv, tv2 (and prob_dist) against the reference's CSV (6 decimals)
+    np.testing.assert_allclose(got_log[:, 1:], want_log[:, 1:], rtol=1e-9, atol=2e-6)
