@@ -319,7 +319,7 @@ constexpr int kStripCols = 124;   // output columns per wavefront strip
 #define J2P_RING 4
 #endif
 constexpr int kRing = J2P_RING;   // row slots = hand-unroll factor of the marching loop (1 channel; 3 otherwise: registers);
-                                  // rows are fetched (slots - 2) trips ahead
+                                  // rows are fetched (slots - 1) trips ahead
 
 template <int NCH, bool TGV>
 struct SourceTerms {
@@ -343,14 +343,25 @@ __device__ __forceinline__ v2f sqrt_rsq(v2f x)
         return pk_fma(d, h, s);
 }
 
-// EXACT: result must be sqrtf(x) including x == 0 (the log sums read the norm itself);
-// otherwise only a positive divisor is needed when x == 0 (every numerator is 0 then)
+// EXACT_ZERO: result must be sqrtf(x) including x == 0 (the log sums read the norm itself).
+// Otherwise only a positive divisor is needed when x == 0 (every numerator is 0 then): on the
+// screened path x is 0 or >= 2^-88, so x + 2^-120 is x itself unless x == 0, where the root comes
+// out as exactly 2^-60 (checked by j2p_math_selftest) — one packed add instead of clamping both
+// the radicand and the root.
 template <bool FAST, bool EXACT_ZERO>
 __device__ __forceinline__ v2f sqrt_pair(v2f x)
 {
         if(!FAST) { return v2f{sqrtf(x.x), sqrtf(x.y)}; }
         if(EXACT_ZERO) { return sqrt_fast(x); }
-        return sqrt_rsq(v2f{fmaxf(x.x, 0x1p-100f), fmaxf(x.y, 0x1p-100f)});
+        return sqrt_rsq(x + v2f{0x1p-120f, 0x1p-120f});
+}
+// divisor for the quotients of a pixel whose norm is n (see sqrt_pair)
+template <bool FAST, bool EXACT_ZERO>
+__device__ __forceinline__ v2f divisor_of(v2f n)
+{
+        if(!FAST) { return v2f{n.x == 0.f ? 1.f : n.x, n.y == 0.f ? 1.f : n.y}; }   // divide by 1, scale by 0
+        if(EXACT_ZERO) { return v2f{fmaxf(n.x, 0x1p-60f), fmaxf(n.y, 0x1p-60f)}; }
+        return n;                                                                  // already >= 2^-60
 }
 template <bool FAST, int N>
 __device__ __forceinline__ void div_n(const v2f (&x)[N], v2f d, v2f r, v2f (&q)[N])
@@ -386,8 +397,7 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
         // A pixel with zero norm contributes nothing (compute.c:97).  Screened path: n == 0 implies
         // every numerator is exactly 0 (no square can underflow), so any positive divisor gives 0.
         // Unscreened path: divide by 1, scale by 0.
-        const v2f d1 = FAST ? v2f{fmaxf(n1.x, 0x1p-60f), fmaxf(n1.y, 0x1p-60f)}
-                            : v2f{n1.x == 0.f ? 1.f : n1.x, n1.y == 0.f ? 1.f : n1.y};
+        const v2f d1 = divisor_of<FAST, LOG>(n1);
         const v2f a1 = FAST ? v2f{a_tv, a_tv} : v2f{n1.x == 0.f ? 0.f : a_tv, n1.y == 0.f ? 0.f : a_tv};
         const v2f r1 = FAST ? div_prepare(d1) : d1;
 #pragma unroll
@@ -418,8 +428,7 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
                         tv2 += (double)(a_tgv * n2.x);
                         tv2 += (double)(a_tgv * n2.y);
                 }
-                const v2f d2 = FAST ? v2f{fmaxf(n2.x, 0x1p-60f), fmaxf(n2.y, 0x1p-60f)}
-                                    : v2f{n2.x == 0.f ? 1.f : n2.x, n2.y == 0.f ? 1.f : n2.y};
+                const v2f d2 = divisor_of<FAST, LOG>(n2);
                 const v2f a2 = FAST ? v2f{a_tgv, a_tgv}
                                     : v2f{n2.x == 0.f ? 0.f : a_tgv, n2.y == 0.f ? 0.f : a_tgv};   // compute.c:158
                 const v2f r2 = FAST ? div_prepare(d2) : d2;
@@ -481,8 +490,7 @@ __device__ __forceinline__ void source_terms_joint(int cidx, int lane, int parit
                 tv += (double)(a_tv * n1.x);
                 tv += (double)(a_tv * n1.y);
         }
-        const v2f d1 = FAST ? v2f{fmaxf(n1.x, 0x1p-60f), fmaxf(n1.y, 0x1p-60f)}
-                            : v2f{n1.x == 0.f ? 1.f : n1.x, n1.y == 0.f ? 1.f : n1.y};
+        const v2f d1 = divisor_of<FAST, LOG>(n1);
         const v2f a1 = FAST ? v2f{a_tv, a_tv} : v2f{n1.x == 0.f ? 0.f : a_tv, n1.y == 0.f ? 0.f : a_tv};
         const v2f r1 = FAST ? div_prepare(d1) : d1;
         {
@@ -499,8 +507,7 @@ __device__ __forceinline__ void source_terms_joint(int cidx, int lane, int parit
                         tv2 += (double)(a_tgv * n2.x);
                         tv2 += (double)(a_tgv * n2.y);
                 }
-                const v2f d2 = FAST ? v2f{fmaxf(n2.x, 0x1p-60f), fmaxf(n2.y, 0x1p-60f)}
-                                    : v2f{n2.x == 0.f ? 1.f : n2.x, n2.y == 0.f ? 1.f : n2.y};
+                const v2f d2 = divisor_of<FAST, LOG>(n2);
                 const v2f a2 = FAST ? v2f{a_tgv, a_tgv} : v2f{n2.x == 0.f ? 0.f : a_tgv, n2.y == 0.f ? 0.f : a_tgv};
                 const v2f r2 = FAST ? div_prepare(d2) : d2;
                 const v2f num[4] = {sy + xx, yy + sy, -sy, -(2.f * xx + 2.f * sy + 2.f * yy)};
@@ -530,7 +537,8 @@ void k_gradient(GradArgs a)
 {
         static_assert(J == 1 || NCH == 1, "channel-per-wavefront mode keeps one channel per wavefront");
         __shared__ __attribute__((aligned(16))) v2f xchg[J == 1 ? 1 : 2 * J * 64 * 3];
-        const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+        const int lane = (int)threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // uniform: keeps row/strip arithmetic scalar
         // XCD-aware order (speed only): workgroup b runs on XCD b % 8, so give every XCD a contiguous,
         // row-major run of (segment, strip-group) pairs — vertically adjacent strips then meet in one
         // L2 and their shared halo rows are fetched from HBM once.  Bijective for any grid size.
@@ -562,35 +570,40 @@ void k_gradient(GradArgs a)
         const v2f m_gx = v2f{in_f, xl + 1 >= W - 1 ? 0.f : in_f};   // gx = 0 on the last column (compute.c:79)
         const v2f m_hx = v2f{xl == 0 ? 0.f : in_f, in_f};           // gxx, gyx = 0 on the first column
 
-        // Rows are fetched kRing-2 loop trips before they are needed: `fetch_row` only issues the
+        // Rows are fetched kRing-1 loop trips before they are needed: `fetch_row` only issues the
         // loads of x_k / x_{k-1} (raw values stay in the ring), `make_y` turns them into the FISTA
         // point (compute.c:433-439) when the row is first used.  All loads are UNCONDITIONAL —
         // lanes left/right of the image and rows above/below it read a clamped, valid address and
         // are zeroed by a mask afterwards — so the loop body is straight-line code and the compiler
         // can keep the younger loads in flight (counted s_waitcnt) instead of draining them.
         const int xl_c = xl < 0 ? 0 : (xl > W - 2 ? W - 2 : xl);
+        const unsigned xoff = (unsigned)xl_c * 4u;             // byte offset of the lane's column pair within a row
         const int lr_lo = -(row0 < (int)kHalo ? row0 : (int)kHalo);                      // first readable band-local row
         const int lr_hi = rows - 1 + (H - row0 - rows < (int)kHalo ? H - row0 - rows : (int)kHalo);
         auto fetch_row = [&](int lr, v2f (&rc)[NCH], v2f (&rp)[NCH]) {
                 // rows past the strip's last needed row (t1+1) re-read that row: a cache hit, not HBM traffic
                 const int lm = lr > t1 + 1 ? t1 + 1 : lr;
                 const int lc = lm < lr_lo ? lr_lo : (lm > lr_hi ? lr_hi : lm);
-                const ptrdiff_t off = (ptrdiff_t)lc * W + xl_c;
+                // uniform row pointer + loop-invariant 32-bit lane offset: scalar-base addressing, no
+                // 64-bit vector address arithmetic per row
+                const ptrdiff_t roff = (ptrdiff_t)lc * W;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
-                        rc[c] = *reinterpret_cast<const v2f *>(a.ch[cbase + c].xcur + off);
-                        rp[c] = *reinterpret_cast<const v2f *>(a.ch[cbase + c].xprev + off);
+                        rc[c] = *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(a.ch[cbase + c].xcur + roff) + xoff);
+                        rp[c] = *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(a.ch[cbase + c].xprev + roff) + xoff);
                 }
         };
-        auto make_y = [&](int lr, const v2f (&rc)[NCH], const v2f (&rp)[NCH], v2f (&y)[NCH], bool &suspect) {
+        auto make_y = [&](int lr, const v2f (&rc)[NCH], const v2f (&rp)[NCH], v2f (&y)[NCH], unsigned &suspect) {
                 const int gr = row0 + lr;
                 const float m = gr >= 0 && gr < H ? in_f : 0.f;   // 0 outside the image
-                suspect = false;
+                bool sus = false;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
                         y[c] = (rc[c] + a.factor * (rc[c] - rp[c])) * m;
-                        suspect |= y_suspect(y[c]);
+                        sus |= y_suspect(y[c]);
                 }
+                // wave-uniform, and a 32-bit value rather than a bool so that it is carried round the loop in a scalar register
+                suspect = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(sus) != 0 ? 1u : 0u);
         };
         // forward differences of row gr given rows gr and gr+1 (compute.c:79,81)
         auto diffs = [&](int gr, const v2f (&yc)[NCH], const v2f (&yn)[NCH], v2f (&gx)[NCH], v2f (&gy)[NCH]) {
@@ -615,8 +628,8 @@ void k_gradient(GradArgs a)
                 p_scale[c] = on ? v2f{k.p_alpha, k.p_alpha} : v2f{0.f, 0.f};
                 const unsigned cmax = k.cw - 1;
                 const unsigned c0 = (unsigned)xl_c / k.ws, c1 = (unsigned)(xl_c + 1) / k.ws;
-                p_col[c][0] = (int)(c0 > cmax ? cmax : c0);
-                p_col[c][1] = (int)(c1 > cmax ? cmax : c1);
+                p_col[c][0] = (int)(c0 > cmax ? cmax : c0) * 4;   // byte offsets within a coefficient row
+                p_col[c][1] = (int)(c1 > cmax ? cmax : c1) * 4;
         }
         auto load_p = [&](int lt, v2f (&pv)[NCH]) {
 #pragma unroll
@@ -628,24 +641,24 @@ void k_gradient(GradArgs a)
                         const unsigned cr_hi = k.crow0 + (k.crows ? k.crows - 1 : 0);
                         cr = cr < k.crow0 ? k.crow0 : (cr > cr_hi ? cr_hi : cr);
                         const float *prow = k.pg + (size_t)(cr - k.crow0) * k.cw;
-                        if(k.ws == 1) { pv[c] = *reinterpret_cast<const v2f *>(prow + p_col[c][0]); }
-                        else { pv[c] = v2f{prow[p_col[c][0]], prow[p_col[c][1]]}; }
+                        pv[c] = v2f{*reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][0]),
+                                    *reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][1])};   // two dword loads whatever the sampling: no branch
                 }
         };
 
         // rings of kRing row slots, slot = (row - (t0-1)) mod kRing = phase of the trip that owns the row
         constexpr int R = NCH == 1 ? kRing : 3;
         v2f RC[R][NCH], RP[R][NCH], Y[R][NCH], GX[R][NCH], GY[R][NCH], PV[R][NCH];
-        bool bad[R];
+        unsigned bad[R];
         SourceTerms<NCH, TGV> S[R];
         {
-                // rows t0-2, t0-1, t0 are needed at once; rows up to t0+R-3 are put in flight
+                // rows t0-2, t0-1, t0 are needed at once; rows up to t0+R-2 are put in flight
                 v2f mc[NCH], mp[NCH], ym[NCH];
-                bool bm;
+                unsigned bm;
                 fetch_row(t0 - 2, mc, mp);
                 fetch_row(t0 - 1, RC[0], RP[0]);
 #pragma unroll
-                for(int i = 1; i <= R - 2; i++) { fetch_row(t0 - 1 + i, RC[i], RP[i]); }
+                for(int i = 1; i <= R - 1; i++) { fetch_row(t0 - 1 + i, RC[i], RP[i]); }
 #pragma unroll
                 for(int i = 1; i <= R - 3; i++) { load_p(t0 - 1 + i, PV[i]); }
                 make_y(t0 - 2, mc, mp, ym, bm);
@@ -664,12 +677,12 @@ void k_gradient(GradArgs a)
         auto trip = [&](auto phase, int r) {
                 constexpr int P = decltype(phase)::value, P1 = (P + 1) % R, PM1 = (P + R - 1) % R, PM2 = (P + R - 2) % R;
                 const int gr = row0 + r;
-                // put row r+R-1 in flight (its slot held row r-1, whose raw values are dead), and the
-                // prob state of target row r+R-2; then finish row r+1, fetched R-2 trips ago
-                fetch_row(r + R - 1, RC[PM1], RP[PM1]);
+                // put row r+R in flight (its slot held row r, whose raw values became y last trip), and the
+                // prob state of target row r+R-2; then finish row r+1, fetched R-1 trips ago
+                fetch_row(r + R, RC[P], RP[P]);
                 load_p(r + R - 2, PV[PM2]);
                 make_y(r + 1, RC[P1], RP[P1], Y[P1], bad[P1]);
-                const bool prev_bad = bad[PM1];
+                const unsigned prev_bad = bad[PM1];
                 SourceTerms<NCH, TGV> &s = S[P];
                 diffs(gr, Y[P], Y[P1], GX[P], GY[P]);
                 {
@@ -680,7 +693,7 @@ void k_gradient(GradArgs a)
                         const v2f m_hy = v2f{hy, hy};
                         if(J > 1) {
                                 const int parity = (r - t0 + 1) & 1;
-                                if(__builtin_amdgcn_ballot_w64(prev_bad | bad[P] | bad[P1]) == 0) {
+                                if((prev_bad | bad[P] | bad[P1]) == 0) {
                                         source_terms_joint<J, TGV, LOG, true>(cbase, lane, parity, xchg, GX[P][0], GY[P][0], GX[PM1][0],
                                                                               GY[PM1][0], m_hx, m_hy, a.a_tv, a.a_tgv, log_row,
                                                                               tv_acc, tv2_acc, reinterpret_cast<SourceTerms<1, TGV> &>(s));
@@ -689,7 +702,7 @@ void k_gradient(GradArgs a)
                                                                                GY[PM1][0], m_hx, m_hy, a.a_tv, a.a_tgv, log_row,
                                                                                tv_acc, tv2_acc, reinterpret_cast<SourceTerms<1, TGV> &>(s));
                                 }
-                        } else if(__builtin_amdgcn_ballot_w64(prev_bad | bad[P] | bad[P1]) == 0) {
+                        } else if((prev_bad | bad[P] | bad[P1]) == 0) {
                                 source_terms<NCH, TGV, LOG, true>(GX[P], GY[P], GX[PM1], GY[PM1], m_hx, m_hy, a.a_tv, a.a_tgv,
                                                                   log_row, tv_acc, tv2_acc, s);
                         } else {
@@ -720,7 +733,7 @@ void k_gradient(GradArgs a)
                                         g += s.B[c];             // (x,   t+1)
                                 }
                                 if(pair_own) {
-                                        *reinterpret_cast<v2f *>(k.grad + (size_t)t * W + xl) = g;
+                                        *reinterpret_cast<v2f *>(reinterpret_cast<char *>(k.grad + (size_t)t * W) + (unsigned)xl * 4u) = g;
                                         const v2f sq = g * g;
                                         g2[c] += (double)sq.x;   // compute.c:203
                                         g2[c] += (double)sq.y;
@@ -1405,6 +1418,12 @@ __global__ __launch_bounds__(256) void k_math_selftest(size_t n, unsigned seed, 
                 const v2f si = v2f{sqrtf(sx.x), sqrtf(sx.y)};
                 bad_sqrt += __builtin_bit_cast(unsigned, sf.x) != __builtin_bit_cast(unsigned, si.x);
                 bad_sqrt += __builtin_bit_cast(unsigned, sf.y) != __builtin_bit_cast(unsigned, si.y);
+        }
+        if(blockIdx.x == 0 && threadIdx.x == 0) {
+                // the zero-norm divisor of sqrt_pair<true, false>
+                const v2f z = sqrt_pair<true, false>(v2f{0.f, 0x1p-88f});
+                bad_sqrt += z.x != 0x1p-60f;
+                bad_sqrt += z.y != 0x1p-44f;
         }
         if(bad_div) { atomicAdd(&mism[0], bad_div); }
         if(bad_sqrt) { atomicAdd(&mism[1], bad_sqrt); }
