@@ -148,6 +148,10 @@ int j2p_solver_commit_initial_halo(j2p_solver *s);
  * this is what compute() hands back in coef->fdata (compute.c:455-461) */
 int j2p_solver_download(j2p_solver *s, unsigned c, float *out);
 
+/* diagnostics: channel c's objective gradient as the last gradient phase left it (W * band_rows
+ * floats; compute.c's aux->obj_gradient before the step) */
+int j2p_solver_download_gradient(j2p_solver *s, unsigned c, float *out);
+
 /* device pointer to channel c's current iterate (own rows), for on-device consumers */
 int j2p_solver_plane_ptr(j2p_solver *s, unsigned c, float **dev_ptr);
 

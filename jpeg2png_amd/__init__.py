@@ -59,6 +59,7 @@ C_ABI_SYMBOLS = [
     "j2p_solver_reset", "j2p_solver_run", "j2p_solver_phase_gradient", "j2p_solver_phase_project",
     "j2p_solver_phase_gradient_part", "j2p_solver_phase_rowsums",
     "j2p_solver_exchange_info", "j2p_solver_commit_initial_halo", "j2p_solver_download",
+    "j2p_solver_download_gradient",
     "j2p_solver_plane_ptr", "j2p_solver_sync", "j2p_solver_kernel_times", "j2p_solver_enable_timing",
     "j2p_decode_plane", "j2p_dct8x8_blocks", "j2p_math_selftest", "j2p_planes_to_rgb", "j2p_sqrt_exhaustive",
     "compute", "j2p_compute",
@@ -97,6 +98,7 @@ def load_library():
     lib.j2p_solver_run.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.POINTER(_CLogRow)]
     lib.j2p_solver_exchange_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(_CExchange)]
     lib.j2p_solver_download.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p]
+    lib.j2p_solver_download_gradient.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p]
     lib.j2p_solver_plane_ptr.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_void_p)]
     lib.j2p_solver_kernel_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint)]
@@ -242,6 +244,12 @@ class Solver:
     def download(self, c):
         out = np.empty((self.row_end - self.row_begin, self.W), dtype=np.float32)
         _check(self._lib.j2p_solver_download(self._h, c, out.ctypes.data))
+        return out
+
+    def download_gradient(self, c):
+        """diagnostics: the objective gradient the last gradient phase wrote for channel c"""
+        out = np.empty((self.row_end - self.row_begin, self.W), dtype=np.float32)
+        _check(self._lib.j2p_solver_download_gradient(self._h, c, out.ctypes.data))
         return out
 
     def plane_ptr(self, c):

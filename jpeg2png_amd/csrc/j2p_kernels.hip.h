@@ -294,6 +294,9 @@ __device__ __forceinline__ bool in_fast_range(float v, float lo, float hi)
 }
 __device__ __forceinline__ bool y_suspect(v2f y)
 {
+#ifdef J2P_FORCE_IEEE_GRADIENT   /* debugging aid: every row of phase A on the plain `/` + sqrtf() path */
+        return true;
+#endif
         return !(in_fast_range(y.x, 0x1p-20f, 0x1p41f) && in_fast_range(y.y, 0x1p-20f, 0x1p41f));
 }
 
@@ -905,6 +908,9 @@ __device__ __forceinline__ float stepped(const ChanDev &k, ptrdiff_t off, float 
 // numerator screen of the short division: 0 < |x| < 2^-100, |x| >= 2^61, or NaN
 __device__ __forceinline__ bool num_suspect(v2f x)
 {
+#ifdef J2P_FORCE_IEEE_PROJECT    /* debugging aid: every division of phase B on the plain `/` path */
+        return true;
+#endif
         return !(in_fast_range(x.x, 0x1p-100f, 0x1p61f) && in_fast_range(x.y, 0x1p-100f, 0x1p61f));
 }
 __device__ __forceinline__ bool den_ok(float d) { return d >= 0x1p-20f && d <= 0x1p26f; }
@@ -1051,9 +1057,15 @@ __global__ __launch_bounds__(256) void k_project(ProjArgs a)
         const unsigned cy0 = (a.geo.row0 / hs) + by * 8;              // first coefficient row (global)
         const bool covered = cx < k.cw && cy0 < k.ch;                 // block-granular: cw, ch multiples of 8
         const unsigned ly0 = by * 8 * hs;                             // band-local canvas row
-        const bool direct = ws == 1 && hs == 1;
+        // A full-resolution channel whose coefficient plane is smaller than the canvas (the chroma planes pad
+        // further than the luma plane: most 4:2:0 images) still goes through the reference's resampling code
+        // with a 1 x 1 footprint (compute.c:348-370, 390-403): the DCT sees 0.f + x and the result is
+        // (x - (0.f + x)) + p.  That only differs from p itself in the sign of a zero, but it does differ.
+        const bool unit = ws == 1 && hs == 1;
+        const bool resample1 = unit && (k.cw != W || k.ch != a.geo.H);
+        const bool direct = unit && !resample1;
         // wave-uniform: the whole 64 x 8 strip is inside the canvas and projected
-        const bool full = WS == 1 && HS == 1 && direct && sx * 64 + 64 <= k.cw && sx * 64 + 64 <= W && cy0 < k.ch &&
+        const bool full = WS == 1 && HS == 1 && unit && sx * 64 + 64 <= k.cw && sx * 64 + 64 <= W && cy0 < k.ch &&
                           ly0 + 8 <= a.geo.rows;
 
         // subsampled channel, strip wholly inside canvas and coverage: register-resident fast path
@@ -1064,6 +1076,7 @@ __global__ __launch_bounds__(256) void k_project(ProjArgs a)
         SubTile<(kSub ? WS : 1), (kSub ? HS : 1)> tile;
 
         float v[8];
+        float st1[8];                                                   // stepped pixels of a `full && resample1` strip
         if(fullsub) {
                 sub_load_step_mean<(kSub ? WS : 1), (kSub ? HS : 1)>(k, sub_base, W, a.factor, a.step, norm, tile, v);
         } else if(full) {
@@ -1101,6 +1114,13 @@ __global__ __launch_bounds__(256) void k_project(ProjArgs a)
                 for(int p = 0; p < 4; p++) {
                         v[2 * p] = y2[p].x;
                         v[2 * p + 1] = y2[p].y;
+                }
+                if(resample1) {
+#pragma unroll
+                        for(int r = 0; r < 8; r++) {
+                                st1[r] = v[r];
+                                v[r] = 0.f + v[r];                          // mean of one sample (compute.c:352-358)
+                        }
                 }
         } else if(direct) {
                 const bool inside = cx < W;
@@ -1222,6 +1242,11 @@ __global__ __launch_bounds__(256) void k_project(ProjArgs a)
                 transpose8(v, scratch, lane);
                 if(fullsub) {
                         sub_store_residual<(kSub ? WS : 1), (kSub ? HS : 1)>(k, sub_base, W, tile, mean_old, v);
+                } else if(full) {
+                        // full && resample1: residual (x - mean) + new mean, lane = column again
+                        const size_t base = (size_t)ly0 * W + cx;
+#pragma unroll
+                        for(int r = 0; r < 8; r++) { k.xprev[base + (size_t)r * W] = (st1[r] - mean_old[r]) + v[r]; }
                 } else if(covered) {
 #pragma unroll 1
                         for(int r = 0; r < 8; r++) {

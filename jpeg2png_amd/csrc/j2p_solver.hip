@@ -802,6 +802,16 @@ int j2p_solver_download(j2p_solver *s, unsigned c, float *out)
         return J2P_OK;
 }
 
+int j2p_solver_download_gradient(j2p_solver *s, unsigned c, float *out)
+{
+        if(!s || !out) { return fail(J2P_EINVAL, "NULL argument"); }
+        if(c >= s->nch) { return fail(J2P_EINVAL, "channel %u out of range", c); }
+        DeviceGuard guard(s->device);
+        HIP_TRY(hipMemcpyAsync(out, s->ch[c].grad, (size_t)s->rows * s->W * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        return J2P_OK;
+}
+
 int j2p_solver_plane_ptr(j2p_solver *s, unsigned c, float **dev_ptr)
 {
         if(!s || !dev_ptr) { return fail(J2P_EINVAL, "NULL argument"); }

@@ -424,6 +424,11 @@ void oracle_canvas_size(unsigned nch, const oracle_plane *pl, unsigned *W, unsig
         *H = h;
 }
 
+/* debugging aid for tools/trace_vs_oracle.py: when set, every iteration appends, per channel, the
+ * gradient (W*H floats) and then the new iterate (W*H floats) to this buffer */
+static float *g_trace;
+void oracle_set_trace(float *buf) { g_trace = buf; }
+
 int oracle_compute(unsigned nch, const oracle_plane *pl, float weight, const float *pweight,
                    unsigned iterations, float *const *out, double *log_rows)
 {
@@ -490,11 +495,21 @@ int oracle_compute(unsigned nch, const oracle_plane *pl, float weight, const flo
                         log_rows[4*it + 3] = tv2;
                 }
 
+                if(g_trace) {
+                        for(unsigned c = 0; c < nch; c++) {
+                                memcpy(g_trace + ((size_t)(it * nch + c) * 2) * n, cs[c].g, sizeof(float) * n);
+                        }
+                }
                 for(unsigned c = 0; c < nch; c++) { descend(&cs[c], n, step); }
                 carried_prob = 0.;
                 for(unsigned c = 0; c < nch; c++) {
                         double dsum = project(&cs[c], W, H, pweight[c] != 0.f);
                         if(pweight[c] != 0.f) { carried_prob += 0.5 * dsum; }
+                }
+                if(g_trace) {
+                        for(unsigned c = 0; c < nch; c++) {
+                                memcpy(g_trace + ((size_t)(it * nch + c) * 2 + 1) * n, cs[c].x, sizeof(float) * n);
+                        }
                 }
         }
         for(unsigned c = 0; c < nch; c++) {

@@ -24,6 +24,7 @@ void oracle_canvas_size(unsigned nch, const oracle_plane *pl, unsigned *W, unsig
 
 /* restatement of compute() (compute.c:407): out[c] receives the W*H canvas plane;
  * log_rows (optional) receives iterations x {objective, prob_dist, tv, tv2} */
+void oracle_set_trace(float *buf);   /* debugging aid, see solver_oracle.c */
 int oracle_compute(unsigned nch, const oracle_plane *pl, float weight, const float *pweight,
                    unsigned iterations, float *const *out, double *log_rows);
 

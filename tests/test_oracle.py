@@ -108,3 +108,27 @@ def test_synth_is_band_invariant():
     band = synth.make_planes(96, 128, "444", 10, seed=9, y_only=True, rows=(64, 128))[0]
     assert band.h == 64 and band.w == 96
     assert np.array_equal(band.data, whole.data.reshape(16, -1)[8:].reshape(-1))
+
+
+def test_oracle_matches_reference_on_sweep_cases():
+    """the restatement against the compiled reference on the randomised case stream the GPU tests use
+    (small cases only: the oracle is a slow scalar program)"""
+    from oracle import bindings
+    if not bindings.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    from sweep_cases import cases
+    done = 0
+    for cs in cases(11, 60):
+        if cs.W * cs.H * cs.iterations > 1.5e6:
+            continue
+        planes = cs.planes()
+        for p in planes:
+            p.fdata = bindings.decode_plane(p)
+        want, want_log, _ = bindings.ref_compute(planes, cs.weight, cs.pweights, cs.iterations, log=cs.log)
+        got, got_log = bindings.oracle_compute(planes, cs.weight, cs.pweights, cs.iterations, log=cs.log)
+        for c in range(len(planes)):
+            assert bit_equal(got[c], want[c]), cs.describe()
+        if cs.log and cs.iterations:
+            np.testing.assert_allclose(got_log[:, 1:], want_log[:, 1:], rtol=1e-9, atol=2e-6)
+        done += 1
+    assert done >= 15

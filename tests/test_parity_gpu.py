@@ -506,3 +506,39 @@ def test_full_size_against_the_compiled_reference(lib, oracle, case):
     assert exact, f"{name}: above {PSNR_BAR_DB} dB but not bit-identical (norm rounding flip?)"
     # tv, tv2 (and prob_dist) against the reference's CSV (6 decimals)
     np.testing.assert_allclose(got_log[:, 1:], want_log[:, 1:], rtol=1e-9, atol=2e-6)
+
+
+def _sweep_check(lib, oracle, cs):
+    import jpeg2png_amd as j
+    planes = cs.planes()
+    for p in planes:
+        p.fdata = j.decode_plane(p)
+    want, want_log, _ = oracle.ref_compute(planes, cs.weight, cs.pweights, cs.iterations, log=cs.log)
+    got = copy.deepcopy(planes)
+    got_log = j.compute(got, cs.weight, cs.pweights, cs.iterations, log=cs.log)
+    for c in range(len(planes)):
+        assert bit_equal(got[c].fdata, want[c]), f"sweep case {cs.describe()} channel {c}"
+    if cs.log and cs.iterations:
+        np.testing.assert_allclose(got_log[:, 1:], want_log[:, 1:], rtol=1e-9, atol=2e-6)
+
+
+def test_randomised_sweep_against_the_compiled_reference(lib, oracle):
+    """40 random configurations (tests/sweep_cases.py: ragged sizes from 1x1 up, all samplings, qualities,
+    TV-only, per-channel pweights, flat areas, logging) against the unmodified reference, bitwise;
+    tools/sweep_vs_ref.py runs the same stream for as long as one likes (400 cases of seed 2 pass)."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    from sweep_cases import cases
+    for cs in cases(7, 40):
+        _sweep_check(lib, oracle, cs)
+
+
+@pytest.mark.parametrize("index", [55, 101])
+def test_sign_of_zero_of_a_resampled_full_resolution_plane(lib, oracle, index):
+    """seed-2 sweep cases in which the luma plane is smaller than the canvas (chroma pads further), so the
+    reference resamples it with a 1x1 footprint: x_new = (x - (0.f + x)) + p turns a projected -0 into +0
+    (compute.c:348-370,390-403).  Invisible in PSNR, but the planes are compared bitwise."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    from sweep_cases import case
+    _sweep_check(lib, oracle, case(2, index))
