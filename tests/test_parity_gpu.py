@@ -9,6 +9,7 @@ difference is the summation order of the double-precision sum(g*g) (SURVEY.md
 clear 80 dB and is reported.
 """
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -18,6 +19,7 @@ from conftest import bit_equal, make_case, psnr
 pytestmark = pytest.mark.gpu
 
 PSNR_BAR_DB = 80.0   # stated tolerance for the floating-point path
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_dct_blocks_bit_exact(lib, oracle):
@@ -542,3 +544,15 @@ def test_sign_of_zero_of_a_resampled_full_resolution_plane(lib, oracle, index):
         pytest.skip("oracle/_ref not built (needs /root/reference)")
     from sweep_cases import case
     _sweep_check(lib, oracle, case(2, index))
+
+
+def test_randomised_band_splits_match_the_whole_canvas(lib):
+    """tools/sweep_bands.py as a test: 25 configurations of the shared case stream, each cut into 2-4 row
+    bands at random aligned positions on one GPU, equal the whole-canvas solve bitwise (141 of 141 in the
+    150-case run of seed 3)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_bands.py"), "25", "9"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "band splits bit-identical" in r.stdout
