@@ -125,3 +125,15 @@ def test_multiple_files_and_default_names(cli, tmp_path):
         r = run(REF_CLI, names[i], "-o", str(ref), "-q", "-i", "5")
         assert r.returncode == 0
         assert out.read_bytes() == ref.read_bytes()
+
+
+@pytest.mark.gpu
+def test_randomised_cli_sweep(cli):
+    """tools/sweep_cli.py as a test: 16 random JPEGs (sizes from 1x1, qualities 3..100, 4:4:4/4:2:2/4:2:0,
+    progressive / optimised entropy coding, flat areas) with random -s/-i/-w/-p/-1 flags; PNGs byte-identical
+    to the reference program's (120 of 120 in the long run of seed 1)."""
+    if not os.path.exists(REF_CLI):
+        pytest.skip("oracle/_ref/jpeg2png_ref not built (needs /root/reference)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_cli.py"), "16", "4"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
