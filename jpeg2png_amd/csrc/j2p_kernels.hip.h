@@ -806,14 +806,49 @@ __device__ __forceinline__ double strip_sum(const double *p, unsigned n)
         return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
-__global__ __launch_bounds__(256) void k_rowsums(const double *part, double *rowsum, unsigned ntx, unsigned nrows_local, unsigned nch)
+// Both level-1 kernels first stage the partials into LDS with coalesced loads (every load of the launch
+// in flight at once) and then let one thread per tile row run strip_sum over its LDS copy: the per-thread
+// strided global reads of the direct form cost one dependent L2/fabric round trip per 8 strips.
+constexpr unsigned kStageDoubles = 2048;          // 16 KB of static LDS per k_rowsums block: many small blocks, one round each
+constexpr unsigned kNormLdsBytes = 156 * 1024;    // dynamic LDS k_norm_whole may ask for
+
+// copy n doubles global -> LDS with all 256 threads; loads are issued in batches of 40 per thread before
+// the first store so that the whole copy is one or two memory round trips, not one per element
+__device__ __forceinline__ void stage_copy(double *dst, const double *src, unsigned n)
+{
+        constexpr unsigned kBatch = 40;
+        for(unsigned base = threadIdx.x; base < n; base += 256 * kBatch) {
+                double v[kBatch];
+#pragma unroll
+                for(unsigned j = 0; j < kBatch; j++) {
+                        const unsigned i = base + j * 256;
+                        v[j] = src[i < n ? i : n - 1];
+                }
+#pragma unroll
+                for(unsigned j = 0; j < kBatch; j++) {
+                        const unsigned i = base + j * 256;
+                        if(i < n) { dst[i] = v[j]; }
+                }
+        }
+}
+
+__global__ __launch_bounds__(256) void k_rowsums(const double *part, double *rowsum, unsigned ntx, unsigned nrows_local, unsigned nch,
+                                                 unsigned items_per_block)
 {
         // part: [c][local tile row][strip] -> rowsum: [local tile row][c]  (tile-row major, so that
-        // concatenating the bands of consecutive GPUs yields the global array)
-        const unsigned i = blockIdx.x * 256 + threadIdx.x;
-        if(i >= nrows_local * nch) { return; }
-        const unsigned c = i / nrows_local, r = i % nrows_local;
-        rowsum[(size_t)r * nch + c] = strip_sum(part + (size_t)i * ntx, ntx);
+        // concatenating the bands of consecutive GPUs yields the global array).  Item i = c * nrows_local + r;
+        // a block owns items_per_block consecutive items (items_per_block * ntx <= kStageDoubles).
+        __shared__ double st[kStageDoubles];
+        const unsigned total = nrows_local * nch;
+        const unsigned i0 = blockIdx.x * items_per_block;
+        const unsigned items = i0 + items_per_block <= total ? items_per_block : total - i0;
+        const double *src = part + (size_t)i0 * ntx;
+        stage_copy(st, src, items * ntx);
+        __syncthreads();
+        for(unsigned k = threadIdx.x; k < items; k += 256) {
+                const unsigned i = i0 + k, c = i / nrows_local, r = i % nrows_local;
+                rowsum[(size_t)r * nch + c] = strip_sum(st + (size_t)k * ntx, ntx);
+        }
 }
 
 constexpr int kMaxTileRows = 4096;   // canvas height <= 65536 (JPEG limit) / kTY
@@ -843,19 +878,37 @@ __global__ __launch_bounds__(256) void k_norm_finish(const double *rowsum_all, u
         if(threadIdx.x == 0) { norm[blockIdx.x] = sqrtf((float)s); }
 }
 
-// whole-canvas solver: both levels in one launch (one block per channel), same arithmetic
-__global__ __launch_bounds__(256) void k_norm_whole(const double *part, unsigned ntx, unsigned nrows, unsigned nch, float *norm)
+// whole-canvas solver: both levels in one launch (one block per channel), same arithmetic.
+// Dynamic LDS: P doubles for the tree followed by stage_doubles for staging (kNormLdsBytes together at most;
+// gfx950 lets one workgroup have all 160 KiB of a CU).
+__global__ __launch_bounds__(256) void k_norm_whole(const double *part, unsigned ntx, unsigned nrows, unsigned nch, float *norm,
+                                                    unsigned stage_doubles)
 {
         extern __shared__ __attribute__((aligned(16))) float smem[];
         double *buf = reinterpret_cast<double *>(smem);
         const unsigned c = blockIdx.x;
         unsigned P = 1;
         while(P < nrows) { P <<= 1; }
-        for(unsigned r = threadIdx.x; r < P; r += 256) {
-                buf[r] = r < nrows ? strip_sum(part + ((size_t)c * nrows + r) * ntx, ntx) : 0.;
+        double *st = buf + P;
+        const double *src = part + (size_t)c * nrows * ntx;
+        if(stage_doubles == 0) {
+                // few strips per tile row: one thread per tile row straight from global memory (the strided
+                // reads cost one round trip per 8 strips, cheaper than funnelling everything through one CU's LDS)
+                for(unsigned r = threadIdx.x; r < nrows; r += 256) { buf[r] = strip_sum(src + (size_t)r * ntx, ntx); }
+        } else {
+                const unsigned group = stage_doubles / ntx;         // tile rows staged per round (ntx <= 529 < stage_doubles)
+                for(unsigned r0 = 0; r0 < nrows; r0 += group) {
+                        const unsigned rows = r0 + group <= nrows ? group : nrows - r0;
+                        __syncthreads();                            // the previous round's readers are done
+                        stage_copy(st, src + (size_t)r0 * ntx, rows * ntx);
+                        __syncthreads();
+                        for(unsigned r = threadIdx.x; r < rows; r += 256) { buf[r0 + r] = strip_sum(st + (size_t)r * ntx, ntx); }
+                }
         }
+        for(unsigned r = nrows + threadIdx.x; r < P; r += 256) { buf[r] = 0.; }
         const double s = tree_sum_lds(buf, nrows, P);
         if(threadIdx.x == 0) { norm[c] = sqrtf((float)s); }
+        (void)nch;
 }
 
 // log sums: tv / tv2 from the gradient tiles and per-channel prob distance from the
