@@ -73,6 +73,29 @@ def build(force=False, verbose=False):
     return _build(force=force, verbose=verbose)
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  A process must not end up with
+    two HIP runtimes (ours from /opt/rocm loaded first, torch's afterwards: torch then reports "No HIP GPUs
+    are available"), so when torch is installed but not imported yet, load ITS runtime first; our library's
+    libamdhip64.so.N dependency then resolves to that copy, exactly as when torch was imported first."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        try:
+            ctypes.CDLL(bundled, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """dlopen libjpeg2png_amd.so; raises J2PError when it has not been built."""
     global _lib
@@ -81,6 +104,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise J2PError(f"{LIB_PATH} is missing: run `python -m jpeg2png_amd.buildlib` "
                        "(the HIP extension is the only implementation; there is no fallback)")
+    _share_torch_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)   # RTLD_LOCAL: our `compute` must not interpose other libraries' symbols
     lib.j2p_version.restype = ctypes.c_char_p
     lib.j2p_last_error.restype = ctypes.c_char_p

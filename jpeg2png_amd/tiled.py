@@ -20,6 +20,7 @@ production engine is HipBandEngine (the C-ABI solver, device memory aliased as
 torch tensors); tests drive the same exchange code with a CPU engine over gloo.
 """
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -167,6 +168,13 @@ class RowTiledSolver:
         self._ops = {}
         self.up = self.rank - 1 if self.rank > 0 else None
         self.down = self.rank + 1 if self.rank < self.world - 1 else None
+        # debugging / timing aid for single-GPU boxes: a lone rank exchanges its halo rows with ITSELF and
+        # runs the real all-gather, so the whole communication path (grouped send/recv on the aliased
+        # tensors, stream choreography, per-iteration host cost) is exercised.  Harmless for the result:
+        # the rows received land above the first / below the last image row, which the kernels mask.
+        self.self_neighbours = self.world == 1 and os.environ.get("J2P_TILED_SELF_NEIGHBOURS", "0") == "1"
+        if self.self_neighbours:
+            self.up = self.down = self.rank
         counts = torch.zeros(self.world, dtype=torch.int64)
         counts[self.rank] = engine.local_tile_rows
         counts = counts.to(engine.partials_local.device)
@@ -182,7 +190,7 @@ class RowTiledSolver:
     # -- exchanges ---------------------------------------------------------
     def gather_partials(self):
         e = self.e
-        if self.world == 1:
+        if self.world == 1 and not self.self_neighbours:
             if e.partials_all.data_ptr() != e.partials_local.data_ptr():
                 e.partials_all.copy_(e.partials_local)
             return
@@ -199,7 +207,7 @@ class RowTiledSolver:
             off += n * e.nch
 
     def exchange_halo(self):
-        if self.world == 1:
+        if self.up is None and self.down is None:
             return
         h = self.e.halo()
         key = tuple(t.data_ptr() for k in ("send_top", "recv_top", "send_bottom", "recv_bottom") for t in h[k])

@@ -366,11 +366,26 @@ def test_tiled_engine_on_one_gpu(lib, oracle):
         drv2.start()
         drv2.iterate(its)
         got1b = e.download(0)
+        # (c) the lone rank as its own neighbour: RCCL grouped send/recv on the aliased halo tensors and the
+        #     real all-gather every iteration (the rows it receives land outside the image and are masked)
+        os.environ["J2P_TILED_SELF_NEIGHBOURS"] = "1"
+        try:
+            got1c = []
+            for overlap in (True, False):
+                e.reset()
+                drv3 = tiled.RowTiledSolver(e, overlap=overlap)
+                assert drv3.self_neighbours and drv3.up == 0 and drv3.down == 0
+                drv3.start()
+                drv3.iterate(its)
+                got1c.append(e.download(0))
+        finally:
+            del os.environ["J2P_TILED_SELF_NEIGHBOURS"]
         e.close()
     finally:
         dist.destroy_process_group()
     assert bit_equal(got1, want)
     assert bit_equal(got1b, want)
+    assert bit_equal(got1c[0], want) and bit_equal(got1c[1], want)
 
 
 def test_out_of_range_operands_take_the_ieee_path(lib, oracle):
@@ -556,3 +571,31 @@ def test_randomised_band_splits_match_the_whole_canvas(lib):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "band splits bit-identical" in r.stdout
+
+
+@pytest.mark.parametrize("order", ["lib_first", "torch_first"])
+def test_library_and_torch_share_one_hip_runtime(order):
+    """PyTorch-ROCm bundles its own HIP runtime; a fresh process that touches our library first and torch
+    afterwards (or the other way round) must see the GPU from both"""
+    import subprocess
+    import sys
+    code = f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+import jpeg2png_amd as j
+from jpeg2png_amd import synth
+def use_lib():
+    planes = synth.make_planes(64, 48, "444", 10, seed=1, y_only=True)
+    with j.Solver(planes, 0.3, [0.001], 2) as s:
+        s.run(2); s.sync()
+def use_torch():
+    import torch
+    torch.cuda.init()
+    assert torch.cuda.device_count() >= 1
+    (torch.ones(4, device="cuda") * 2).sum().item()
+for f in ([use_lib, use_torch] if {order!r} == "lib_first" else [use_torch, use_lib]):
+    f()
+print("both fine")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "both fine" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
