@@ -123,6 +123,13 @@ int j2p_solver_phase_project(j2p_solver *s);
 int j2p_solver_phase_gradient_part(j2p_solver *s, int part, void *stream);
 int j2p_solver_phase_rowsums(j2p_solver *s);
 
+/* phase_project in two parts, for the same purpose: the BOUNDARY part computes the norm and projects the
+ * band's first and last block row of every channel — the rows send_top / send_bottom point into — so the
+ * halo exchange can start while the INTERIOR part (everything else; ends the iteration) is still running. */
+#define J2P_PROJECT_BOUNDARY 1
+#define J2P_PROJECT_INTERIOR 2
+int j2p_solver_phase_project_part(j2p_solver *s, int part);
+
 /* Device addresses the caller needs for the exchanges (all on the solver's device).
  *   partials_local : nchannel * local_tile_rows doubles written by phase_gradient
  *   partials_all   : nchannel * global_tile_rows doubles read by phase_project;

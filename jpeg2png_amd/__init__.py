@@ -57,7 +57,7 @@ C_ABI_SYMBOLS = [
     "j2p_version", "j2p_last_error", "j2p_device_count",
     "j2p_solver_create", "j2p_solver_destroy", "j2p_solver_canvas", "j2p_solver_band",
     "j2p_solver_reset", "j2p_solver_run", "j2p_solver_phase_gradient", "j2p_solver_phase_project",
-    "j2p_solver_phase_gradient_part", "j2p_solver_phase_rowsums",
+    "j2p_solver_phase_gradient_part", "j2p_solver_phase_rowsums", "j2p_solver_phase_project_part",
     "j2p_solver_exchange_info", "j2p_solver_commit_initial_halo", "j2p_solver_download",
     "j2p_solver_download_gradient",
     "j2p_solver_plane_ptr", "j2p_solver_sync", "j2p_solver_kernel_times", "j2p_solver_enable_timing",
@@ -96,6 +96,17 @@ def _share_torch_hip_runtime():
             pass
 
 
+def hip_runtime():
+    """ctypes handle of the HIP runtime this process (and our library) is bound to — for tests and tools that
+    want hipMemcpy & co.  Loading "libamdhip64.so" by name could pull a second copy of the runtime in."""
+    load_library()
+    with open("/proc/self/maps") as f:
+        paths = {line.split()[-1] for line in f if "libamdhip64" in line}
+    if not paths:
+        raise J2PError("no HIP runtime is mapped into this process")
+    return ctypes.CDLL(sorted(paths)[0])
+
+
 def load_library():
     """dlopen libjpeg2png_amd.so; raises J2PError when it has not been built."""
     global _lib
@@ -114,6 +125,7 @@ def load_library():
     lib.j2p_solver_destroy.argtypes = [ctypes.c_void_p]
     lib.j2p_solver_destroy.restype = None
     lib.j2p_solver_phase_gradient_part.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.j2p_solver_phase_project_part.argtypes = [ctypes.c_void_p, ctypes.c_int]
     for name in ("j2p_solver_reset", "j2p_solver_phase_gradient", "j2p_solver_phase_project",
                  "j2p_solver_sync", "j2p_solver_commit_initial_halo", "j2p_solver_phase_rowsums"):
         getattr(lib, name).argtypes = [ctypes.c_void_p]
@@ -250,6 +262,10 @@ class Solver:
         """part 1 = interior segments (no halo needed), 2 = the band's first/last segment (optionally
         on another hipStream_t); follow part 2 with phase_rowsums() once the solver's stream waits for it."""
         _check(self._lib.j2p_solver_phase_gradient_part(self._h, int(part), stream))
+
+    def phase_project_part(self, part):
+        """part 1 = norm + the band's first/last block rows (the rows the neighbours need), 2 = the rest"""
+        _check(self._lib.j2p_solver_phase_project_part(self._h, int(part)))
 
     def phase_rowsums(self):
         _check(self._lib.j2p_solver_phase_rowsums(self._h))

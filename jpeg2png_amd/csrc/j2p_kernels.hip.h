@@ -180,6 +180,9 @@ struct ProjArgs {
         double *part_prob;  // [c][strip]  (LOG only)
         unsigned strips_per_chan;   // stride of part_prob
         unsigned chan_of_z[kMaxCh]; // channel handled by blockIdx.z (channels are launched grouped by sampling)
+        // block rows of the band handled by this launch: by = by_offset + i * by_mul for i < nby
+        // (all: 0,1,brows; first and last only: 0,brows-1,2; all but those: 1,1,brows-2)
+        unsigned by_offset, by_mul, nby;
 };
 
 // rows per norm partial: the granularity of the GPU-count invariant reduction (J2P_TILE_ROWS)
@@ -1100,9 +1103,11 @@ __global__ __launch_bounds__(256) void k_project(ProjArgs a)
         const unsigned ws = k.ws, hs = k.hs;
         const unsigned strips_x = (W + 64 * ws - 1) / (64 * ws);      // strips across the canvas
         const unsigned brows = (a.geo.rows + 8 * hs - 1) / (8 * hs);  // block rows in the band
-        const unsigned strip = blockIdx.x * 4 + wave;
-        if(strip >= strips_x * brows) { return; }
-        const unsigned by = strip / strips_x, sx = strip % strips_x;
+        const unsigned lstrip = blockIdx.x * 4 + wave;                // index within this launch
+        if(lstrip >= strips_x * a.nby) { return; }
+        const unsigned by = a.by_offset + (lstrip / strips_x) * a.by_mul, sx = lstrip % strips_x;
+        const unsigned strip = by * strips_x + sx;                    // index within the band
+        (void)brows;
         float *scratch = tp + wave * kTpWave;
 
         const float norm = a.norm[c];

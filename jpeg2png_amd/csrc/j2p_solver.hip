@@ -73,6 +73,7 @@ struct j2p_solver {
         float factor = 0.f;      // of the iteration whose gradient phase ran last
         int cur = 0;             // xbuf[cur] is x_k
         bool grad_done = false;
+        bool proj_boundary_done = false;   // between the two parts of a split projection phase
         // reductions
         unsigned rpw = 16;
         unsigned *seg_row = nullptr;     // device: [nseg + 1] segment start rows
@@ -292,13 +293,19 @@ int do_rowsums(j2p_solver *s)
         return J2P_OK;
 }
 
-int do_phase_project(j2p_solver *s, bool log)
+// part: 0 = whole phase; J2P_PROJECT_BOUNDARY (1) = norm + the band's first and last block row of every
+// channel (they hold the rows the neighbours need); J2P_PROJECT_INTERIOR (2) = the rest, ends the iteration
+int do_phase_project(j2p_solver *s, bool log, int part = 0)
 {
         if(!s->grad_done) { return fail(J2P_ESTATE, "phase_project called before phase_gradient"); }
         if(s->rowsums_pending) { return fail(J2P_ESTATE, "phase_project before j2p_solver_phase_rowsums"); }
+        if(part == 2 && !s->proj_boundary_done) { return fail(J2P_ESTATE, "interior part of phase_project before the boundary part"); }
+        if(part != 2 && s->proj_boundary_done) { return fail(J2P_ESTATE, "boundary part of phase_project issued twice"); }
         unsigned P = 1;
         while(P < s->ntr_global) { P <<= 1; }
-        if(s->whole) {
+        if(part == 2) {
+                // the norm is already there
+        } else if(s->whole) {
                 // stage as many of the partials at once as the CU's LDS holds (P <= 4096)
                 unsigned stage = 0;                                  // narrow canvases: direct form (4.6 vs 5.4 us at 4096^2)
                 if(s->ntx > 48) {
@@ -320,7 +327,7 @@ int do_phase_project(j2p_solver *s, bool log)
         a.norm = s->norm;
         a.part_prob = s->part_prob;
         a.strips_per_chan = s->strips_stride;
-        mark(s);
+        if(part != 1) { mark(s); }
         // one launch per sampling class present (usually: luma 1x1, both chroma 2x2)
         bool done[kMaxCh] = {false, false, false};
         for(unsigned c0 = 0; c0 < s->nch; c0++) {
@@ -333,7 +340,12 @@ int do_phase_project(j2p_solver *s, bool log)
                                 done[c] = true;
                         }
                 }
-                const unsigned strips = ((s->W + 64 * ws - 1) / (64 * ws)) * ((s->rows + 8 * hs - 1) / (8 * hs));
+                const unsigned brows = (s->rows + 8 * hs - 1) / (8 * hs);
+                if(part == 0) { a.by_offset = 0; a.by_mul = 1; a.nby = brows; }
+                else if(part == 1) { a.by_offset = 0; a.by_mul = brows > 1 ? brows - 1 : 1; a.nby = brows < 2 ? brows : 2; }
+                else { a.by_offset = 1; a.by_mul = 1; a.nby = brows > 2 ? brows - 2 : 0; }
+                if(a.nby == 0) { continue; }
+                const unsigned strips = ((s->W + 64 * ws - 1) / (64 * ws)) * a.nby;
                 dim3 grid((strips + 3) / 4, 1, nz);
 #define J2P_LAUNCH_PROJECT(WS_, HS_)                                                               \
         do {                                                                                       \
@@ -347,8 +359,13 @@ int do_phase_project(j2p_solver *s, bool log)
                 else { J2P_LAUNCH_PROJECT(0, 0); }
 #undef J2P_LAUNCH_PROJECT
         }
-        mark(s);
+        if(part != 1) { mark(s); }
         HIP_TRY(hipGetLastError());
+        if(part == 1) {
+                s->proj_boundary_done = true;
+                return J2P_OK;
+        }
+        s->proj_boundary_done = false;
         s->cur ^= 1;        // SWAP(fdata, fista) of compute.c:438: the buffer just written is x_{k+1}
         s->iter++;
         s->grad_done = false;
@@ -706,6 +723,14 @@ int j2p_solver_phase_project(j2p_solver *s)
         return do_phase_project(s, false);
 }
 
+int j2p_solver_phase_project_part(j2p_solver *s, int part)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        if(part != J2P_PROJECT_BOUNDARY && part != J2P_PROJECT_INTERIOR) { return fail(J2P_EINVAL, "part must be J2P_PROJECT_BOUNDARY or J2P_PROJECT_INTERIOR"); }
+        DeviceGuard guard(s->device);
+        return do_phase_project(s, false, part);
+}
+
 int j2p_solver_run(j2p_solver *s, unsigned n, j2p_log_row *rows)
 {
         if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
@@ -783,7 +808,9 @@ int j2p_solver_exchange_info(j2p_solver *s, j2p_exchange *info)
         info->first_tile_row = s->first_tr;
         info->halo_floats = (size_t)kHalo * s->W;
         for(unsigned c = 0; c < s->nch; c++) {
-                float *base = s->ch[c].xbuf[s->cur];
+                // between the two parts of a split projection phase the rows to exchange are those of the
+                // iterate being written (the buffers swap when the interior part is issued)
+                float *base = s->ch[c].xbuf[s->proj_boundary_done ? s->cur ^ 1 : s->cur];
                 info->recv_top[c] = base;
                 info->send_top[c] = base + (size_t)kHalo * s->W;
                 info->send_bottom[c] = base + (size_t)s->rows * s->W;

@@ -130,8 +130,25 @@ class HipBandEngine:
         self._edges_done = self.side.record_event()
 
     def finish_gradient(self):
-        self.stream.wait_event(self._edges_done)
+        if self._edges_done is not None:
+            self.stream.wait_event(self._edges_done)
+            self._edges_done = None
         self.solver.phase_rowsums()
+
+    def gradient_edges_inline(self, halo_ready=None):
+        """first/last segment on the solver's own stream, behind `halo_ready`"""
+        if halo_ready is not None:
+            self.stream.wait_event(halo_ready)
+        self.solver.phase_gradient_part(2)
+
+    # -- projection phase split in two, so that the halo rows leave as early as possible ---------
+    def project_boundary(self):
+        """norm + the band's first and last block rows; halo() then refers to the NEW iterate"""
+        self.solver.phase_project_part(1)
+        self._parity ^= 1
+
+    def project_interior(self):
+        self.solver.phase_project_part(2)
 
     def project_done_event(self):
         return self.stream.record_event()
@@ -257,15 +274,20 @@ class RowTiledSolver:
                     e.phase_project()
                     self.exchange_halo()
             return
+        # One stream carries the whole iteration; only the halo exchange runs beside it.  The rows the
+        # neighbours need are projected first, so the exchange has the interior of the projection AND the
+        # interior of the next gradient phase (two kernels, ~2/3 of the iteration) to complete in; the
+        # all-gather of the norm partials is the only communication left on the critical path.
         for _ in range(n):
             with e.stream_context():
                 e.gradient_interior()
-            e.gradient_edges(self._halo_ready)
-            with e.stream_context():
+                e.gradient_edges_inline(self._halo_ready)
                 e.finish_gradient()
                 self.gather_partials()
-                e.phase_project()
+                e.project_boundary()
             self._halo_ready = self._exchange_halo_async()
+            with e.stream_context():
+                e.project_interior()
         # leave the solver's stream consistent for whoever comes next (download, reset, ...)
         if self._halo_ready is not None:
             e.stream.wait_event(self._halo_ready)

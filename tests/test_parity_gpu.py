@@ -166,7 +166,7 @@ def test_band_split_matches_whole(lib, oracle):
     with j.Solver(planes, 0.3, [0.001], its) as whole:
         whole.run(its)
         want = whole.download(0)
-    hip = ctypes.CDLL("libamdhip64.so")
+    hip = j.hip_runtime()
     hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     D2D = 3
     bands = [j.Solver(planes, 0.3, [0.001], its, band=(0, 48)), j.Solver(planes, 0.3, [0.001], its, band=(48, 96))]

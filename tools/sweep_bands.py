@@ -15,7 +15,7 @@ from sweep_cases import cases
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-hip = ctypes.CDLL("libamdhip64.so")
+hip = j.hip_runtime()
 hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
 D2D = 3
 rng = np.random.default_rng([seed, 77])
