@@ -211,7 +211,9 @@ def main():
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "iterations_per_step": its, "weight": WEIGHT, "pweight": PWEIGHT,
-                       "parallelism": "single GPU" if not tiled_mode else f"row-tiled x{n_gpus}, RCCL halo + norm all-gather"},
+                       "parallelism": "single GPU" if not tiled_mode else
+                       f"row-tiled x{n_gpus}, RCCL halo send/recv + norm all-gather "
+                       f"({'librccl called on the solver streams' if driver.direct is not None else 'through torch.distributed'})"},
             "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_unit": "bytes per launch", "traffic_source": traffic_src,

@@ -192,6 +192,21 @@ class RowTiledSolver:
         self.self_neighbours = self.world == 1 and os.environ.get("J2P_TILED_SELF_NEIGHBOURS", "0") == "1"
         if self.self_neighbours:
             self.up = self.down = self.rank
+        # RCCL called directly on the solver's streams where possible (GPU engine, nccl backend); the
+        # torch.distributed calls remain for CPU engines (gloo tests), unequal bands and as the fallback
+        self.direct = None
+        want = os.environ.get("J2P_TILED_TRANSPORT", "rccl")
+        if want == "rccl" and getattr(engine, "can_split", None) is not None and dist.get_backend(group) == "nccl":
+            try:
+                from . import rccl
+                with torch.cuda.device(engine.device):
+                    # two communicators: RCCL orders the operations of ONE communicator among themselves even
+                    # across streams, and the halo exchange must not get in the all-gather's way
+                    self.direct = rccl.Communicator(group)
+                    self.direct_p2p = rccl.Communicator(group)
+            except Exception as ex:                       # noqa: BLE001 — any failure means "use torch's path"
+                import sys
+                print(f"jpeg2png_amd.tiled: direct RCCL unavailable ({ex}); using torch.distributed", file=sys.stderr)
         counts = torch.zeros(self.world, dtype=torch.int64)
         counts[self.rank] = engine.local_tile_rows
         counts = counts.to(engine.partials_local.device)
@@ -210,6 +225,10 @@ class RowTiledSolver:
         if self.world == 1 and not self.self_neighbours:
             if e.partials_all.data_ptr() != e.partials_local.data_ptr():
                 e.partials_all.copy_(e.partials_local)
+            return
+        if self.equal and self.direct is not None:
+            self.direct.all_gather(e.partials_local.data_ptr(), e.partials_all.data_ptr(), e.partials_local.numel(),
+                                   ctypes.c_void_p(torch.cuda.current_stream(e.device).cuda_stream))
             return
         if self.equal:
             dist.all_gather_into_tensor(e.partials_all, e.partials_local, group=self.group)
@@ -243,8 +262,20 @@ class RowTiledSolver:
             self._ops[key] = (ops, h)     # keep the views alive
         else:
             ops = ops[0]
+        if self.direct is not None:
+            sends = [(op.tensor.data_ptr(), op.tensor.numel(), op.peer) for op in ops if op.op is dist.isend]
+            recvs = [(op.tensor.data_ptr(), op.tensor.numel(), op.peer) for op in ops if op.op is dist.irecv]
+            self.direct_p2p.exchange(sends, recvs, ctypes.c_void_p(torch.cuda.current_stream(self.e.device).cuda_stream))
+            return
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+
+    def close(self):
+        """release the direct RCCL communicators (the engine is closed by its owner)"""
+        if self.direct is not None:
+            self.direct.close()
+            self.direct_p2p.close()
+            self.direct = None
 
     # -- loop --------------------------------------------------------------
     def start(self):
