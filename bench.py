@@ -55,6 +55,16 @@ def parse():
     return ap.parse_args()
 
 
+def _flush_c_stdio():
+    """RCCL prints its NCCL_DEBUG=VERSION banner through C stdio, which is block-buffered on a pipe and would
+    otherwise surface at exit, after the JSON line: push it out when the communicators exist"""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def cpu_baseline(width, seed):
     """time the reference solver on a bounded sample of the same workload: the same plane
     (same seed, Y-only, Q10, same weights), 4096 rows x `width`, but 40 iterations instead of
@@ -138,6 +148,7 @@ def main():
         engine = tiled.HipBandEngine(band_planes, WEIGHT, [PWEIGHT], its, (r0, r1), local_rank)
         del band_planes
         driver = tiled.RowTiledSolver(engine)
+        _flush_c_stdio()
 
         def reset():
             engine.reset()
@@ -225,6 +236,7 @@ def main():
         }
         if not tiled_mode and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, seed)
+        _flush_c_stdio()
         print(json.dumps(out), flush=True)
     if tiled_mode:
         import torch.distributed as dist
