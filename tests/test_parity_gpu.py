@@ -599,3 +599,15 @@ print("both fine")
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "both fine" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_extreme_shapes_against_the_compiled_reference(lib, oracle):
+    """tools/extreme_shapes.py as a test: 65500 pixels in one dimension (the JPEG limit) by a few in the other,
+    all samplings, and two joint images above the 9 Mpixel switch to the channels-in-one-wavefront kernel"""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "extreme_shapes.py")], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
