@@ -201,10 +201,16 @@ def main():
         else:
             kern, dur_ms, bpp = "k_project", p_ms, BYTES_PROJECT
         achieved = band_px * bpp / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+        # pixels per TIMED launch: in the row-tiled schedule the events bracket the interior launches only
+        # (all 16-row segments but the band's first and last; all block rows but the first and last)
+        px_of = {"k_gradient": band_px, "k_project": band_px}
+        if tiled_mode and driver.overlap:
+            px_of = {"k_gradient": W * (rows_per_gpu - 32), "k_project": W * (rows_per_gpu - 16)}
+        achieved = px_of[kern] * bpp / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
         per_kernel = {}
         for kname, kms, kb in (("k_gradient", g_ms, BYTES_GRADIENT), ("k_project", p_ms, BYTES_PROJECT)):
-            gbs = band_px * kb / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-            per_kernel[kname] = {"avg_launch_ms": round(kms, 4), "algorithmic_bytes_per_launch": band_px * kb,
+            gbs = px_of[kname] * kb / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+            per_kernel[kname] = {"avg_launch_ms": round(kms, 4), "algorithmic_bytes_per_launch": px_of[kname] * kb,
                                  "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
         # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/, corrected as
         # MI355X_MICROARCH.md prescribes); only meaningful for the N=1 workload they were taken on
@@ -228,7 +234,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": band_px * bpp,
+                         "algorithmic_bytes_per_launch": px_of[kern] * bpp,
                          "avg_launch_ms": {"k_gradient": round(g_ms, 4), "k_project": round(p_ms, 4)},
                          "per_kernel": per_kernel,
                          "event_samples": samples,

@@ -398,6 +398,7 @@ int launch_init(j2p_solver *s)
         s->grad_done = false;
         s->interior_done = false;
         s->rowsums_pending = false;
+        s->proj_boundary_done = false;
         for(unsigned c = 0; c < kMaxCh; c++) { s->carried_prob[c] = 0.; }
         s->carried_valid = true;
         return J2P_OK;
