@@ -249,11 +249,12 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         a.part_tv = s->part_tv;
         const bool tgv = s->weight != 0.f;
         if(part != 2) { mark(s); }     // event timing covers the main launch only (the edge part runs on another stream)
-        // joint images: one wavefront per channel (norms exchanged through LDS) gives three times the
-        // wavefronts and wins up to ~9 Mpixel; above that all channels in one wavefront is as fast
-        // (measured crossover ~3072^2).  J2P_JOINT_INWAVE=0/1 forces either.
+        // joint images: one wavefront per channel, the norms exchanged through LDS (three times the
+        // wavefronts at 4 per SIMD), beats all channels in one wavefront (248 VGPRs, 2 per SIMD) at every
+        // size measured: 198 vs 293 us at 12 Mpixel 4:2:0, 494 vs 717 us at 36 Mpixel.  J2P_JOINT_INWAVE=1
+        // selects the in-wavefront kernel (kept: it is the same arithmetic in another schedule, and tested).
         const char *jenv = getenv("J2P_JOINT_INWAVE");
-        const bool inwave = jenv ? atoi(jenv) != 0 : (size_t)s->W * s->H >= ((size_t)9 << 20);
+        const bool inwave = jenv ? atoi(jenv) != 0 : false;
         switch(s->nch) {
         case 1: launch_gradient_n<1, 1>(a, s->ntx, nseg_launch, st, tgv, log); break;
         case 2:

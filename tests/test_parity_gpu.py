@@ -603,7 +603,7 @@ print("both fine")
 
 def test_extreme_shapes_against_the_compiled_reference(lib, oracle):
     """tools/extreme_shapes.py as a test: 65500 pixels in one dimension (the JPEG limit) by a few in the other,
-    all samplings, and two joint images above the 9 Mpixel switch to the channels-in-one-wavefront kernel"""
+    all samplings, and two joint images of ~9.5 Mpixel"""
     if not oracle.have_ref():
         pytest.skip("oracle/_ref not built (needs /root/reference)")
     import subprocess

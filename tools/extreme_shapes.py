@@ -1,5 +1,5 @@
 """extreme aspect ratios against the compiled reference — the JPEG limit (65500 pixels a side) in one dimension —
-and joint images large enough for the channels-in-one-wavefront gradient kernel (>= 9 Mpixel)"""
+and two joint images of ~9.5 Mpixel"""
 import copy
 import sys
 
