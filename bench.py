@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--height", type=int, default=0, help="override plane height (debug, single GPU)")
     ap.add_argument("--iterations", type=int, default=0, help="override iterations per solve (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--timing-every", type=int, default=4, help="HIP-event sample stride (iterations)")
+    ap.add_argument("--timing-every", type=int, default=16, help="HIP-event sample stride (iterations)")
     ap.add_argument("--force-tiled", action="store_true", help="run the row-tiled path even with one rank (debug)")
     return ap.parse_args()
 
