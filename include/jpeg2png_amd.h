@@ -137,15 +137,28 @@ int j2p_solver_phase_project_part(j2p_solver *s, int part);
  *                    [tile_row][channel], so the bands of consecutive GPUs concatenate.
  *   halo addresses : for channel c, the rows of the CURRENT iterate x_k:
  *                    send_top  = first J2P_HALO_ROWS own rows, recv_top = the halo
- *                    rows above them (same for bottom); each J2P_HALO_ROWS*W floats. */
+ *                    rows above them (same for bottom); each J2P_HALO_ROWS*W floats.
+ *   log_local      : NULL unless j2p_solver_set_logging() is on; then 2 + J2P_MAX_CHANNELS doubles:
+ *                    the band's tv and tv2 sums (valid after the gradient phase) and its prob distance
+ *                    per channel for the state the projection phase leaves. */
 typedef struct j2p_exchange {
         double *partials_local;  unsigned local_tile_rows;
         double *partials_all;    unsigned global_tile_rows; unsigned first_tile_row;
         float *send_top[J2P_MAX_CHANNELS], *recv_top[J2P_MAX_CHANNELS];
         float *send_bottom[J2P_MAX_CHANNELS], *recv_bottom[J2P_MAX_CHANNELS];
         size_t halo_floats;
+        double *log_local;
 } j2p_exchange;
 int j2p_solver_exchange_info(j2p_solver *s, j2p_exchange *info);
+
+/* CSV logging for band solvers (the "+3 doubles when logging" of the norm exchange): with logging on, the
+ * phase calls also leave the band's tv / tv2 / prob sums in j2p_exchange.log_local; the caller adds the bands'
+ * sums up (any fixed order: the values only feed the log) and turns n iterations' worth of
+ * {tv, tv2, prob[J2P_MAX_CHANNELS]} into the reference's log rows (compute.c:226-272, logger.c:20-28):
+ * row i reports the prob distance of the state ENTERING iteration i (0 at iteration 0). */
+int j2p_solver_set_logging(j2p_solver *s, int on);
+int j2p_log_rows_from_sums(unsigned nchannel, float weight, const float pweight[], unsigned n,
+                           const double *sums /* n * (2 + J2P_MAX_CHANNELS) */, j2p_log_row *rows);
 
 /* band-local arrays only: after the caller has exchanged the halo rows of the INITIAL
  * iterate, copy them into x_{k-1}'s halo rows too (fista = copy(fdata), compute.c:307-309) */

@@ -49,7 +49,7 @@ class _CExchange(ctypes.Structure):
                 ("first_tile_row", ctypes.c_uint),
                 ("send_top", ctypes.c_void_p * 3), ("recv_top", ctypes.c_void_p * 3),
                 ("send_bottom", ctypes.c_void_p * 3), ("recv_bottom", ctypes.c_void_p * 3),
-                ("halo_floats", ctypes.c_size_t)]
+                ("halo_floats", ctypes.c_size_t), ("log_local", ctypes.c_void_p)]
 
 
 # every symbol include/jpeg2png_amd.h and include/jpeg2png_amd_compute.h declare
@@ -59,7 +59,7 @@ C_ABI_SYMBOLS = [
     "j2p_solver_reset", "j2p_solver_run", "j2p_solver_phase_gradient", "j2p_solver_phase_project",
     "j2p_solver_phase_gradient_part", "j2p_solver_phase_rowsums", "j2p_solver_phase_project_part",
     "j2p_solver_exchange_info", "j2p_solver_commit_initial_halo", "j2p_solver_download",
-    "j2p_solver_download_gradient",
+    "j2p_solver_download_gradient", "j2p_solver_set_logging", "j2p_log_rows_from_sums",
     "j2p_solver_plane_ptr", "j2p_solver_sync", "j2p_solver_kernel_times", "j2p_solver_enable_timing",
     "j2p_decode_plane", "j2p_dct8x8_blocks", "j2p_math_selftest", "j2p_planes_to_rgb", "j2p_sqrt_exhaustive",
     "compute", "j2p_compute",
@@ -126,6 +126,9 @@ def load_library():
     lib.j2p_solver_destroy.restype = None
     lib.j2p_solver_phase_gradient_part.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     lib.j2p_solver_phase_project_part.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.j2p_solver_set_logging.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.j2p_log_rows_from_sums.argtypes = [ctypes.c_uint, ctypes.c_float, ctypes.POINTER(ctypes.c_float), ctypes.c_uint,
+                                           ctypes.c_void_p, ctypes.POINTER(_CLogRow)]
     for name in ("j2p_solver_reset", "j2p_solver_phase_gradient", "j2p_solver_phase_project",
                  "j2p_solver_sync", "j2p_solver_commit_initial_halo", "j2p_solver_phase_rowsums"):
         getattr(lib, name).argtypes = [ctypes.c_void_p]
@@ -267,6 +270,10 @@ class Solver:
         """part 1 = norm + the band's first/last block rows (the rows the neighbours need), 2 = the rest"""
         _check(self._lib.j2p_solver_phase_project_part(self._h, int(part)))
 
+    def set_logging(self, on=True):
+        """band solvers: the phase calls also leave the band's tv / tv2 / prob sums in exchange_info().log_local"""
+        _check(self._lib.j2p_solver_set_logging(self._h, 1 if on else 0))
+
     def phase_rowsums(self):
         _check(self._lib.j2p_solver_phase_rowsums(self._h))
 
@@ -305,6 +312,17 @@ class Solver:
         g, p, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint()
         _check(self._lib.j2p_solver_kernel_times(self._h, ctypes.byref(g), ctypes.byref(p), ctypes.byref(n)))
         return g.value, p.value, n.value
+
+
+def log_rows_from_sums(nch, weight, pweight, sums):
+    """log rows [objective, prob_dist, tv, tv2] from per-iteration global sums (n x 5: tv, tv2, prob per channel)"""
+    lib = load_library()
+    sums = np.ascontiguousarray(sums, dtype=np.float64).reshape(-1, 2 + J2P_MAX_CHANNELS)
+    n = sums.shape[0]
+    rows = (_CLogRow * max(n, 1))()
+    pw = (ctypes.c_float * nch)(*[float(x) for x in pweight])
+    _check(lib.j2p_log_rows_from_sums(nch, float(weight), pw, n, sums.ctypes.data, rows))
+    return np.array([[r.objective, r.prob_dist, r.tv, r.tv2] for r in rows[:n]], dtype=np.float64).reshape(n, 4)
 
 
 def compute(planes, weight, pweight, iterations, log=False, device=0):

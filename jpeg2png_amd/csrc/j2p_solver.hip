@@ -93,6 +93,9 @@ struct j2p_solver {
         unsigned logsums_cap = 0;
         double carried_prob[kMaxCh] = {0., 0., 0.};
         bool carried_valid = true;
+        bool log_phases = false;         // the phase calls run the logging kernels and fill log_band
+        bool bandlog_pending = false;    // split gradient phase: band sums still to be launched (phase_rowsums)
+        double *log_band = nullptr;      // [2 + kMaxCh]: tv, tv2 of the last gradient phase, prob per channel of the last projection
         // timing
         unsigned timing = 0;     // 0 = off, k = time every k-th iteration
         std::vector<hipEvent_t> ev;      // triples: before gradient, after gradient/before reduce.., see record()
@@ -209,6 +212,18 @@ int flush_timing(j2p_solver *s)
 // part: 0 = all segments, 1 = interior segments only (they never read halo rows), 2 = the first and
 // last segment (after the halo rows have arrived).  1 then 2 make one gradient phase; `st` is the stream
 // the kernel goes to (part 2 may use a side stream so that it overlaps part 1).
+// band-level sums for the CSV row (tv, tv2 after a gradient phase; prob distance after a projection)
+static void launch_band_log(j2p_solver *s, int which)
+{
+        if(which == 0) {
+                hipLaunchKernelGGL(k_log_sums, dim3(1), dim3(256), 0, s->stream, (const double *)s->part_tv, s->ntx * s->nseg,
+                                   (const double *)s->part_prob, 0u, s->strips_stride, s->nch, s->log_band, 0);
+        } else {
+                hipLaunchKernelGGL(k_log_sums, dim3(1), dim3(256), 0, s->stream, (const double *)s->part_tv, 0u,
+                                   (const double *)s->part_prob, s->strips_stride, s->strips_stride, s->nch, s->log_band, 1);
+        }
+}
+
 // per-tile-row sums of the band's norm partials: blocks of up to 256 tile rows, as many as stage in LDS
 static void launch_rowsums(j2p_solver *s)
 {
@@ -279,6 +294,13 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         }
         s->grad_done = true;
         s->rowsums_pending = part == 2 && !s->whole;
+        // band sums for the CSV row: behind the last launch of the phase (for a split phase that is
+        // j2p_solver_phase_rowsums(), once the solver's stream has joined the edge part)
+        s->bandlog_pending = false;
+        if(log && s->log_phases) {
+                if(part == 0) { launch_band_log(s, 0); }
+                else { s->bandlog_pending = true; }
+        }
         return J2P_OK;
 }
 
@@ -287,6 +309,10 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
 int do_rowsums(j2p_solver *s)
 {
         if(!s->grad_done) { return fail(J2P_ESTATE, "rowsums without a finished gradient phase"); }
+        if(s->bandlog_pending) {
+                launch_band_log(s, 0);
+                s->bandlog_pending = false;
+        }
         if(!s->rowsums_pending) { return J2P_OK; }     // whole-canvas solver: folded into the norm kernel
         launch_rowsums(s);
         HIP_TRY(hipGetLastError());
@@ -367,6 +393,7 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
                 return J2P_OK;
         }
         s->proj_boundary_done = false;
+        if(log && s->log_phases) { launch_band_log(s, 1); }
         s->cur ^= 1;        // SWAP(fdata, fista) of compute.c:438: the buffer just written is x_{k+1}
         s->iter++;
         s->grad_done = false;
@@ -400,6 +427,7 @@ int launch_init(j2p_solver *s)
         s->interior_done = false;
         s->rowsums_pending = false;
         s->proj_boundary_done = false;
+        s->bandlog_pending = false;
         for(unsigned c = 0; c < kMaxCh; c++) { s->carried_prob[c] = 0.; }
         s->carried_valid = true;
         return J2P_OK;
@@ -445,6 +473,7 @@ void j2p_solver_destroy(j2p_solver *s)
         (void)hipFree(s->part_tv);
         (void)hipFree(s->part_prob);
         (void)hipFree(s->logsums);
+        (void)hipFree(s->log_band);
         for(hipEvent_t e : s->ev) { (void)hipEventDestroy(e); }
         if(s->own_stream && s->stream) { (void)hipStreamDestroy(s->stream); }
         delete s;
@@ -700,7 +729,7 @@ int j2p_solver_phase_gradient(j2p_solver *s)
 {
         if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
         DeviceGuard guard(s->device);
-        return do_phase_gradient(s, false);
+        return do_phase_gradient(s, s->log_phases);
 }
 
 int j2p_solver_phase_gradient_part(j2p_solver *s, int part, void *stream)
@@ -708,7 +737,7 @@ int j2p_solver_phase_gradient_part(j2p_solver *s, int part, void *stream)
         if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
         if(part != J2P_GRADIENT_INTERIOR && part != J2P_GRADIENT_EDGES) { return fail(J2P_EINVAL, "part must be J2P_GRADIENT_INTERIOR or J2P_GRADIENT_EDGES"); }
         DeviceGuard guard(s->device);
-        return do_phase_gradient(s, false, part, (hipStream_t)stream);
+        return do_phase_gradient(s, s->log_phases, part, (hipStream_t)stream);
 }
 
 int j2p_solver_phase_rowsums(j2p_solver *s)
@@ -722,7 +751,7 @@ int j2p_solver_phase_project(j2p_solver *s)
 {
         if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
         DeviceGuard guard(s->device);
-        return do_phase_project(s, false);
+        return do_phase_project(s, s->log_phases);
 }
 
 int j2p_solver_phase_project_part(j2p_solver *s, int part)
@@ -730,7 +759,58 @@ int j2p_solver_phase_project_part(j2p_solver *s, int part)
         if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
         if(part != J2P_PROJECT_BOUNDARY && part != J2P_PROJECT_INTERIOR) { return fail(J2P_EINVAL, "part must be J2P_PROJECT_BOUNDARY or J2P_PROJECT_INTERIOR"); }
         DeviceGuard guard(s->device);
-        return do_phase_project(s, false, part);
+        return do_phase_project(s, s->log_phases, part);
+}
+
+// log rows from per-iteration sums {tv, tv2, prob distance per channel of the state LEFT by the iteration}
+// (compute.c:226-272: total_alpha in float, objective in double).  carried[] is the prob distance of the
+// state entering the first of the n iterations (0 at iteration 0: cos = d*q) and is updated.
+static void rows_from_sums(unsigned nch, float weight, const float *pweight, unsigned n, const double *sums,
+                           double *carried, bool carried_valid, j2p_log_row *rows)
+{
+        constexpr unsigned kRow = 2 + kMaxCh;
+        float total_alpha = 0.f;
+        for(unsigned c = 0; c < nch; c++) {
+                if(pweight[c] != 0.f) { total_alpha += pweight[c] * 2 * 255 * sqrtf(2); }
+        }
+        total_alpha += nch;
+        if(weight != 0.f) { total_alpha += (weight / sqrtf((float)(4 / 2))) * nch; }
+        for(unsigned i = 0; i < n; i++) {
+                const double *h = &sums[(size_t)i * kRow];
+                double prob = 0.;
+                for(unsigned c = 0; c < nch; c++) {
+                        if(pweight[c] != 0.f) { prob += 0.5 * carried[c]; }   // compute_simd_step.c:61
+                }
+                if(!carried_valid) { prob = NAN; }
+                rows[i].tv = h[0];
+                rows[i].tv2 = weight != 0.f ? h[1] : 0.;
+                rows[i].prob_dist = prob;
+                rows[i].objective = (rows[i].tv + rows[i].tv2 + prob) / total_alpha;
+                for(unsigned c = 0; c < nch; c++) { carried[c] = h[2 + c]; }
+                carried_valid = true;
+        }
+}
+
+int j2p_log_rows_from_sums(unsigned nchannel, float weight, const float pweight[], unsigned n, const double *sums,
+                           j2p_log_row *rows)
+{
+        if(!pweight || !sums || !rows) { return fail(J2P_EINVAL, "NULL argument"); }
+        if(nchannel == 0 || nchannel > kMaxCh) { return fail(J2P_EINVAL, "nchannel must be 1..3"); }
+        double carried[kMaxCh] = {0., 0., 0.};
+        rows_from_sums(nchannel, weight, pweight, n, sums, carried, true, rows);
+        return J2P_OK;
+}
+
+int j2p_solver_set_logging(j2p_solver *s, int on)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        DeviceGuard guard(s->device);
+        if(on && !s->log_band) {
+                HIP_TRY(hipMalloc(&s->log_band, (2 + kMaxCh) * sizeof(double)));
+                HIP_TRY(hipMemsetAsync(s->log_band, 0, (2 + kMaxCh) * sizeof(double), s->stream));
+        }
+        s->log_phases = on != 0;
+        return J2P_OK;
 }
 
 int j2p_solver_run(j2p_solver *s, unsigned n, j2p_log_row *rows)
@@ -772,27 +852,10 @@ int j2p_solver_run(j2p_solver *s, unsigned n, j2p_log_row *rows)
                 std::vector<double> host((size_t)n * kRow);
                 HIP_TRY(hipMemcpyAsync(host.data(), s->logsums, host.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream));
                 HIP_TRY(hipStreamSynchronize(s->stream));
-                // compute.c:226-272: total_alpha in float, objective in double
-                float total_alpha = 0.f;
-                for(unsigned c = 0; c < s->nch; c++) {
-                        if(s->ch[c].pweight != 0.f) { total_alpha += s->ch[c].pweight * 2 * 255 * sqrtf(2); }
-                }
-                total_alpha += s->nch;
-                if(s->weight != 0.f) { total_alpha += (s->weight / sqrtf((float)(4 / 2))) * s->nch; }
-                for(unsigned i = 0; i < n; i++) {
-                        const double *h = &host[(size_t)i * kRow];
-                        double prob = 0.;
-                        for(unsigned c = 0; c < s->nch; c++) {
-                                if(s->ch[c].pweight != 0.f) { prob += 0.5 * s->carried_prob[c]; }   // compute_simd_step.c:61
-                        }
-                        if(!s->carried_valid) { prob = NAN; }
-                        rows[i].tv = h[0];
-                        rows[i].tv2 = s->weight != 0.f ? h[1] : 0.;
-                        rows[i].prob_dist = prob;
-                        rows[i].objective = (rows[i].tv + rows[i].tv2 + prob) / total_alpha;
-                        for(unsigned c = 0; c < s->nch; c++) { s->carried_prob[c] = h[2 + c]; }
-                        s->carried_valid = true;
-                }
+                float pw[kMaxCh] = {0.f, 0.f, 0.f};
+                for(unsigned c = 0; c < s->nch; c++) { pw[c] = s->ch[c].pweight; }
+                rows_from_sums(s->nch, s->weight, pw, n, host.data(), s->carried_prob, s->carried_valid, rows);
+                s->carried_valid = true;
         } else if(n) {
                 s->carried_valid = false;
         }
@@ -809,6 +872,7 @@ int j2p_solver_exchange_info(j2p_solver *s, j2p_exchange *info)
         info->global_tile_rows = s->ntr_global;
         info->first_tile_row = s->first_tr;
         info->halo_floats = (size_t)kHalo * s->W;
+        info->log_local = s->log_band;
         for(unsigned c = 0; c < s->nch; c++) {
                 // between the two parts of a split projection phase the rows to exchange are those of the
                 // iterate being written (the buffers swap when the interior part is issued)

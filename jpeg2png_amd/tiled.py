@@ -25,7 +25,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import J2P_HALO_ROWS, J2P_TILE_ROWS, Solver
+from . import J2P_HALO_ROWS, J2P_MAX_CHANNELS, J2P_TILE_ROWS, Solver, log_rows_from_sums
 
 
 def band_alignment(planes):
@@ -76,6 +76,8 @@ class HipBandEngine:
                              stream=ctypes.c_void_p(self.stream.cuda_stream), band=band,
                              band_local_arrays=band_local_arrays)
         self.nch = self.solver.nch
+        self.weight, self.pweight = float(weight), [float(x) for x in pweight]
+        self.log_local = None
         e = self.solver.exchange_info()
         self.local_tile_rows, self.global_tile_rows = e.local_tile_rows, e.global_tile_rows
         self.first_tile_row = e.first_tile_row
@@ -86,6 +88,12 @@ class HipBandEngine:
         self.side = torch.cuda.Stream(device=self.device)     # edge segments of the gradient phase
         self.comm = torch.cuda.Stream(device=self.device)     # halo exchange
         self._edges_done = None
+
+    def enable_logging(self):
+        """the phase calls also produce the band's tv / tv2 / prob sums (5 doubles, aliased as a tensor)"""
+        self.solver.set_logging(True)
+        e = self.solver.exchange_info()
+        self.log_local = alias_tensor(e.log_local, 2 + J2P_MAX_CHANNELS, torch.float64, self.device)
 
     def _views(self):
         if self._parity not in self._halo:
@@ -175,9 +183,14 @@ class RowTiledSolver:
     last 16-row segments wait for the neighbours' rows.  The all-gather of the norm partials stays
     on the critical path (it is the global dependency of the algorithm)."""
 
-    def __init__(self, engine, group=None, overlap=True):
+    def __init__(self, engine, group=None, overlap=True, log=False):
         self.e = engine
         self.group = group
+        self.log = bool(log)
+        self._logbuf = None
+        self._logged = 0
+        if self.log:
+            engine.enable_logging()
         self.overlap = bool(overlap) and getattr(engine, "can_split", False)
         self._halo_ready = None
         self.rank = dist.get_rank(group)
@@ -242,6 +255,37 @@ class RowTiledSolver:
             e.partials_all[off: off + n * e.nch] = self._stage[r * m: r * m + n * e.nch]
             off += n * e.nch
 
+    # -- CSV log sums (the "+3 doubles" of the norm exchange; only when logging) ------------------
+    def _gather_log(self):
+        """all-gather the band's {tv, tv2, prob per channel} of the iteration just finished"""
+        e = self.e
+        k = 2 + J2P_MAX_CHANNELS
+        if self._logbuf is None or self._logged >= self._logbuf.shape[0]:
+            grown = torch.zeros((max(64, 2 * self._logged), self.world, k), dtype=torch.float64, device=e.log_local.device)
+            if self._logbuf is not None:
+                grown[: self._logged] = self._logbuf[: self._logged]
+            self._logbuf = grown
+        dst = self._logbuf[self._logged]
+        if self.world == 1 and not self.self_neighbours:
+            dst[0].copy_(e.log_local)
+        elif self.direct is not None:
+            self.direct.all_gather(e.log_local.data_ptr(), dst.data_ptr(), k,
+                                   ctypes.c_void_p(torch.cuda.current_stream(e.device).cuda_stream))
+        else:
+            dist.all_gather_into_tensor(dst.view(-1), e.log_local, group=self.group)
+        self._logged += 1
+
+    def log_rows(self):
+        """the reference's CSV values [objective, prob_dist, tv, tv2] of every iteration run so far
+        (bands added up in rank order; synchronises)"""
+        if not self.log:
+            raise RuntimeError("RowTiledSolver was created without log=True")
+        sums = self._logbuf[: self._logged].cpu().numpy() if self._logged else torch.zeros((0, self.world, 5)).numpy()
+        total = sums[:, 0, :].copy()
+        for r in range(1, self.world):
+            total += sums[:, r, :]
+        return log_rows_from_sums(self.e.nch, self.e.weight, self.e.pweight, total)
+
     def exchange_halo(self):
         if self.up is None and self.down is None:
             return
@@ -280,6 +324,7 @@ class RowTiledSolver:
     # -- loop --------------------------------------------------------------
     def start(self):
         """initial halo rows of x_0 (needed when every rank only uploaded its own band)."""
+        self._logged = 0
         with self.e.stream_context():
             self.exchange_halo()
             self.e.commit_initial_halo()
@@ -303,6 +348,8 @@ class RowTiledSolver:
                     e.phase_gradient()
                     self.gather_partials()
                     e.phase_project()
+                    if self.log:
+                        self._gather_log()
                     self.exchange_halo()
             return
         # One stream carries the whole iteration; only the halo exchange runs beside it.  The rows the
@@ -319,6 +366,8 @@ class RowTiledSolver:
             self._halo_ready = self._exchange_halo_async()
             with e.stream_context():
                 e.project_interior()
+                if self.log:
+                    self._gather_log()
         # leave the solver's stream consistent for whoever comes next (download, reset, ...)
         if self._halo_ready is not None:
             e.stream.wait_event(self._halo_ready)

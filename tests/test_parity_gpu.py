@@ -268,7 +268,7 @@ def test_tiled_engine_on_one_gpu(lib, oracle):
     W, H, its = 160, 128, 5
     planes = make_case(W, H, "444", 10, seed=41, y_only=True)
     with j.Solver(planes, 0.3, [0.001], its) as whole:
-        whole.run(its)
+        want_rows = whole.run(its, log=True)
         want = whole.download(0)
 
     def band_planes(r0, r1):
@@ -356,11 +356,12 @@ def test_tiled_engine_on_one_gpu(lib, oracle):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         e = tiled.HipBandEngine(band_planes(0, H), 0.3, [0.001], its, (0, H), 0)
-        drv = tiled.RowTiledSolver(e)
+        drv = tiled.RowTiledSolver(e, log=True)       # logging on: the "+3 doubles" exchange of every iteration
         assert drv.overlap
         drv.start()
         drv.iterate(its)
         got1 = e.download(0)
+        np.testing.assert_allclose(drv.log_rows(), want_rows, rtol=1e-12, atol=0)
         e.reset()
         drv2 = tiled.RowTiledSolver(e, overlap=False)
         drv2.start()
@@ -373,11 +374,12 @@ def test_tiled_engine_on_one_gpu(lib, oracle):
             got1c = []
             for overlap in (True, False):
                 e.reset()
-                drv3 = tiled.RowTiledSolver(e, overlap=overlap)
+                drv3 = tiled.RowTiledSolver(e, overlap=overlap, log=True)
                 assert drv3.self_neighbours and drv3.up == 0 and drv3.down == 0
                 drv3.start()
                 drv3.iterate(its)
                 got1c.append(e.download(0))
+                np.testing.assert_allclose(drv3.log_rows(), want_rows, rtol=1e-12, atol=0)
         finally:
             del os.environ["J2P_TILED_SELF_NEIGHBOURS"]
         e.close()

@@ -36,10 +36,13 @@ for cs in cases(seed, n):
     its = min(cs.iterations, 12)
     ran += 1
     ref = copy.deepcopy(planes)
-    j.compute(ref, cs.weight, cs.pweights, its)
+    ref_rows = j.compute(ref, cs.weight, cs.pweights, its, log=True)
     bands = [j.Solver(planes, cs.weight, cs.pweights, its, band=(edges[i], edges[i + 1])) for i in range(nb)]
+    sums = np.zeros((its, 5))
     try:
-        for _ in range(its):
+        for s in bands:
+            s.set_logging(True)
+        for it in range(its):
             for s in bands:
                 s.phase_gradient()
             infos = [s.exchange_info() for s in bands]
@@ -54,6 +57,10 @@ for cs in cases(seed, n):
             for s in bands:
                 s.sync()
             infos = [s.exchange_info() for s in bands]
+            for info in infos:                     # the bands' tv / tv2 / prob sums of this iteration
+                part = np.zeros(5)
+                hip.hipMemcpy(part.ctypes.data, info.log_local, 40, 2)
+                sums[it] += part
             nbytes = infos[0].halo_floats * 4
             for i in range(nb - 1):
                 for c in range(nch):
@@ -66,6 +73,10 @@ for cs in cases(seed, n):
     finally:
         for s in bands:
             s.close()
+    rows = j.log_rows_from_sums(nch, cs.weight, cs.pweights, sums)
+    if its and not np.allclose(rows, ref_rows, rtol=1e-9, atol=1e-12):
+        same = False
+        print("      log rows differ:", rows[:2], ref_rows[:2])
     bad += not same
     print(("ok   " if same else "DIFF ") + cs.describe() + f"  bands {edges} its {its}", flush=True)
 print(f"{ran - bad}/{ran} band splits bit-identical to the whole canvas")
