@@ -94,6 +94,8 @@ def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("J2P_BENCH_ONE_DEVICE"):      # debugging on a 1-GPU box: every rank on the same device
+        local_rank = int(os.environ["J2P_BENCH_ONE_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     n_gpus = a.gpus
     if world != n_gpus:
