@@ -60,3 +60,40 @@ def case(seed, index):
     for c in cases(seed, index + 1):
         pass
     return c
+
+
+def cases_wide(seed, n):
+    """a second stream with wider ranges: sizes to ~3000, continuous weights, qualities 1..100, up to 120
+    iterations, quantisation tables scaled into the 16-bit range (below 32768), sparse data"""
+    rng = np.random.default_rng([seed, 0xA11CE])
+    for i in range(n):
+        sub = str(rng.choice(["444", "420", "422", "440", "411", "410"]))
+        big = rng.random() < 0.15
+        W = int(rng.integers(8, 3000 if big else 700))
+        H = int(rng.integers(8, 2200 if big else 500))
+        q = int(rng.integers(1, 101))
+        y_only = bool(rng.random() < 0.3)
+        its = int(rng.integers(1, 30 if big else 120))
+        weight = float(rng.choice([0.0, float(rng.uniform(0, 2))]))
+        pseed = int(rng.integers(1 << 30))
+        flat = bool(rng.random() < 0.3)
+        pws = [float(rng.choice([0.0, float(10 ** rng.uniform(-5, -1))])) for _ in range(1 if y_only else 3)]
+        log = bool(rng.random() < 0.3)
+        c = SweepCase(i, W, H, sub, q, y_only, its, weight, pseed, flat, pws, log)
+        c.qscale = int(rng.choice([1, 1, 1, 7, 100]))          # 16-bit-precision tables
+        c.sparsify = bool(rng.random() < 0.2)                  # keep only DC and a few AC coefficients
+        yield c
+
+
+def planes_wide(cs):
+    planes = cs.planes()
+    rng = np.random.default_rng(cs.plane_seed)
+    for p in planes:
+        if getattr(cs, "qscale", 1) != 1:
+            p.quant_table = np.minimum(p.quant_table.astype(np.int64) * cs.qscale, 30000).astype(np.uint16)
+        if getattr(cs, "sparsify", False):
+            d = p.data.reshape(-1, 64)
+            keep = rng.random(64) < 0.15
+            keep[0] = True
+            d[:, ~keep] = 0
+    return planes

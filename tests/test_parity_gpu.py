@@ -626,3 +626,22 @@ def test_the_bench_workload_itself_is_bit_identical(lib, oracle):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "headline_parity.py")], cwd=ROOT,
                        capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and "bit-identical True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_wide_randomised_sweep_against_the_compiled_reference(lib, oracle):
+    """30 cases of the second stream (tests/sweep_cases.py: cases_wide): continuous weights, every quality,
+    quantisation tables scaled into the 16-bit range, sparse coefficient data, up to 120 iterations
+    (tools/sweep_wide.py: 1000 cases of seeds 1-3 pass)"""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    import jpeg2png_amd as j
+    from sweep_cases import cases_wide, planes_wide
+    for cs in cases_wide(5, 30):
+        planes = planes_wide(cs)
+        for p in planes:
+            p.fdata = j.decode_plane(p)
+        want, _, _ = oracle.ref_compute(planes, cs.weight, cs.pweights, cs.iterations)
+        got = copy.deepcopy(planes)
+        j.compute(got, cs.weight, cs.pweights, cs.iterations)
+        for c in range(len(planes)):
+            assert bit_equal(got[c].fdata, want[c]), f"wide sweep case {cs.describe()} channel {c}"
