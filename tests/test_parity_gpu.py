@@ -645,3 +645,17 @@ def test_wide_randomised_sweep_against_the_compiled_reference(lib, oracle):
         j.compute(got, cs.weight, cs.pweights, cs.iterations)
         for c in range(len(planes)):
             assert bit_equal(got[c].fdata, want[c]), f"wide sweep case {cs.describe()} channel {c}"
+
+
+@pytest.mark.parametrize("inwave", ["0", "1"])
+def test_two_channel_joint_against_the_compiled_reference(lib, oracle, inwave):
+    """nchannel == 2 (compute.c:118 allows 1..3; the CLI only uses 1 and 3): every pair of components of the
+    sweep stream's colour cases, both schedules of the joint gradient kernel"""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    import subprocess
+    import sys
+    env = dict(os.environ, J2P_JOINT_INWAVE=inwave)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "two_channel.py")], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
