@@ -137,3 +137,14 @@ def test_randomised_cli_sweep(cli):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_cli.py"), "16", "4"], cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_default_and_long_iteration_counts(cli):
+    """tools/cli_long.py: no -i (the default 50), more iterations than one 32-iteration host chunk, per-component
+    counts in -s mode, with and without the CSV log — PNG bytes and CSV values against the reference program"""
+    if not os.path.exists(REF_CLI):
+        pytest.skip("oracle/_ref/jpeg2png_ref not built (needs /root/reference)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_long.py")], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
