@@ -324,6 +324,10 @@ constexpr int kStripCols = 124;   // output columns per wavefront strip
 #ifndef J2P_RING
 #define J2P_RING 4
 #endif
+#ifndef J2P_RING_TURNS
+#define J2P_RING_TURNS 1
+#endif
+constexpr int kRingTurns = J2P_RING_TURNS;   // ring turns unrolled into one loop iteration
 constexpr int kRing = J2P_RING;   // row slots = hand-unroll factor of the marching loop (1 channel; 3 otherwise: registers);
                                   // rows are fetched (slots - 1) trips ahead
 
@@ -383,7 +387,7 @@ __device__ __forceinline__ void div_n(const v2f (&x)[N], v2f d, v2f r, v2f (&q)[
 // Source terms of one image row for a lane's column pair.  gx,gy: forward differences of
 // this row, gxp,gyp: of the row above.  m_hx / m_hy zero the second differences on the first
 // column / first row (compute.c:137-143).  tv / tv2 receive the log sums when `log_row`.
-template <int NCH, bool TGV, bool LOG, bool FAST>
+template <int NCH, bool TGV, bool LOG, bool FAST, bool MASKED = true>
 __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&gy)[NCH], const v2f (&gxp)[NCH],
                                              const v2f (&gyp)[NCH], v2f m_hx, v2f m_hy, float a_tv, float a_tgv,
                                              bool log_row, double &tv, double &tv2, SourceTerms<NCH, TGV> &s)
@@ -422,10 +426,12 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
                 v2f xx[NCH], sy[NCH], yy[NCH];
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
-                        xx[c] = (gx[c] - left_of(gx[c])) * m_hx;
-                        const v2f gyx = (gy[c] - left_of(gy[c])) * m_hx;
-                        const v2f gxy = (gx[c] - gxp[c]) * m_hy;
-                        yy[c] = (gy[c] - gyp[c]) * m_hy;
+                        // MASKED == false: the caller knows every mask is 1 here (v * 1.f is v, so dropping
+                        // the products changes no bit)
+                        xx[c] = MASKED ? (gx[c] - left_of(gx[c])) * m_hx : gx[c] - left_of(gx[c]);
+                        const v2f gyx = MASKED ? (gy[c] - left_of(gy[c])) * m_hx : gy[c] - left_of(gy[c]);
+                        const v2f gxy = MASKED ? (gx[c] - gxp[c]) * m_hy : gx[c] - gxp[c];
+                        yy[c] = MASKED ? (gy[c] - gyp[c]) * m_hy : gy[c] - gyp[c];
                         sy[c] = (gxy + gyx) * 0.5f;                     // (g_xy + g_yx) / 2.
                         n2 += xx[c] * xx[c] + 2.f * (sy[c] * sy[c]) + yy[c] * yy[c];
                 }
@@ -464,17 +470,17 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
 // ((((0 + gx0^2) + gy0^2) + gx1^2) + ... ; per-channel Hessian terms likewise), so all of them
 // hold bit-identical norms and the rest of the work stays private to the channel.
 // `xchg` is a double-buffered LDS area: [2][J][64 lanes][3] float2.
-template <int J, bool TGV, bool LOG, bool FAST>
+template <int J, bool TGV, bool LOG, bool FAST, bool MASKED = true>
 __device__ __forceinline__ void source_terms_joint(int cidx, int lane, int parity, v2f *xchg, v2f gx, v2f gy, v2f gxp, v2f gyp,
                                                    v2f m_hx, v2f m_hy, float a_tv, float a_tgv, bool log_row, double &tv,
                                                    double &tv2, SourceTerms<1, TGV> &s)
 {
         v2f xx = v2f{0.f, 0.f}, sy = xx, yy = xx, tq = xx;
         if(TGV) {
-                xx = (gx - left_of(gx)) * m_hx;
-                const v2f gyx = (gy - left_of(gy)) * m_hx;
-                const v2f gxy = (gx - gxp) * m_hy;
-                yy = (gy - gyp) * m_hy;
+                xx = MASKED ? (gx - left_of(gx)) * m_hx : gx - left_of(gx);
+                const v2f gyx = MASKED ? (gy - left_of(gy)) * m_hx : gy - left_of(gy);
+                const v2f gxy = MASKED ? (gx - gxp) * m_hy : gx - gxp;
+                yy = MASKED ? (gy - gyp) * m_hy : gy - gyp;
                 sy = (gxy + gyx) * 0.5f;
                 tq = xx * xx + 2.f * (sy * sy) + yy * yy;
         }
@@ -586,10 +592,13 @@ void k_gradient(GradArgs a)
         const unsigned xoff = (unsigned)xl_c * 4u;             // byte offset of the lane's column pair within a row
         const int lr_lo = -(row0 < (int)kHalo ? row0 : (int)kHalo);                      // first readable band-local row
         const int lr_hi = rows - 1 + (H - row0 - rows < (int)kHalo ? H - row0 - rows : (int)kHalo);
-        auto fetch_row = [&](int lr, v2f (&rc)[NCH], v2f (&rp)[NCH]) {
+        // FREE (a std::bool_constant, see `march` below): the strip is known to lie inside the image and the
+        // band with room to spare, so the row clamps and every 0/1 mask are the identity and are left out
+        auto fetch_row = [&](auto free_tag, int lr, v2f (&rc)[NCH], v2f (&rp)[NCH]) {
+                constexpr bool FREE = decltype(free_tag)::value;
                 // rows past the strip's last needed row (t1+1) re-read that row: a cache hit, not HBM traffic
                 const int lm = lr > t1 + 1 ? t1 + 1 : lr;
-                const int lc = lm < lr_lo ? lr_lo : (lm > lr_hi ? lr_hi : lm);
+                const int lc = FREE ? lm : (lm < lr_lo ? lr_lo : (lm > lr_hi ? lr_hi : lm));
                 // uniform row pointer + loop-invariant 32-bit lane offset: scalar-base addressing, no
                 // 64-bit vector address arithmetic per row
                 const ptrdiff_t roff = (ptrdiff_t)lc * W;
@@ -599,25 +608,28 @@ void k_gradient(GradArgs a)
                         rp[c] = *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(a.ch[cbase + c].xprev + roff) + xoff);
                 }
         };
-        auto make_y = [&](int lr, const v2f (&rc)[NCH], const v2f (&rp)[NCH], v2f (&y)[NCH], unsigned &suspect) {
+        auto make_y = [&](auto free_tag, int lr, const v2f (&rc)[NCH], const v2f (&rp)[NCH], v2f (&y)[NCH], unsigned &suspect) {
+                constexpr bool FREE = decltype(free_tag)::value;
                 const int gr = row0 + lr;
                 const float m = gr >= 0 && gr < H ? in_f : 0.f;   // 0 outside the image
                 bool sus = false;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
-                        y[c] = (rc[c] + a.factor * (rc[c] - rp[c])) * m;
+                        const v2f yy = rc[c] + a.factor * (rc[c] - rp[c]);   // compute.c:435
+                        y[c] = FREE ? yy : yy * m;
                         sus |= y_suspect(y[c]);
                 }
                 // wave-uniform, and a 32-bit value rather than a bool so that it is carried round the loop in a scalar register
                 suspect = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(sus) != 0 ? 1u : 0u);
         };
         // forward differences of row gr given rows gr and gr+1 (compute.c:79,81)
-        auto diffs = [&](int gr, const v2f (&yc)[NCH], const v2f (&yn)[NCH], v2f (&gx)[NCH], v2f (&gy)[NCH]) {
+        auto diffs = [&](auto free_tag, int gr, const v2f (&yc)[NCH], const v2f (&yn)[NCH], v2f (&gx)[NCH], v2f (&gy)[NCH]) {
+                constexpr bool FREE = decltype(free_tag)::value;
                 const float m_gy = gr >= 0 && gr < H - 1 ? 1.f : 0.f;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
-                        gx[c] = (right_of(yc[c]) - yc[c]) * m_gx;
-                        gy[c] = (yn[c] - yc[c]) * m_gy;
+                        gx[c] = FREE ? right_of(yc[c]) - yc[c] : (right_of(yc[c]) - yc[c]) * m_gx;
+                        gy[c] = FREE ? yn[c] - yc[c] : (yn[c] - yc[c]) * m_gy;
                 }
         };
 
@@ -637,143 +649,182 @@ void k_gradient(GradArgs a)
                 p_col[c][0] = (int)(c0 > cmax ? cmax : c0) * 4;   // byte offsets within a coefficient row
                 p_col[c][1] = (int)(c1 > cmax ? cmax : c1) * 4;
         }
-        auto load_p = [&](int lt, v2f (&pv)[NCH]) {
+        auto load_p = [&](auto free_tag, int lt, v2f (&pv)[NCH]) {
+                constexpr bool FREE = decltype(free_tag)::value;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
                         const ChanDev &k = a.ch[cbase + c];
                         // coefficient row of canvas row lt, clamped into the rows this band holds
-                        const int gt = row0 + (lt < 0 ? 0 : (lt > t1 - 1 ? t1 - 1 : lt));   // past the strip: re-read its last row
-                        unsigned cr = (unsigned)gt / k.hs;
-                        const unsigned cr_hi = k.crow0 + (k.crows ? k.crows - 1 : 0);
-                        cr = cr < k.crow0 ? k.crow0 : (cr > cr_hi ? cr_hi : cr);
+                        const int ltc = lt > t1 - 1 ? t1 - 1 : lt;                     // past the strip: re-read its last row
+                        const int gt = row0 + (FREE ? ltc : (ltc < 0 ? 0 : ltc));
+                        unsigned cr;
+                        if(k.hs == 1) { cr = (unsigned)gt; }                            // (uniform branch: skips the scalar division)
+                        else { cr = (unsigned)gt / k.hs; }
+                        if(!FREE) {
+                                const unsigned cr_hi = k.crow0 + (k.crows ? k.crows - 1 : 0);
+                                cr = cr < k.crow0 ? k.crow0 : (cr > cr_hi ? cr_hi : cr);
+                        }
                         const float *prow = k.pg + (size_t)(cr - k.crow0) * k.cw;
                         pv[c] = v2f{*reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][0]),
                                     *reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][1])};   // two dword loads whatever the sampling: no branch
                 }
         };
 
-        // rings of kRing row slots, slot = (row - (t0-1)) mod kRing = phase of the trip that owns the row
-        constexpr int R = NCH == 1 ? kRing : 3;
-        v2f RC[R][NCH], RP[R][NCH], Y[R][NCH], GX[R][NCH], GY[R][NCH], PV[R][NCH];
-        unsigned bad[R];
-        SourceTerms<NCH, TGV> S[R];
-        {
-                // rows t0-2, t0-1, t0 are needed at once; rows up to t0+R-2 are put in flight
-                v2f mc[NCH], mp[NCH], ym[NCH];
-                unsigned bm;
-                fetch_row(t0 - 2, mc, mp);
-                fetch_row(t0 - 1, RC[0], RP[0]);
-#pragma unroll
-                for(int i = 1; i <= R - 1; i++) { fetch_row(t0 - 1 + i, RC[i], RP[i]); }
-#pragma unroll
-                for(int i = 1; i <= R - 3; i++) { load_p(t0 - 1 + i, PV[i]); }
-                make_y(t0 - 2, mc, mp, ym, bm);
-                make_y(t0 - 1, RC[0], RP[0], Y[0], bad[0]);
-                bad[R - 1] = bm;                               // slot of row t0-2
-                diffs(row0 + t0 - 2, ym, Y[0], GX[R - 1], GY[R - 1]);
-        }
-        double g2[NCH];
-#pragma unroll
-        for(int c = 0; c < NCH; c++) { g2[c] = 0.; }
         double tv_acc = 0., tv2_acc = 0.;
         const size_t ntiles_row = a.geo.ntx;
         const size_t nparts = (size_t)((rows + kTY - 1) / kTY) * ntiles_row;
+        constexpr int R = NCH == 1 ? kRing : 3;
 
-        // one trip: source terms of row r into slot P, then target row r-1
-        auto trip = [&](auto phase, int r) {
-                constexpr int P = decltype(phase)::value, P1 = (P + 1) % R, PM1 = (P + R - 1) % R, PM2 = (P + R - 2) % R;
-                const int gr = row0 + r;
-                // put row r+R in flight (its slot held row r, whose raw values became y last trip), and the
-                // prob state of target row r+R-2; then finish row r+1, fetched R-1 trips ago
-                fetch_row(r + R, RC[P], RP[P]);
-                load_p(r + R - 2, PV[PM2]);
-                make_y(r + 1, RC[P1], RP[P1], Y[P1], bad[P1]);
-                const unsigned prev_bad = bad[PM1];
-                SourceTerms<NCH, TGV> &s = S[P];
-                diffs(gr, Y[P], Y[P1], GX[P], GY[P]);
+        // The march over the strip's rows, compiled twice: once general, once for strips that touch neither an
+        // image edge, a band edge nor a channel's coverage limit (all but the outermost strips and segments).
+        // In the second form the clamps, compares and multiplications by 1.f disappear — about a seventh of the
+        // instructions of a trip, most of them scalar — and nothing else changes, so the bits are the same.
+        auto march = [&](auto free_tag) {
+                constexpr bool FREE = decltype(free_tag)::value;
+                // rings of kRing row slots, slot = (row - (t0-1)) mod kRing = phase of the trip that owns the row
+                v2f RC[R][NCH], RP[R][NCH], Y[R][NCH], GX[R][NCH], GY[R][NCH], PV[R][NCH];
+                unsigned bad[R];
+                SourceTerms<NCH, TGV> S[R];
                 {
-                        // A row above or below the image needs no special case: its y is 0, m_gy zeroes
-                        // its gy, and hy = 0 zeroes its gxy/gyy, so every term comes out 0.
-                        const bool log_row = LOG && pair_own && r >= t0 && r < t1 && cbase == 0;
-                        const float hy = gr <= 0 || gr >= H ? 0.f : in_f;  // gxy, gyy = 0 on the first row (compute.c:141-143)
-                        const v2f m_hy = v2f{hy, hy};
-                        if(J > 1) {
-                                const int parity = (r - t0 + 1) & 1;
-                                if((prev_bad | bad[P] | bad[P1]) == 0) {
-                                        source_terms_joint<J, TGV, LOG, true>(cbase, lane, parity, xchg, GX[P][0], GY[P][0], GX[PM1][0],
-                                                                              GY[PM1][0], m_hx, m_hy, a.a_tv, a.a_tgv, log_row,
-                                                                              tv_acc, tv2_acc, reinterpret_cast<SourceTerms<1, TGV> &>(s));
-                                } else {
-                                        source_terms_joint<J, TGV, LOG, false>(cbase, lane, parity, xchg, GX[P][0], GY[P][0], GX[PM1][0],
-                                                                               GY[PM1][0], m_hx, m_hy, a.a_tv, a.a_tgv, log_row,
-                                                                               tv_acc, tv2_acc, reinterpret_cast<SourceTerms<1, TGV> &>(s));
-                                }
-                        } else if((prev_bad | bad[P] | bad[P1]) == 0) {
-                                source_terms<NCH, TGV, LOG, true>(GX[P], GY[P], GX[PM1], GY[PM1], m_hx, m_hy, a.a_tv, a.a_tgv,
-                                                                  log_row, tv_acc, tv2_acc, s);
-                        } else {
-                                source_terms<NCH, TGV, LOG, false>(GX[P], GY[P], GX[PM1], GY[PM1], m_hx, m_hy, a.a_tv, a.a_tgv,
-                                                                   log_row, tv_acc, tv2_acc, s);
-                        }
+                        // rows t0-2, t0-1, t0 are needed at once; rows up to t0+R-2 are put in flight
+                        v2f mc[NCH], mp[NCH], ym[NCH];
+                        unsigned bm;
+                        fetch_row(free_tag, t0 - 2, mc, mp);
+                        fetch_row(free_tag, t0 - 1, RC[0], RP[0]);
+        #pragma unroll
+                        for(int i = 1; i <= R - 1; i++) { fetch_row(free_tag, t0 - 1 + i, RC[i], RP[i]); }
+        #pragma unroll
+                        for(int i = 1; i <= R - 3; i++) { load_p(free_tag, t0 - 1 + i, PV[i]); }
+                        make_y(free_tag, t0 - 2, mc, mp, ym, bm);
+                        make_y(free_tag, t0 - 1, RC[0], RP[0], Y[0], bad[0]);
+                        bad[R - 1] = bm;                               // slot of row t0-2
+                        diffs(free_tag, row0 + t0 - 2, ym, Y[0], GX[R - 1], GY[R - 1]);
                 }
-                // ---- target row t = r-1: rows t-1, t, t+1 live in slots PM2, PM1, P ----
-                const int t = r - 1;
-                if(t >= t0) {
-                        const SourceTerms<NCH, TGV> &up = S[PM2], &mid = S[PM1];
-                        const int gt = row0 + t;
-#pragma unroll
-                        for(int c = 0; c < NCH; c++) {
-                                const ChanDev &k = a.ch[cbase + c];
-                                v2f g = v2f{0.f, 0.f};
-                                if((unsigned)gt < k.ch * k.hs) { g += p_scale[c] * PV[PM1][c]; }   // row t, fetched R-1 trips ago
-                                g += up.tvy[c];                  // TV from (x, t-1)
-                                g += mid.tvxL[c];                // TV from (x-1, t)
-                                g += mid.tvo[c];                 // TV own
-                                if(TGV) {
-                                        g += up.B[c];            // (x,   t-1)
-                                        g += up.CR[c];           // (x+1, t-1)
-                                        g += left_of(mid.A[c]);  // (x-1, t)
-                                        g += mid.O[c];           // own
-                                        g += right_of(mid.A[c]); // (x+1, t)
-                                        g += s.CL[c];            // (x-1, t+1)
-                                        g += s.B[c];             // (x,   t+1)
-                                }
-                                if(pair_own) {
-                                        *reinterpret_cast<v2f *>(reinterpret_cast<char *>(k.grad + (size_t)t * W) + (unsigned)xl * 4u) = g;
-                                        const v2f sq = g * g;
-                                        g2[c] += (double)sq.x;   // compute.c:203
-                                        g2[c] += (double)sq.y;
+                double g2[NCH];
+        #pragma unroll
+                for(int c = 0; c < NCH; c++) { g2[c] = 0.; }
+
+                // one trip: source terms of row r into slot P, then target row r-1
+                auto trip = [&](auto phase, int r) {
+                        constexpr int P = decltype(phase)::value, P1 = (P + 1) % R, PM1 = (P + R - 1) % R, PM2 = (P + R - 2) % R;
+                        const int gr = row0 + r;
+                        // put row r+R in flight (its slot held row r, whose raw values became y last trip), and the
+                        // prob state of target row r+R-2; then finish row r+1, fetched R-1 trips ago
+                        fetch_row(free_tag, r + R, RC[P], RP[P]);
+                        load_p(free_tag, r + R - 2, PV[PM2]);
+                        make_y(free_tag, r + 1, RC[P1], RP[P1], Y[P1], bad[P1]);
+                        const unsigned prev_bad = bad[PM1];
+                        SourceTerms<NCH, TGV> &s = S[P];
+                        diffs(free_tag, gr, Y[P], Y[P1], GX[P], GY[P]);
+                        {
+                                // A row above or below the image needs no special case: its y is 0, m_gy zeroes
+                                // its gy, and hy = 0 zeroes its gxy/gyy, so every term comes out 0.
+                                const bool log_row = LOG && pair_own && r >= t0 && r < t1 && cbase == 0;
+                                const float hy = gr <= 0 || gr >= H ? 0.f : in_f;  // gxy, gyy = 0 on the first row (compute.c:141-143)
+                                const v2f m_hy = v2f{hy, hy};
+                                if(J > 1) {
+                                        const int parity = (r - t0 + 1) & 1;
+                                        if((prev_bad | bad[P] | bad[P1]) == 0) {
+                                                source_terms_joint<J, TGV, LOG, true, !FREE>(cbase, lane, parity, xchg, GX[P][0], GY[P][0], GX[PM1][0],
+                                                                                      GY[PM1][0], m_hx, m_hy, a.a_tv, a.a_tgv, log_row,
+                                                                                      tv_acc, tv2_acc, reinterpret_cast<SourceTerms<1, TGV> &>(s));
+                                        } else {
+                                                source_terms_joint<J, TGV, LOG, false, !FREE>(cbase, lane, parity, xchg, GX[P][0], GY[P][0], GX[PM1][0],
+                                                                                       GY[PM1][0], m_hx, m_hy, a.a_tv, a.a_tgv, log_row,
+                                                                                       tv_acc, tv2_acc, reinterpret_cast<SourceTerms<1, TGV> &>(s));
+                                        }
+                                } else if((prev_bad | bad[P] | bad[P1]) == 0) {
+                                        source_terms<NCH, TGV, LOG, true, !FREE>(GX[P], GY[P], GX[PM1], GY[PM1], m_hx, m_hy, a.a_tv, a.a_tgv,
+                                                                          log_row, tv_acc, tv2_acc, s);
+                                } else {
+                                        source_terms<NCH, TGV, LOG, false, !FREE>(GX[P], GY[P], GX[PM1], GY[PM1], m_hx, m_hy, a.a_tv, a.a_tgv,
+                                                                           log_row, tv_acc, tv2_acc, s);
                                 }
                         }
-                        // one partial per 16-row tile row and strip: the granularity of the GPU-count
-                        // invariant norm reduction
-                        if((t & (kTY - 1)) == kTY - 1 || t == t1 - 1) {
-#pragma unroll
+                        // ---- target row t = r-1: rows t-1, t, t+1 live in slots PM2, PM1, P ----
+                        const int t = r - 1;
+                        if(t >= t0) {
+                                const SourceTerms<NCH, TGV> &up = S[PM2], &mid = S[PM1];
+                                const int gt = row0 + t;
+        #pragma unroll
                                 for(int c = 0; c < NCH; c++) {
-                                        double v = g2[c];
-#pragma unroll
-                                        for(int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); }
-                                        if(lane == 0) { a.part_g2[(cbase + c) * nparts + (size_t)(t / kTY) * ntiles_row + wcol] = v; }
-                                        g2[c] = 0.;
+                                        const ChanDev &k = a.ch[cbase + c];
+                                        v2f g = v2f{0.f, 0.f};
+                                        if(FREE || (unsigned)gt < k.ch * k.hs) { g += p_scale[c] * PV[PM1][c]; }   // row t, fetched R-1 trips ago
+                                        g += up.tvy[c];                  // TV from (x, t-1)
+                                        g += mid.tvxL[c];                // TV from (x-1, t)
+                                        g += mid.tvo[c];                 // TV own
+                                        if(TGV) {
+                                                g += up.B[c];            // (x,   t-1)
+                                                g += up.CR[c];           // (x+1, t-1)
+                                                g += left_of(mid.A[c]);  // (x-1, t)
+                                                g += mid.O[c];           // own
+                                                g += right_of(mid.A[c]); // (x+1, t)
+                                                g += s.CL[c];            // (x-1, t+1)
+                                                g += s.B[c];             // (x,   t+1)
+                                        }
+                                        if(pair_own) {
+                                                *reinterpret_cast<v2f *>(reinterpret_cast<char *>(k.grad + (size_t)t * W) + (unsigned)xl * 4u) = g;
+                                                const v2f sq = g * g;
+                                                g2[c] += (double)sq.x;   // compute.c:203
+                                                g2[c] += (double)sq.y;
+                                        }
+                                }
+                                // one partial per 16-row tile row and strip: the granularity of the GPU-count
+                                // invariant norm reduction
+                                if((t & (kTY - 1)) == kTY - 1 || t == t1 - 1) {
+        #pragma unroll
+                                        for(int c = 0; c < NCH; c++) {
+                                                double v = g2[c];
+        #pragma unroll
+                                                for(int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); }
+                                                if(lane == 0) { a.part_g2[(cbase + c) * nparts + (size_t)(t / kTY) * ntiles_row + wcol] = v; }
+                                                g2[c] = 0.;
+                                        }
                                 }
                         }
+                };
+
+                // one turn of the ring = R trips; returns false once the last row (t1) has been done
+                auto ring = [&](int r) -> bool {
+                        trip(std::integral_constant<int, 0>{}, r);
+                        if(r + 1 > t1) { return false; }
+                        trip(std::integral_constant<int, 1>{}, r + 1);
+                        if(r + 2 > t1) { return false; }
+                        trip(std::integral_constant<int, 2>{}, r + 2);
+                        if(R > 3) {
+                                if(r + 3 > t1) { return false; }
+                                trip(std::integral_constant<int, 3 % R>{}, r + 3);
+                        }
+                        if(R > 4) {
+                                if(r + 4 > t1) { return false; }
+                                trip(std::integral_constant<int, 4 % R>{}, r + 4);
+                        }
+                        return r + R <= t1;
+                };
+                // kRingTurns turns per loop iteration: the compiler drains every outstanding load at the loop
+                // header (s_waitcnt vmcnt(0)), so the fewer headers a strip passes, the fewer times its prefetched
+                // rows have to land all at once
+                for(int r = t0 - 1; r <= t1; r += R * kRingTurns) {
+                        bool more = true;
+        #pragma unroll
+                        for(int u = 0; u < kRingTurns; u++) {
+                                if(more) { more = ring(r + u * R); }
+                        }
+                        if(!more) { break; }
                 }
         };
-
-        for(int r = t0 - 1; r <= t1; r += R) {
-                trip(std::integral_constant<int, 0>{}, r);
-                if(r + 1 > t1) { break; }
-                trip(std::integral_constant<int, 1>{}, r + 1);
-                if(r + 2 > t1) { break; }
-                trip(std::integral_constant<int, 2>{}, r + 2);
-                if(R > 3) {
-                        if(r + 3 > t1) { break; }
-                        trip(std::integral_constant<int, 3 % R>{}, r + 3);
+        {
+                bool seg_free = wcol > 0 && wcol * kStripCols + 128 <= W - 1 &&          // no lane on the first / last column
+                                row0 + t0 - 2 >= 0 && row0 + t1 + 1 < H &&                // rows t0-2 .. t1+1 inside the image
+                                t0 - 2 >= lr_lo && t1 + 1 <= lr_hi;                       // ... and readable in this band
+#pragma unroll
+                for(int c = 0; c < NCH; c++) {
+                        const ChanDev &k = a.ch[cbase + c];
+                        seg_free = seg_free && (unsigned)(row0 + t1) <= k.ch * k.hs;      // every target row is covered by the channel
                 }
-                if(R > 4) {
-                        if(r + 4 > t1) { break; }
-                        trip(std::integral_constant<int, 4 % R>{}, r + 4);
-                }
+                if(__builtin_amdgcn_readfirstlane(seg_free ? 1 : 0)) { march(std::true_type{}); }
+                else { march(std::false_type{}); }
         }
         if(LOG) {
 #pragma unroll
