@@ -240,13 +240,15 @@ __device__ __forceinline__ double block_sum(double v, double *red /* >= 4 double
 // ---------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// wave_shr:1 / wave_shl:1 with bound_ctrl: the lane without a source reads 0, and because no "old" value
+// has to be supplied the compiler does not spend a v_mov on initialising the destination
 __device__ __forceinline__ float lane_from_left(float v)    // value held by lane-1 (0 in lane 0)
 {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float lane_from_right(float v)   // value held by lane+1 (0 in lane 63)
 {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 // columns x-1 / x+1 of a lane's column pair
 __device__ __forceinline__ v2f left_of(v2f a) { return v2f{lane_from_left(a.y), a.x}; }
