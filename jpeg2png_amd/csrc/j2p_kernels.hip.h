@@ -299,9 +299,6 @@ __device__ __forceinline__ bool in_fast_range(float v, float lo, float hi)
 }
 __device__ __forceinline__ bool y_suspect(v2f y)
 {
-#ifdef J2P_FORCE_IEEE_GRADIENT   /* debugging aid: every row of phase A on the plain `/` + sqrtf() path */
-        return true;
-#endif
         return !(in_fast_range(y.x, 0x1p-20f, 0x1p41f) && in_fast_range(y.y, 0x1p-20f, 0x1p41f));
 }
 
@@ -614,15 +611,28 @@ void k_gradient(GradArgs a)
                 constexpr bool FREE = decltype(free_tag)::value;
                 const int gr = row0 + lr;
                 const float m = gr >= 0 && gr < H ? in_f : 0.f;   // 0 outside the image
-                bool sus = false;
+                // the operand screen of the short division / sqrt sequences (see y_suspect) for the whole row at
+                // once, on the bit patterns: hi = largest |y|, lo = smallest NON-ZERO |y| minus one ulp (0 - 1
+                // wraps to the top, so zeros drop out of the minimum).  Two compares per row, each feeding a
+                // ballot directly, so the flag is born in scalar registers.
+                unsigned hi = 0u, lo = ~0u;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
                         const v2f yy = rc[c] + a.factor * (rc[c] - rp[c]);   // compute.c:435
                         y[c] = FREE ? yy : yy * m;
-                        sus |= y_suspect(y[c]);
+                        // (bit-cast the VECTOR: hipcc 7.2 turns element-wise casts of .x and .y into two reads of .x)
+                        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                        const v2u u = __builtin_bit_cast(v2u, y[c]) & 0x7fffffffu;
+                        const v2u um = u - 1u;
+                        hi = max(hi, max(u.x, u.y));
+                        lo = min(lo, min(um.x, um.y));
                 }
-                // wave-uniform, and a 32-bit value rather than a bool so that it is carried round the loop in a scalar register
-                suspect = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(sus) != 0 ? 1u : 0u);
+                constexpr unsigned kLo = 0x35800000u, kHi = 0x54000000u;      // bits of 2^-20 and 2^41
+                const unsigned long long out_of_range = __builtin_amdgcn_ballot_w64(hi >= kHi) | __builtin_amdgcn_ballot_w64(lo < kLo - 1u);
+                suspect = (unsigned)out_of_range | (unsigned)(out_of_range >> 32);   // wave-uniform, non-zero = suspect
+#ifdef J2P_FORCE_IEEE_GRADIENT   /* debugging aid: every row of phase A on the plain `/` + sqrtf() path */
+                suspect = 1u;
+#endif
         };
         // forward differences of row gr given rows gr and gr+1 (compute.c:79,81)
         auto diffs = [&](auto free_tag, int gr, const v2f (&yc)[NCH], const v2f (&yn)[NCH], v2f (&gx)[NCH], v2f (&gy)[NCH]) {
@@ -685,7 +695,7 @@ void k_gradient(GradArgs a)
                 constexpr bool FREE = decltype(free_tag)::value;
                 // rings of kRing row slots, slot = (row - (t0-1)) mod kRing = phase of the trip that owns the row
                 v2f RC[R][NCH], RP[R][NCH], Y[R][NCH], GX[R][NCH], GY[R][NCH], PV[R][NCH];
-                unsigned bad[R];
+                unsigned bad1, bad2;   // screen results (non-zero = suspect) of the last two rows made; plain scalars
                 SourceTerms<NCH, TGV> S[R];
                 {
                         // rows t0-2, t0-1, t0 are needed at once; rows up to t0+R-2 are put in flight
@@ -697,9 +707,11 @@ void k_gradient(GradArgs a)
                         for(int i = 1; i <= R - 1; i++) { fetch_row(free_tag, t0 - 1 + i, RC[i], RP[i]); }
         #pragma unroll
                         for(int i = 1; i <= R - 3; i++) { load_p(free_tag, t0 - 1 + i, PV[i]); }
+                        unsigned b0;
                         make_y(free_tag, t0 - 2, mc, mp, ym, bm);
-                        make_y(free_tag, t0 - 1, RC[0], RP[0], Y[0], bad[0]);
-                        bad[R - 1] = bm;                               // slot of row t0-2
+                        make_y(free_tag, t0 - 1, RC[0], RP[0], Y[0], b0);
+                        bad2 = bm;
+                        bad1 = b0;
                         diffs(free_tag, row0 + t0 - 2, ym, Y[0], GX[R - 1], GY[R - 1]);
                 }
                 double g2[NCH];
@@ -714,8 +726,11 @@ void k_gradient(GradArgs a)
                         // prob state of target row r+R-2; then finish row r+1, fetched R-1 trips ago
                         fetch_row(free_tag, r + R, RC[P], RP[P]);
                         load_p(free_tag, r + R - 2, PV[PM2]);
-                        make_y(free_tag, r + 1, RC[P1], RP[P1], Y[P1], bad[P1]);
-                        const unsigned prev_bad = bad[PM1];
+                        unsigned bnew;
+                        make_y(free_tag, r + 1, RC[P1], RP[P1], Y[P1], bnew);
+                        const unsigned badmask = bad2 | bad1 | bnew;        // rows r-1, r, r+1
+                        bad2 = bad1;
+                        bad1 = bnew;
                         SourceTerms<NCH, TGV> &s = S[P];
                         diffs(free_tag, gr, Y[P], Y[P1], GX[P], GY[P]);
                         {
@@ -726,7 +741,7 @@ void k_gradient(GradArgs a)
                                 const v2f m_hy = v2f{hy, hy};
                                 if(J > 1) {
                                         const int parity = (r - t0 + 1) & 1;
-                                        if((prev_bad | bad[P] | bad[P1]) == 0) {
+                                        if(badmask == 0) {
                                                 source_terms_joint<J, TGV, LOG, true, !FREE>(cbase, lane, parity, xchg, GX[P][0], GY[P][0], GX[PM1][0],
                                                                                       GY[PM1][0], m_hx, m_hy, a.a_tv, a.a_tgv, log_row,
                                                                                       tv_acc, tv2_acc, reinterpret_cast<SourceTerms<1, TGV> &>(s));
@@ -735,7 +750,7 @@ void k_gradient(GradArgs a)
                                                                                        GY[PM1][0], m_hx, m_hy, a.a_tv, a.a_tgv, log_row,
                                                                                        tv_acc, tv2_acc, reinterpret_cast<SourceTerms<1, TGV> &>(s));
                                         }
-                                } else if((prev_bad | bad[P] | bad[P1]) == 0) {
+                                } else if(badmask == 0) {
                                         source_terms<NCH, TGV, LOG, true, !FREE>(GX[P], GY[P], GX[PM1], GY[PM1], m_hx, m_hy, a.a_tv, a.a_tgv,
                                                                           log_row, tv_acc, tv2_acc, s);
                                 } else {
