@@ -447,13 +447,15 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
                 for(int c = 0; c < NCH; c++) {
                         if(NCH > 1) { __builtin_amdgcn_sched_barrier(0); }
                         // a2 * (expr / n2): division first (compute.c:165-182)
-                        const v2f num[4] = {sy[c] + xx[c], yy[c] + sy[c], -sy[c], -(2.f * xx[c] + 2.f * sy[c] + 2.f * yy[c])};
+                        // the two negative numerators are divided as positives and the sign goes onto the quotient:
+                        // (-v) / n == -(v / n) bit for bit, in the IEEE and in the short sequence alike
+                        const v2f num[4] = {sy[c] + xx[c], yy[c] + sy[c], sy[c], 2.f * xx[c] + 2.f * sy[c] + 2.f * yy[c]};
                         v2f q[4];
                         div_n<FAST, 4>(num, d2, r2, q);
                         const v2f tA = a2 * q[0];                                       // to (x-1,y), (x+1,y)
                         s.B[c] = a2 * q[1];                                             // to (x,y-1), (x,y+1)
-                        const v2f tC = a2 * q[2];                                       // to (x+1,y-1), (x-1,y+1)
-                        s.O[c] = a2 * q[3];                                             // own
+                        const v2f tC = a2 * -q[2];                                      // to (x+1,y-1), (x-1,y+1)
+                        s.O[c] = a2 * -q[3];                                            // own
                         s.A[c] = tA;
                         s.CL[c] = left_of(tC);
                         s.CR[c] = right_of(tC);
@@ -521,13 +523,13 @@ __device__ __forceinline__ void source_terms_joint(int cidx, int lane, int parit
                 const v2f d2 = divisor_of<FAST, LOG>(n2);
                 const v2f a2 = FAST ? v2f{a_tgv, a_tgv} : v2f{n2.x == 0.f ? 0.f : a_tgv, n2.y == 0.f ? 0.f : a_tgv};
                 const v2f r2 = FAST ? div_prepare(d2) : d2;
-                const v2f num[4] = {sy + xx, yy + sy, -sy, -(2.f * xx + 2.f * sy + 2.f * yy)};
+                const v2f num[4] = {sy + xx, yy + sy, sy, 2.f * xx + 2.f * sy + 2.f * yy};   // signs: see source_terms
                 v2f q[4];
                 div_n<FAST, 4>(num, d2, r2, q);
-                const v2f tC = a2 * q[2];
+                const v2f tC = a2 * -q[2];
                 s.A[0] = a2 * q[0];
                 s.B[0] = a2 * q[1];
-                s.O[0] = a2 * q[3];
+                s.O[0] = a2 * -q[3];
                 s.CL[0] = left_of(tC);
                 s.CR[0] = right_of(tC);
         }
@@ -717,6 +719,7 @@ void k_gradient(GradArgs a)
                 double g2[NCH];
         #pragma unroll
                 for(int c = 0; c < NCH; c++) { g2[c] = 0.; }
+                int next_flush = (t0 | (kTY - 1)) < t1 - 1 ? (t0 | (kTY - 1)) : t1 - 1;   // last row of the first tile row
 
                 // one trip: source terms of row r into slot P, then target row r-1
                 auto trip = [&](auto phase, int r) {
@@ -789,7 +792,7 @@ void k_gradient(GradArgs a)
                                 }
                                 // one partial per 16-row tile row and strip: the granularity of the GPU-count
                                 // invariant norm reduction
-                                if((t & (kTY - 1)) == kTY - 1 || t == t1 - 1) {
+                                if(t == next_flush) {                 // (t & 15) == 15 || t == t1 - 1, as one compare
         #pragma unroll
                                         for(int c = 0; c < NCH; c++) {
                                                 double v = g2[c];
@@ -798,6 +801,7 @@ void k_gradient(GradArgs a)
                                                 if(lane == 0) { a.part_g2[(cbase + c) * nparts + (size_t)(t / kTY) * ntiles_row + wcol] = v; }
                                                 g2[c] = 0.;
                                         }
+                                        next_flush = t + kTY < t1 - 1 ? t + kTY : t1 - 1;
                                 }
                         }
                 };
