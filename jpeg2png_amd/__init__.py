@@ -16,7 +16,8 @@ import numpy as np
 from .synth import Plane  # noqa: F401  (re-export: the Python twin of struct coef)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjpeg2png_amd.so")
+# J2P_LIBRARY selects another build of the library (A/B timing of kernel variants on one box)
+LIB_PATH = os.environ.get("J2P_LIBRARY") or os.path.join(_HERE, "libjpeg2png_amd.so")
 
 J2P_MAX_CHANNELS = 3
 J2P_HALO_ROWS = 2
