@@ -4,10 +4,12 @@
 // forces the split):
 //
 //   k_gradient : FISTA point y = x_k + factor*(x_k - x_{k-1}) formed on the fly
-//                (compute.c:433-439), staged with a 2-pixel halo in LDS, then
-//                the prob (compute.c:53-66), TV (compute.c:73-125) and TGV2
+//                (compute.c:433-439) by wavefronts that march down 128-column
+//                strips with the row neighbourhood in registers and the column
+//                neighbourhood through DPP lane shifts (no LDS), then the prob
+//                (compute.c:53-66), TV (compute.c:73-125) and TGV2
 //                (compute.c:128-197) subgradients in GATHER form, g written to
-//                HBM plus one double sum(g*g) per workgroup.
+//                HBM plus one double sum(g*g) per strip and 16-row tile row.
 //   k_project  : norm + step (compute.c:200-216) fused in front of the 8x8
 //                DCT -> clamp -> IDCT projection (compute.c:334-404); also
 //                emits the next iteration's prob gradient block
@@ -289,9 +291,10 @@ __device__ __forceinline__ void div_shared_n(const v2f (&x)[N], v2f d, v2f r, v2
 }
 
 // true when a loaded pixel is outside the range for which the fast paths are exact:
-// 0 < |y| < 2^-20, |y| >= 2^41, or NaN.  Three compares per element; flat regions whose pixels
-// are rounding noise around 0 (1e-17 in the chroma of a grey area) do occur in image data, so
-// the lower bound has to hold all the way down to the subnormals.
+// 0 < |y| < 2^-20, |y| >= 2^41, or NaN.  Flat regions whose pixels are rounding noise around 0
+// (1e-17 in the chroma of a grey area) do occur in image data, so the lower bound has to hold
+// all the way down to the subnormals.  (k_gradient applies the same test to a whole row at a
+// time on the bit patterns, see make_y; this per-value form is what it implements.)
 __device__ __forceinline__ bool in_fast_range(float v, float lo, float hi)
 {
         const float av = __builtin_fabsf(v);
