@@ -333,6 +333,15 @@ constexpr int kRingTurns = J2P_RING_TURNS;   // ring turns unrolled into one loo
 constexpr int kRing = J2P_RING;   // row slots = hand-unroll factor of the marching loop (1 channel; 3 otherwise: registers);
                                   // rows are fetched (slots - 1) trips ahead
 
+// compile-time description of a strip for k_gradient's march: `value` = it touches no image / band / coverage
+// edge (clamps and masks are the identity), `unit` = additionally every channel of the wavefront is sampled 1x1
+// and covers all of the strip's columns (the prob state of a lane's column pair is one 8-byte load)
+template <bool FREE, bool UNIT>
+struct MarchTag {
+        static constexpr bool value = FREE;
+        static constexpr bool unit = UNIT;
+};
+
 template <int NCH, bool TGV>
 struct SourceTerms {
         v2f tvxL[NCH], tvo[NCH], tvy[NCH];                        // TV: from (x-1), own, to the row below
@@ -674,6 +683,11 @@ void k_gradient(GradArgs a)
                         // coefficient row of canvas row lt, clamped into the rows this band holds
                         const int ltc = lt > t1 - 1 ? t1 - 1 : lt;                     // past the strip: re-read its last row
                         const int gt = row0 + (FREE ? ltc : (ltc < 0 ? 0 : ltc));
+                        if constexpr(decltype(free_tag)::unit) {
+                                const float *prow = k.pg + (size_t)((unsigned)gt - k.crow0) * k.cw;
+                                pv[c] = *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(prow) + xoff);
+                                continue;
+                        }
                         unsigned cr;
                         if(k.hs == 1) { cr = (unsigned)gt; }                            // (uniform branch: skips the scalar division)
                         else { cr = (unsigned)gt / k.hs; }
@@ -847,8 +861,15 @@ void k_gradient(GradArgs a)
                         const ChanDev &k = a.ch[cbase + c];
                         seg_free = seg_free && (unsigned)(row0 + t1) <= k.ch * k.hs;      // every target row is covered by the channel
                 }
-                if(__builtin_amdgcn_readfirstlane(seg_free ? 1 : 0)) { march(std::true_type{}); }
-                else { march(std::false_type{}); }
+                bool unit = seg_free;
+#pragma unroll
+                for(int c = 0; c < NCH; c++) {
+                        const ChanDev &k = a.ch[cbase + c];
+                        unit = unit && k.ws == 1 && k.hs == 1 && (unsigned)(wcol * kStripCols + 128) <= k.cw;
+                }
+                if(__builtin_amdgcn_readfirstlane(unit ? 1 : 0)) { march(MarchTag<true, true>{}); }
+                else if(__builtin_amdgcn_readfirstlane(seg_free ? 1 : 0)) { march(MarchTag<true, false>{}); }
+                else { march(MarchTag<false, false>{}); }
         }
         if(LOG) {
 #pragma unroll
