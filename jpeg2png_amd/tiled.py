@@ -18,6 +18,8 @@ torch.distributed is plumbing only (backend "nccl" = RCCL over xGMI on the GPUs,
 "gloo" in the CPU tests); the arithmetic lives behind the `engine` object.  The
 production engine is HipBandEngine (the C-ABI solver, device memory aliased as
 torch tensors); tests drive the same exchange code with a CPU engine over gloo.
+On GPUs the two exchanges go to librccl directly (jpeg2png_amd/rccl.py) on the
+solver's own streams; torch.distributed then only bootstraps the communicators.
 """
 import ctypes
 import os
@@ -178,10 +180,12 @@ class HipBandEngine:
 class RowTiledSolver:
     """Drives one band engine per rank through the iteration loop (compute.c:427-453).
 
-    overlap=True (default where the engine supports it): the halo exchange runs on its own stream
-    while the interior of the next gradient phase is already computing; only the band's first and
-    last 16-row segments wait for the neighbours' rows.  The all-gather of the norm partials stays
-    on the critical path (it is the global dependency of the algorithm)."""
+    overlap=True (default where the engine supports it): the projection does the band's first and last
+    block rows first, the halo exchange then runs on its own stream while the rest of the projection and
+    the interior of the next gradient phase compute; only the band's first and last 16-row gradient
+    segments wait for the neighbours' rows.  The all-gather of the norm partials stays on the critical
+    path (it is the global dependency of the algorithm).  log=True also gathers the bands' tv / tv2 /
+    prob sums every iteration (log_rows() returns the reference's CSV values)."""
 
     def __init__(self, engine, group=None, overlap=True, log=False):
         self.e = engine
