@@ -350,6 +350,51 @@ def test_tiled_engine_on_one_gpu(lib, oracle):
             e.close()
     assert bit_equal(got2, want)
 
+    # (a'') the schedule RowTiledSolver uses now, with two REAL neighbours: the projection's boundary block rows
+    #       first, the halo rows copied between the two parts of the projection (exchange_info then has to point
+    #       into the iterate being written), gradient interior, then the edge segments behind the copy
+    eng = [tiled.HipBandEngine(band_planes(*b), 0.3, [0.001], its, b, 0) for b in bands]
+    try:
+        comm = torch.cuda.Stream()
+
+        def halo_copy_after(events):
+            with torch.cuda.stream(comm):
+                for d in events:
+                    comm.wait_event(d)
+                h0, h1 = eng[0].halo(), eng[1].halo()
+                h1["recv_top"][0].copy_(h0["send_bottom"][0], non_blocking=True)
+                h0["recv_bottom"][0].copy_(h1["send_top"][0], non_blocking=True)
+                return comm.record_event()
+        ready = halo_copy_after([e.project_done_event() for e in eng])
+        for e in eng:
+            e.stream.wait_event(ready)
+            e.commit_initial_halo()
+        ready = None
+        for _ in range(its):
+            for e in eng:
+                with e.stream_context():
+                    e.gradient_interior()
+                    e.gradient_edges_inline(ready)
+                    e.finish_gradient()
+            torch.cuda.synchronize()
+            allp = torch.cat([e.partials_local for e in eng])
+            for e in eng:
+                with e.stream_context():
+                    e.partials_all.copy_(allp)
+                    e.project_boundary()
+            ready = halo_copy_after([e.project_done_event() for e in eng])
+            for e in eng:
+                with e.stream_context():
+                    e.project_interior()
+        for e in eng:
+            e.stream.wait_event(ready)
+        torch.cuda.synchronize()
+        got3 = np.concatenate([e.download(0) for e in eng], axis=0)
+    finally:
+        for e in eng:
+            e.close()
+    assert bit_equal(got3, want)
+
     # (b) the real driver over a 1-rank RCCL group
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29731")
