@@ -614,10 +614,11 @@ def test_randomised_band_splits_match_the_whole_canvas(lib):
     150-case run of seed 3)."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_bands.py"), "25", "9"], cwd=ROOT,
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "band splits bit-identical" in r.stdout
+    for extra in ([], ["--split"]):        # whole projection phase / boundary block rows, halo copy, interior
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sweep_bands.py"), "25", "9", *extra], cwd=ROOT,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        assert "band splits bit-identical" in r.stdout
 
 
 @pytest.mark.parametrize("order", ["lib_first", "torch_first"])

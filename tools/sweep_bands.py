@@ -13,6 +13,9 @@ import jpeg2png_amd as j
 from jpeg2png_amd import tiled
 from sweep_cases import cases
 
+split = "--split" in sys.argv           # use the two-part projection phase, halo rows copied between the parts
+if split:
+    sys.argv.remove("--split")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 hip = j.hip_runtime()
@@ -52,8 +55,22 @@ for cs in cases(seed, n):
                 for src in infos:
                     hip.hipMemcpy(dst.partials_all + 8 * nch * src.first_tile_row, src.partials_local,
                                   8 * nch * src.local_tile_rows, D2D)
-            for s in bands:
-                s.phase_project()
+            if split:                              # boundary block rows first, halo copy, then the rest
+                for s in bands:
+                    s.phase_project_part(1)
+                for s in bands:
+                    s.sync()
+                infos = [s.exchange_info() for s in bands]      # now points into the iterate being written
+                nbytes = infos[0].halo_floats * 4
+                for i in range(nb - 1):
+                    for c in range(nch):
+                        hip.hipMemcpy(infos[i + 1].recv_top[c], infos[i].send_bottom[c], nbytes, D2D)
+                        hip.hipMemcpy(infos[i].recv_bottom[c], infos[i + 1].send_top[c], nbytes, D2D)
+                for s in bands:
+                    s.phase_project_part(2)
+            else:
+                for s in bands:
+                    s.phase_project()
             for s in bands:
                 s.sync()
             infos = [s.exchange_info() for s in bands]
@@ -64,6 +81,8 @@ for cs in cases(seed, n):
             nbytes = infos[0].halo_floats * 4
             for i in range(nb - 1):
                 for c in range(nch):
+                    if split:
+                        break
                     hip.hipMemcpy(infos[i + 1].recv_top[c], infos[i].send_bottom[c], nbytes, D2D)
                     hip.hipMemcpy(infos[i].recv_bottom[c], infos[i + 1].send_top[c], nbytes, D2D)
         same = True
