@@ -11,23 +11,35 @@ Workloads (BASELINE.json configs):
   N = 1 : configs[2]  4096x4096 Y-only, Q=10, -i 500, weight 0.3, pweight 0.001
           (the configuration the metric "Mpixel-iterations/sec on 4K Y-plane" is quoted on)
   N > 1 : configs[3]  16384-wide Y-only plane, Q=10, -i 100, row-tiled: 2048 rows per GPU
-          (N = 8 is exactly the 16384x16384 config), one RCCL halo exchange + one
-          all-gather of norm partials per iteration; weak scaling (fixed rows per GPU).
+          (N = 8 is exactly the 16384x16384 config); weak scaling (fixed rows per GPU).
+          Default engine: the C row tiling (j2p_tiled: one process drives all N GPUs with one host
+          thread per band; bands exchange edge rows and norm row sums by peer access over xGMI,
+          ordered by HIP events) — rank 0 drives it, the other ranks of the launch only take part
+          in the barriers.  `--tiled-impl rccl`: the round-1 harness, one process per GPU with
+          RCCL send/recv + all-gather (jpeg2png_amd/tiled.py).
+  --config batch : configs[4] slice — B x 1080p 4:2:0 Q=50 -i 100 through the C batch API
+          (host buffers in, RGB out: PCIe inclusive), images/s and Mpx-it/s.
 
 value = canvas pixels x iterations x steps / wall time over all ranks (max over ranks).
 The JSON also carries
-  roofline     : the slower of the two phase kernels, algorithmic bytes (SURVEY.md §8d:
-                 gradient 16 B/px, step+projection 22 B/px, 38 B/px-iteration together)
-                 over its average duration from HIP events recorded on the solver's
-                 stream during the timed region, against the 8 TB/s HBM peak;
+  roofline     : WHOLE ITERATION, wall clock: 38 algorithmic bytes per pixel-iteration
+                 (gradient 16 B/px + step/projection 22 B/px) x px-it/s against the
+                 8 TB/s HBM peak, i.e. launch gaps and everything else included; `kernel` names the
+                 phase kernel with the LOWER per-kernel fraction and `per_kernel` lists both, from
+                 HIP events recorded on the solver's stream during the timed region;
   cpu_baseline : the UNMODIFIED reference (oracle/_ref, built from /root/reference by
                  oracle/Makefile) — or our C port if that .so is absent — timed on this
-                 box's host cores on a bounded sample of the same workload.
+                 box's host cores on a bounded sample of the same workload, 1 thread;
+  cpu_baseline_all_cores : the same library called from one host thread per core on independent
+                 planes — the reference's file-level OpenMP parallelism (jpeg2png.c:330; its
+                 in-solver OpenMP gains nothing for a single plane, SURVEY.md §6.2);
+  other_configs: configs[0], configs[1] and a configs[4] slice timed in this same run.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -38,6 +50,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_GRADIENT = 16              # per canvas pixel per launch (phase A)
 BYTES_PROJECT = 22               # phase B
+BYTES_ITERATION = BYTES_GRADIENT + BYTES_PROJECT
 WEIGHT, PWEIGHT = 0.3, 0.001     # jpeg2png.c:22-23 defaults
 
 
@@ -46,12 +59,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=["headline", "batch"], default="headline")
     ap.add_argument("--size", type=int, default=0, help="override plane width (debug)")
     ap.add_argument("--height", type=int, default=0, help="override plane height (debug, single GPU)")
     ap.add_argument("--iterations", type=int, default=0, help="override iterations per solve (debug)")
+    ap.add_argument("--batch", type=int, default=32, help="--config batch: images per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--timing-every", type=int, default=16, help="HIP-event sample stride (iterations)")
     ap.add_argument("--force-tiled", action="store_true", help="run the row-tiled path even with one rank (debug)")
+    ap.add_argument("--bands", type=int, default=0, help="--force-tiled on one GPU: number of bands on device 0")
+    ap.add_argument("--tiled-impl", choices=["c", "rccl"], default="c")
+    ap.add_argument("--norm-fold", type=int, default=1, help="0: the round-1 stand-alone norm kernels (A/B)")
     return ap.parse_args()
 
 
@@ -63,6 +82,16 @@ def _flush_c_stdio():
         ctypes.CDLL(None).fflush(None)
     except OSError:
         pass
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(width, seed):
@@ -84,10 +113,125 @@ def cpu_baseline(width, seed):
         ob.oracle_compute(planes, WEIGHT, [PWEIGHT], its)
         secs = time.perf_counter() - t0
         kind = "port"
-    return {"value": round(width * rows * its / secs / 1e6, 2), "unit": "Mpixel-iterations/s", "cores": 1,
-            "kind": kind,
-            "sample": f"{width}x{rows} Y-only Q10, {its} iterations, weight {WEIGHT}, pweight {PWEIGHT}, "
-                      f"{secs:.2f} s inside compute(), host has {os.cpu_count()} cores"}
+    one = {"value": round(width * rows * its / secs / 1e6, 2), "unit": "Mpixel-iterations/s", "cores": 1,
+           "kind": kind, "cpu": cpu_model(),
+           "sample": f"{width}x{rows} Y-only Q10, {its} iterations, weight {WEIGHT}, pweight {PWEIGHT}, "
+                     f"{secs:.2f} s inside compute(), host has {os.cpu_count()} cores"}
+    # all cores: one compute() per host thread on independent planes (the reference's omp-parallel-for over files,
+    # jpeg2png.c:330): the 4096-row plane cut into 512-row pieces, each thread solves one piece, 20 iterations
+    ncores = os.cpu_count() or 1
+    nthreads = min(ncores, 256)
+    piece_rows, its_all = 512, 20
+    pieces = []
+    for k in range(8):
+        pl = synth.make_planes(width, 4096, "444", 10, seed=seed, y_only=True, rows=(k * piece_rows, (k + 1) * piece_rows))
+        for p in pl:
+            p.fdata = ob.decode_plane(p)
+        pieces.append(pl)
+    fn = (lambda pl: ob.ref_compute(pl, WEIGHT, [PWEIGHT], its_all)) if kind == "reference" else \
+         (lambda pl: ob.oracle_compute(pl, WEIGHT, [PWEIGHT], its_all))
+    threads = [threading.Thread(target=fn, args=(pieces[i % 8],)) for i in range(nthreads)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    secs_all = time.perf_counter() - t0
+    allc = {"value": round(nthreads * width * piece_rows * its_all / secs_all / 1e6, 2), "unit": "Mpixel-iterations/s",
+            "cores": nthreads, "kind": kind, "cpu": cpu_model(),
+            "sample": f"{nthreads} concurrent compute() calls (one host thread each, the reference's file-level "
+                      f"parallelism), each {width}x{piece_rows} Y-only Q10, {its_all} iterations; {secs_all:.2f} s wall"}
+    return one, allc
+
+
+def other_configs(j, synth):
+    """configs[0], configs[1] and a configs[4] slice on this GPU, solver-resident like the headline (reset + run)."""
+    out = []
+
+    def timed(fn, reps):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps
+
+    planes = synth.make_planes(512, 512, "420", 10, seed=1235)
+    s = j.Solver(planes, WEIGHT, [PWEIGHT] * 3, 50)
+
+    def run0():
+        s.reset()
+        s.run(50)
+        s.sync()
+    dt = timed(run0, 20)
+    s.close()
+    out.append({"config": "configs[0] 512x512 4:2:0 Q10 -i 50 joint", "ms_per_solve": round(dt * 1e3, 4),
+                "Mpx_it_per_s": round(512 * 512 * 3 * 50 / dt / 1e6, 1)})
+
+    planes = synth.make_planes(1920, 1080, "444", 10, seed=1236)
+    solvers = [j.Solver([p], WEIGHT if c == 0 else 0.0, [PWEIGHT], 100) for c, p in enumerate(planes)]
+
+    def run1():
+        for sv in solvers:
+            sv.reset()
+        # 10-iteration slices round-robin from one host thread: the three streams stay fed without three GIL-bound threads
+        for _ in range(10):
+            for sv in solvers:
+                sv.run(10)
+        for sv in solvers:
+            sv.sync()
+    dt = timed(run1, 5)
+    for sv in solvers:
+        sv.close()
+    out.append({"config": "configs[1] 1920x1080 4:4:4 Q10 -i 100, -s: three compute(1,...) on three streams, weights 0.3/0/0",
+                "ms_per_image": round(dt * 1e3, 4), "Mpx_it_per_s": round(1920 * 1080 * 3 * 100 / dt / 1e6, 1)})
+
+    planes = synth.make_planes(1920, 1080, "420", 50, seed=1238)
+    n = 8
+    solvers = [j.Solver(planes, WEIGHT, [PWEIGHT] * 3, 100) for _ in range(n)]
+    W, H = solvers[0].W, solvers[0].H
+
+    def run4():
+        for sv in solvers:
+            sv.reset()
+        for _ in range(10):
+            for sv in solvers:
+                sv.run(10)
+        for sv in solvers:
+            sv.sync()
+    dt = timed(run4, 2)
+    for sv in solvers:
+        sv.close()
+    out.append({"config": f"configs[4] slice: {n} x 1080p 4:2:0 Q50 -i 100 joint (canvas {W}x{H}), one stream each, resident",
+                "ms_per_batch": round(dt * 1e3, 3), "images_per_s": round(n / dt, 2),
+                "Mpx_it_per_s": round(n * W * H * 3 * 100 / dt / 1e6, 1)})
+    return out
+
+
+def bench_batch(a, j, synth):
+    """configs[4] slice through the C batch API: host buffers in (int16 coefficients), RGB bytes out"""
+    its = a.iterations or 100
+    planes = synth.make_planes(1920, 1080, "420", 50, seed=1238)
+    ndev = max(1, a.gpus)
+    with j.Batch(devices=list(range(ndev)), slots_per_device=4) as b:
+        def step():
+            tickets = [b.submit(planes, WEIGHT, [PWEIGHT] * 3, its, width=1920, height=1080, bits=8) for _ in range(a.batch)]
+            for t in tickets:
+                b.wait(t)
+        for _ in range(a.warmup):
+            step()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        dt = (time.perf_counter() - t0) / a.steps
+    W, H = 1920, 1088
+    print(json.dumps({
+        "metric": "Mpixel-iterations/sec, batch of 1080p 4:2:0 images (host buffers in, RGB out)",
+        "value": round(a.batch * W * H * 3 * its / dt / 1e6, 1), "unit": "Mpixel-iterations/s", "n_gpus": ndev,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "images_per_s": round(a.batch / dt, 2),
+        "config": {"workload": f"{a.batch} x 1080p 4:2:0 Q50 -i {its} joint per step (BASELINE configs[4] slice), "
+                               f"j2p_batch: {ndev} device(s) x 4 slots, PCIe inclusive"}}), flush=True)
 
 
 def main():
@@ -109,7 +253,21 @@ def main():
     j.build()
     torch.cuda.set_device(local_rank)
 
+    if a.config == "batch":
+        if rank == 0:
+            bench_batch(a, j, synth)
+        return
+
     tiled_mode = n_gpus > 1 or a.force_tiled
+    c_tiled = tiled_mode and a.tiled_impl == "c"
+    driver = None
+    dist = None
+    if n_gpus > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not tiled_mode:
         W = a.size or 4096
         H = a.height or W
@@ -118,21 +276,54 @@ def main():
         workload = f"{W}x{H} Y-only Q10 -i {its} (BASELINE configs[2])"
         planes = synth.make_planes(W, H, "444", 10, seed=seed, y_only=True)
         solver = j.Solver(planes, WEIGHT, [PWEIGHT], its, device=local_rank)   # fdata=None: decoded on device
+        solver.debug_option(j.J2P_OPT_NORM_FOLD, a.norm_fold)
         del planes
-
-        def reset():
-            solver.reset()
-
-        def solve():
-            solver.run(its)
-
-        def sync():
-            solver.sync()
+        reset, solve, sync = solver.reset, (lambda: solver.run(its)), solver.sync
         eng = solver
+        parallelism = "single GPU"
+        rows_per_gpu = H
+    elif c_tiled:
+        W = a.size or 16384
+        rows_per_gpu = 2048 if not a.size else max(64, a.size // 8 // 16 * 16)
+        nband = n_gpus if n_gpus > 1 else max(2, a.bands or 2)
+        H = rows_per_gpu * nband
+        its = a.iterations or 100
+        seed = 1234 + 4
+        workload = (f"{W}x{H} Y-only Q10 -i {its}, row-tiled {rows_per_gpu} rows/GPU over {n_gpus} GPUs "
+                    f"(BASELINE configs[3] at 8 GPUs)")
+        # every rank synthesises its own band(s); rank 0 collects them through /dev/shm and drives all GPUs
+        tag = f"/dev/shm/j2p_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+        mine = range(nband) if n_gpus == 1 else [rank]
+        for b in mine:
+            band = synth.make_planes(W, H, "444", 10, seed=seed, y_only=True, rows=(b * rows_per_gpu, (b + 1) * rows_per_gpu))[0]
+            np.save(f"{tag}_{b}.npy", band.data)
+            qt = band.quant_table
+        if dist is not None:
+            dist.barrier()
+        eng = None
+        if rank == 0:
+            data = np.concatenate([np.load(f"{tag}_{b}.npy") for b in range(nband)])
+            plane = synth.Plane(W, H, 1, 1, data, qt)
+            devices = list(range(n_gpus)) if n_gpus > 1 else [local_rank] * nband
+            tsolver = j.TiledSolver([plane], WEIGHT, [PWEIGHT], its, devices=devices)
+            del data, plane
+            eng = tsolver.band_solver(0)
+            reset, solve, sync = tsolver.reset, (lambda: tsolver.run(its)), tsolver.sync
+        else:
+            reset = solve = sync = (lambda: None)
+        if dist is not None:
+            dist.barrier()
+        for b in mine:
+            try:
+                os.unlink(f"{tag}_{b}.npy")
+            except OSError:
+                pass
+        parallelism = (f"row-tiled x{nband}: C engine (j2p_tiled), one process drives all GPUs, one host thread per band; "
+                       "edge rows and norm row sums read over peer access, ordered by HIP events")
     else:
-        import torch.distributed as dist
         from jpeg2png_amd import tiled
-        if not dist.is_initialized():
+        if dist is None:
+            import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29541")
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -155,25 +346,22 @@ def main():
         def reset():
             engine.reset()
             driver.start()
-
-        def solve():
-            driver.iterate(its)
-
-        def sync():
-            engine.solver.sync()
+        solve, sync = (lambda: driver.iterate(its)), engine.solver.sync
         eng = engine.solver
         reset()
+        parallelism = (f"row-tiled x{n_gpus}, one process per GPU, RCCL halo send/recv + norm all-gather "
+                       f"({'librccl called on the solver streams' if driver.direct is not None else 'through torch.distributed'})")
 
     def barrier():
-        if tiled_mode:
-            import torch.distributed as dist
+        if dist is not None and dist.is_initialized():
             dist.barrier()
 
     for _ in range(a.warmup):
         reset()
         solve()
     sync()
-    eng.enable_timing(a.timing_every)
+    if eng is not None:
+        eng.enable_timing(a.timing_every)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -184,10 +372,9 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    g_ms, p_ms, samples = eng.kernel_times()
+    g_ms, p_ms, samples = eng.kernel_times() if eng is not None else (0.0, 0.0, 0)
 
-    if tiled_mode:
-        import torch.distributed as dist
+    if dist is not None and dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -195,59 +382,68 @@ def main():
     if rank == 0:
         px = W * H
         value = px * its * a.steps / elapsed / 1e6
-        band_px = px // n_gpus
-        # the two phase kernels take the same time to within run-to-run noise; report the one with the
-        # lower roofline fraction (k_gradient) unless k_project is clearly the longer one, and list both
-        if g_ms >= 0.97 * p_ms:
-            kern, dur_ms, bpp = "k_gradient", g_ms, BYTES_GRADIENT
-        else:
-            kern, dur_ms, bpp = "k_project", p_ms, BYTES_PROJECT
-        achieved = band_px * bpp / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
-        # pixels per TIMED launch: in the row-tiled schedule the events bracket the interior launches only
+        ngp = n_gpus if n_gpus > 1 else 1
+        band_px = W * rows_per_gpu
+        # pixels per TIMED launch: in the row-tiled schedules the events bracket the interior launches only
         # (all 16-row segments but the band's first and last; all block rows but the first and last)
         px_of = {"k_gradient": band_px, "k_project": band_px}
-        if tiled_mode and driver.overlap:
+        if tiled_mode and (c_tiled or driver.overlap):
             px_of = {"k_gradient": W * (rows_per_gpu - 32), "k_project": W * (rows_per_gpu - 16)}
-        achieved = px_of[kern] * bpp / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
         per_kernel = {}
         for kname, kms, kb in (("k_gradient", g_ms, BYTES_GRADIENT), ("k_project", p_ms, BYTES_PROJECT)):
             gbs = px_of[kname] * kb / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
             per_kernel[kname] = {"avg_launch_ms": round(kms, 4), "algorithmic_bytes_per_launch": px_of[kname] * kb,
                                  "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        kern = min(per_kernel, key=lambda k: per_kernel[k]["frac"])
+        # whole iteration, wall clock, per GPU (bands on one GPU share it)
+        gpus_used = ngp
+        it_gbs = BYTES_ITERATION * value * 1e6 / gpus_used / 1e9
+        it_ms = elapsed / a.steps / its * 1e3
         # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/, corrected as
         # MI355X_MICROARCH.md prescribes); only meaningful for the N=1 workload they were taken on
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if not tiled_mode and not a.size and os.path.exists(pmc):
-            with open(pmc) as f:
-                summ = json.load(f)
-            for name, v in summ.items():
-                if isinstance(v, dict) and name.startswith("j2p::" + kern) and "hbm_bytes_per_launch" in v:
-                    traffic, traffic_src = v["hbm_bytes_per_launch"], "profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE)"
+        for tag in ("r02", "r01"):
+            pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json")
+            if traffic is None and not tiled_mode and not a.size and os.path.exists(pmc):
+                with open(pmc) as f:
+                    summ = json.load(f)
+                tot = {}
+                for name, v in summ.items():
+                    if isinstance(v, dict) and "hbm_bytes_per_launch" in v:
+                        for kk in ("k_gradient", "k_project"):
+                            if name.startswith("j2p::" + kk) or name.startswith(kk):
+                                tot[kk] = v["hbm_bytes_per_launch"]
+                if len(tot) == 2:
+                    traffic = tot["k_gradient"] + tot["k_project"]
+                    traffic_src = f"profiles/{tag}_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE; k_gradient + k_project)"
         out = {
             "metric": "Mpixel-iterations/sec on 4K Y-plane", "value": round(value, 1),
             "unit": "Mpixel-iterations/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "iterations_per_step": its, "weight": WEIGHT, "pweight": PWEIGHT,
-                       "parallelism": "single GPU" if not tiled_mode else
-                       f"row-tiled x{n_gpus}, RCCL halo send/recv + norm all-gather "
-                       f"({'librccl called on the solver streams' if driver.direct is not None else 'through torch.distributed'})"},
-            "roofline": {"bound": "hbm", "kernel": kern, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": px_of[kern] * bpp,
-                         "avg_launch_ms": {"k_gradient": round(g_ms, 4), "k_project": round(p_ms, 4)},
+                       "parallelism": parallelism, "norm_fold": bool(a.norm_fold)},
+            "roofline": {"bound": "hbm", "scope": "whole iteration (k_gradient + k_project, launch gaps included), wall clock, per GPU",
+                         "kernel": kern, "achieved": round(it_gbs, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(it_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes per iteration", "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_iteration": band_px * BYTES_ITERATION,
+                         "iteration_ms": round(it_ms, 5),
+                         "kernel_frac": per_kernel[kern]["frac"],
                          "per_kernel": per_kernel,
                          "event_samples": samples,
-                         "iteration_frac_38B": round(38.0 * value * 1e6 / n_gpus / 1e9 / HBM_PEAK_GBS, 4)},
+                         "note": "per-kernel durations come from HIP events around every "
+                                 f"{a.timing_every}th iteration; the event records themselves cost time on those "
+                                 "iterations, so the two durations can add up to more than iteration_ms"},
         }
+        if not tiled_mode and not a.no_other_configs and not a.size:
+            eng.close()
+            out["other_configs"] = other_configs(j, synth)
         if not tiled_mode and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(W, seed)
+            out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(W, seed)
         _flush_c_stdio()
         print(json.dumps(out), flush=True)
-    if tiled_mode:
-        import torch.distributed as dist
+    if dist is not None and dist.is_initialized():
         dist.destroy_process_group()
 
 

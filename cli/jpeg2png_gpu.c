@@ -9,8 +9,9 @@
  * so that only int16 coefficients go up and only RGB bytes come down.
  *
  * Differences from the reference, on purpose:
- *   -t threads   = number of input files in flight (host threads, one HIP stream each),
- *                  instead of an OpenMP thread count; default 4
+ *   -t threads   = number of input files in flight (host threads reading / writing files; each file's GPU work
+ *                  is a job of the library's batch engine, j2p_batch_*), instead of an OpenMP thread count;
+ *                  default 4
  *   J2P_DEVICE / J2P_DEVICES environment: GPU index, or a comma list to spread files over
  * Messages and exit codes follow the reference ("jpeg2png: <message>", EXIT_FAILURE).
  */
@@ -101,14 +102,19 @@ struct jpeg_in {
         struct component c[3];
 };
 
+/* libjpeg's output_message hook: warnings (a truncated file, extraneous bytes ...) are printed and the
+ * decode carries on, exactly like die_output_message of jpeg.c:14-19 — which, despite its name, returns.
+ * Like die_message_start (utils.c:10-16) it takes the progress bar down for good.  Fatal errors keep
+ * libjpeg's default error_exit: output_message, then exit(EXIT_FAILURE). */
 static void jpeg_message(j_common_ptr info)
 {
         char buf[JMSG_LENGTH_MAX];
         (*info->err->format_message)(info, buf);
-        die("%s", buf);
+        pthread_mutex_lock(&ui_lock);
+        if(bar_on) { bar_clear(); bar_on = false; }
+        fprintf(stderr, "jpeg2png: libjpeg error: %s\n", buf);
+        pthread_mutex_unlock(&ui_lock);
 }
-
-static void jpeg_fatal(j_common_ptr info) { jpeg_message(info); }
 
 static void read_coefficients(FILE *in, struct jpeg_in *jp)
 {
@@ -116,7 +122,6 @@ static void read_coefficients(FILE *in, struct jpeg_in *jp)
         struct jpeg_error_mgr err;
         d.err = jpeg_std_error(&err);
         err.output_message = jpeg_message;
-        err.error_exit = jpeg_fatal;
         jpeg_create_decompress(&d);
         jpeg_stdio_src(&d, in);
         jpeg_read_header(&d, TRUE);
@@ -196,51 +201,55 @@ struct options {
 };
 
 static pthread_mutex_t csv_lock = PTHREAD_MUTEX_INITIALIZER;
+/* the library's batch engine, created when the first file has been read (a file that cannot be read fails on its
+ * own message, with or without a GPU) */
+static j2p_batch *batch = NULL;
+static pthread_once_t batch_once = PTHREAD_ONCE_INIT;
+static unsigned batch_ndev = 1, batch_slots = 1;
+static int batch_devs[16];
+static int batch_rc = J2P_OK;
+static char batch_err[512];
+
+static void batch_start(void)
+{
+        batch_rc = j2p_batch_create(&batch, batch_ndev, batch_devs, batch_slots);
+        if(batch_rc != J2P_OK) { snprintf(batch_err, sizeof(batch_err), "%s", j2p_last_error()); }
+}
 
 static void gpu_check(int rc)
 {
         if(rc != J2P_OK) { die("%s", j2p_last_error()); }
 }
 
-/* run n solvers (1 joint, or 3 separate ones on 3 streams) in chunks of iterations so that the
- * bar and the CSV keep moving (compute.c:427-453); without a CSV the chunks of the different
- * solvers are issued back to back and overlap on the GPU */
-static void run_solvers(unsigned n, j2p_solver **s, const unsigned *iterations, const unsigned *channel,
-                        const struct options *o, const char *name)
+/* callbacks of a batch job (called on the library's worker thread): CSV rows (logger.c:20-28) and progress ticks */
+struct job_ctx {
+        const struct options *o;
+        const char *name;
+};
+
+static void job_rows(void *user, unsigned channel, unsigned first, unsigned n, const j2p_log_row *rows)
 {
-        enum { CHUNK = 32 };
-        j2p_log_row rows[CHUNK];
-        unsigned done[3] = {0, 0, 0};
-        for(;;) {
-                unsigned step[3] = {0, 0, 0}, any = 0;
-                for(unsigned c = 0; c < n; c++) {
-                        unsigned left = iterations[c] - done[c];
-                        step[c] = left < CHUNK ? left : CHUNK;
-                        if(!step[c]) { continue; }
-                        any = 1;
-                        gpu_check(j2p_solver_run(s[c], step[c], o->csv ? rows : NULL));
-                        if(o->csv) {
-                                pthread_mutex_lock(&csv_lock);         /* critical(write_log), logger.c:22 */
-                                for(unsigned i = 0; i < step[c]; i++) {
-                                        if(fprintf(o->csv, "%s,%u,%u,%f,%f,%f,%f\n", name, channel[c], done[c] + i,
-                                                   rows[i].objective, rows[i].prob_dist, rows[i].tv, rows[i].tv2) < 0) {
-                                                die_perror("could not write to csv log");
-                                        }
-                                }
-                                pthread_mutex_unlock(&csv_lock);
-                        }
-                }
-                if(!any) { break; }
-                for(unsigned c = 0; c < n; c++) {
-                        if(!step[c]) { continue; }
-                        if(!o->csv) { gpu_check(j2p_solver_sync(s[c])); }
-                        if(!o->quiet) { bar_add(step[c]); }
-                        done[c] += step[c];
+        struct job_ctx *ctx = user;
+        pthread_mutex_lock(&csv_lock);                                 /* critical(write_log), logger.c:22 */
+        for(unsigned i = 0; i < n; i++) {
+                if(fprintf(ctx->o->csv, "%s,%u,%u,%f,%f,%f,%f\n", ctx->name, channel, first + i, rows[i].objective,
+                           rows[i].prob_dist, rows[i].tv, rows[i].tv2) < 0) {
+                        die_perror("could not write to csv log");
                 }
         }
+        pthread_mutex_unlock(&csv_lock);
 }
 
-static void decode_file(const char *infile, const char *outfile, const struct options *o, int device)
+static void job_progress(void *user, unsigned n)
+{
+        (void)user;
+        bar_add(n);
+}
+
+/* decode_file (jpeg2png.c:120-172): the coefficients go to the library's batch engine, which decodes, solves
+ * (one joint compute(3, ...) or three compute(1, ...), jpeg2png.c:141-152) and converts on a GPU slot of its own
+ * while this thread's neighbours read their JPEGs and deflate their PNGs */
+static void decode_file(const char *infile, const char *outfile, const struct options *o)
 {
         FILE *in = fopen(infile, "rb");
         if(!in) { die_perror("could not open input file `%s`", infile); }
@@ -248,41 +257,39 @@ static void decode_file(const char *infile, const char *outfile, const struct op
         read_coefficients(in, &jp);
         fclose(in);
 
-        j2p_plane planes[3];
+        struct job_ctx ctx = {o, infile};
+        j2p_job job;
+        memset(&job, 0, sizeof(job));
+        job.nchannel = 3;
         for(int c = 0; c < 3; c++) {
-                planes[c].w = jp.c[c].w;
-                planes[c].h = jp.c[c].h;
-                planes[c].w_samp = jp.c[c].w_samp;
-                planes[c].h_samp = jp.c[c].h_samp;
-                planes[c].data = jp.c[c].data;
-                planes[c].fdata = NULL;                                 /* decoded on the device */
-                planes[c].quant_table = jp.c[c].quant;
+                job.planes[c].w = jp.c[c].w;
+                job.planes[c].h = jp.c[c].h;
+                job.planes[c].w_samp = jp.c[c].w_samp;
+                job.planes[c].h_samp = jp.c[c].h_samp;
+                job.planes[c].data = jp.c[c].data;
+                job.planes[c].fdata = NULL;                             /* decoded on the device */
+                job.planes[c].quant_table = jp.c[c].quant;
+                job.weight[c] = o->weights[c];
+                job.pweight[c] = o->pweights[c];
+                job.iterations[c] = o->iterations[c];
         }
-        j2p_band whole = {0, 0};
-        j2p_solver *s[3] = {NULL, NULL, NULL};
-        j2p_plane_ref ref[3];
-        if(o->joint) {
-                gpu_check(j2p_solver_create(&s[0], device, NULL, 3, planes, o->weights[0], o->pweights, o->iterations[0], whole, 0));
-                const unsigned joint_channel = 3;                       /* jpeg2png.c:143 */
-                run_solvers(1, s, o->iterations, &joint_channel, o, infile);
-                for(int c = 0; c < 3; c++) { ref[c].solver = s[0]; ref[c].channel = (unsigned)c; }
-        } else {
-                for(int c = 0; c < 3; c++) {
-                        gpu_check(j2p_solver_create(&s[c], device, NULL, 1, &planes[c], o->weights[c], &o->pweights[c],
-                                                    o->iterations[c], whole, 0));
-                }
-                const unsigned channels[3] = {0, 1, 2};                 /* jpeg2png.c:149 */
-                run_solvers(3, s, o->iterations, channels, o, infile);
-                for(int c = 0; c < 3; c++) { ref[c].solver = s[c]; ref[c].channel = 0; }
-        }
+        job.separate = !o->joint;
+        job.out_bits = o->png_bits;
+        job.out_w = jp.w;
+        job.out_h = jp.h;
         size_t bytes = (size_t)jp.w * jp.h * 3 * (o->png_bits / 8);
         uint8_t *pixels = malloc(bytes);
         if(!pixels) { die("could not allocate image data"); }
-        gpu_check(j2p_planes_to_rgb(ref, jp.w, jp.h, o->png_bits, pixels));
-        for(int c = 0; c < 3; c++) {
-                if(s[c]) { j2p_solver_destroy(s[c]); }
-                free(jp.c[c].data);
-        }
+        job.out_rgb = pixels;
+        job.on_rows = o->csv ? job_rows : NULL;
+        job.on_progress = o->quiet ? NULL : job_progress;
+        job.user = &ctx;
+        int ticket = 0;
+        pthread_once(&batch_once, batch_start);
+        if(batch_rc != J2P_OK) { die("%s", batch_err); }
+        gpu_check(j2p_batch_submit(batch, &job, &ticket));
+        gpu_check(j2p_batch_wait(batch, ticket));
+        for(int c = 0; c < 3; c++) { free(jp.c[c].data); }
         FILE *out = fopen(outfile, "wb");
         if(!out) { die_perror("could not open output file `%s`", outfile); }
         write_rgb_png(out, jp.w, jp.h, o->png_bits, pixels);
@@ -307,7 +314,7 @@ static void *worker(void *arg)
                 unsigned i = w->next++;
                 pthread_mutex_unlock(&w->lock);
                 if(i >= w->nin) { break; }
-                decode_file(w->in[i], w->out[i], w->o, w->o->devs[i % (unsigned)w->o->ndev]);
+                decode_file(w->in[i], w->out[i], w->o);
         }
         return NULL;
 }
@@ -453,11 +460,17 @@ int main(int argc, char **argv)
         struct work w = {.nin = nin, .next = 0, .in = ins, .out = outfiles, .o = &o};
         pthread_mutex_init(&w.lock, NULL);
         if(threads > nin) { threads = nin; }
+        /* as many GPU slots as files in flight, spread over the devices of J2P_DEVICES */
+        batch_ndev = (unsigned)o.ndev;
+        memcpy(batch_devs, o.devs, sizeof(batch_devs));
+        batch_slots = (threads + batch_ndev - 1) / batch_ndev;
+        if(batch_slots > 16) { batch_slots = 16; }
         pthread_t *tid = malloc(sizeof(*tid) * threads);
         for(unsigned t = 1; t < threads; t++) { pthread_create(&tid[t], NULL, worker, &w); }
         worker(&w);
         for(unsigned t = 1; t < threads; t++) { pthread_join(tid[t], NULL); }
         free(tid);
+        if(batch) { j2p_batch_destroy(batch); }
 
         if(!nout) { for(unsigned i = 0; i < nin; i++) { free(outfiles[i]); } }
         free(outfiles);

@@ -87,6 +87,19 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream,
                       j2p_band band, int band_local_arrays);
 void j2p_solver_destroy(j2p_solver *s);
 
+/* Device memory of destroyed solvers is cached per process and handed to the next solver on the same device
+ * (hipMalloc / hipFree cost milliseconds and hipFree stalls every stream of the device, which matters when the
+ * host calls compute() from several threads, jpeg2png.c:147,330).  j2p_pool_trim() releases the cache. */
+void j2p_pool_trim(void);
+
+/* diagnostics: schedule switches that change speed, never results (A/B timing and the parity tests of both
+ * schedules).  Only between iterations. */
+#define J2P_OPT_NORM_FOLD     1   /* 1 (default): ||g|| is reduced inside the gradient kernel by its last-arriving
+                                     wavefronts; 0: separate reduction kernels (the round-1 schedule) */
+#define J2P_OPT_JOINT_INWAVE  2   /* 1: all channels of a joint image in one wavefront; 0 (default): one wavefront
+                                     per channel.  Environment J2P_JOINT_INWAVE sets the default at create time */
+int j2p_solver_debug_option(j2p_solver *s, int option, int value);
+
 /* canvas geometry (compute.c:410-416) and band bookkeeping */
 int j2p_solver_canvas(const j2p_solver *s, unsigned *W, unsigned *H);
 int j2p_solver_band(const j2p_solver *s, unsigned *row_begin, unsigned *row_end);
@@ -151,6 +164,35 @@ typedef struct j2p_exchange {
 } j2p_exchange;
 int j2p_solver_exchange_info(j2p_solver *s, j2p_exchange *info);
 
+/* Pieces of a row-tiled run inside ONE process (what j2p_tiled below is made of; peers' device pointers must be
+ * accessible from the solver's device: same GPU, or peer access enabled).
+ *   stream            : the hipStream_t the solver launches on
+ *   halo_rows         : the send/recv row addresses of j2p_exchange for x buffer 0 or 1 — the iterate produced by
+ *                       iteration k (0-based) lives in buffer (k + 1) & 1 — independent of the solver's state
+ *   norm_from_bands   : between the two phases: ||g|| from every band's level-1 sums (partials_local), read in
+ *                       place; replaces the all-gather into partials_all
+ *   copy_rows         : n row blocks copied on the solver's stream (the neighbours' edge rows into its halo rows) */
+int j2p_solver_stream(j2p_solver *s, void **stream);
+int j2p_solver_halo_rows(j2p_solver *s, int buffer, j2p_exchange *info);
+int j2p_solver_norm_from_bands(j2p_solver *s, unsigned nband, const double *const rowsums[],
+                               const unsigned first_tile_row[], const unsigned tile_rows[]);
+int j2p_solver_copy_rows(j2p_solver *s, unsigned n, float *const dst[], const float *const src[], size_t floats);
+
+/* One plane set row-tiled over several GPUs from one process: nband solvers, band i on devices[i] (ids may
+ * repeat), one host thread per band.  cuts = nband + 1 row boundaries from 0 to the canvas height, aligned to
+ * lcm(16, 8 * h_samp), or NULL for near-equal bands.  run / sync / download mirror the j2p_solver calls; the
+ * planes are bit-identical to a whole-canvas solver's whatever the cut.  (Reference loop: compute.c:427-453.) */
+typedef struct j2p_tiled j2p_tiled;
+int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const unsigned cuts[], unsigned nchannel,
+                     const j2p_plane planes[], float weight, const float pweight[], unsigned iterations);
+void j2p_tiled_destroy(j2p_tiled *t);
+int j2p_tiled_canvas(const j2p_tiled *t, unsigned *W, unsigned *H, unsigned *nband);
+int j2p_tiled_band(const j2p_tiled *t, unsigned band, int *device, unsigned *row_begin, unsigned *row_end, j2p_solver **solver);
+int j2p_tiled_reset(j2p_tiled *t);                                 /* back to iteration 0 from the resident inputs */
+int j2p_tiled_run(j2p_tiled *t, unsigned n, j2p_log_row *rows);   /* asynchronous unless rows != NULL */
+int j2p_tiled_sync(j2p_tiled *t);
+int j2p_tiled_download(j2p_tiled *t, unsigned c, float *out);      /* W * H floats */
+
 /* CSV logging for band solvers (the "+3 doubles when logging" of the norm exchange): with logging on, the
  * phase calls also leave the band's tv / tv2 / prob sums in j2p_exchange.log_local; the caller adds the bands'
  * sums up (any fixed order: the values only feed the log) and turns n iterations' worth of
@@ -201,6 +243,36 @@ typedef struct j2p_plane_ref {
         unsigned channel;
 } j2p_plane_ref;
 int j2p_planes_to_rgb(const j2p_plane_ref planes[3], unsigned w, unsigned h, unsigned bits, uint8_t *out_host);
+
+/* Image batches (BASELINE configs[4]; the file loop jpeg2png.c:330-337): a batch owns slots_per_device worker
+ * threads per GPU, each driving one image at a time on streams of its own, so that the uploads, solves and
+ * downloads of different images overlap; device memory is recycled between images (no hipMalloc / hipFree per
+ * image).  A job is what decode_file() does between read_jpeg() and write_png() (jpeg2png.c:141-161). */
+typedef struct j2p_batch j2p_batch;
+typedef struct j2p_job {
+        unsigned nchannel;                     /* 1..3 */
+        j2p_plane planes[J2P_MAX_CHANNELS];    /* host arrays; must stay valid until j2p_batch_wait() returns */
+        int separate;                          /* 0: one joint compute(nchannel, ...) (jpeg2png.c:144) with weight[0],
+                                                  iterations[0]; 1: one compute(1, ...) per component (jpeg2png.c:147-152) */
+        float weight[J2P_MAX_CHANNELS];
+        float pweight[J2P_MAX_CHANNELS];
+        unsigned iterations[J2P_MAX_CHANNELS];
+        /* output: out_bits 8 / 16 = RGB samples (png.c:37-62 incl. the luma +128 of jpeg2png.c:156-159), cropped to
+         * out_w x out_h, into out_rgb (h*w*3 or h*w*6 bytes); out_bits 0 = the W*H float canvas planes into
+         * out_planes[c] (NULL entries are skipped) */
+        unsigned out_bits, out_w, out_h;
+        uint8_t *out_rgb;
+        float *out_planes[J2P_MAX_CHANNELS];
+        /* optional callbacks, called on the worker thread: log rows of `n` iterations starting at `first`
+         * (channel = component, or 3 for a joint solve: jpeg2png.c:143,149) and progress ticks (iterations done) */
+        void (*on_rows)(void *user, unsigned channel, unsigned first, unsigned n, const j2p_log_row *rows);
+        void (*on_progress)(void *user, unsigned n);
+        void *user;
+} j2p_job;
+int j2p_batch_create(j2p_batch **out, unsigned ndev, const int devices[], unsigned slots_per_device);
+void j2p_batch_destroy(j2p_batch *b);                       /* finishes queued jobs first */
+int j2p_batch_submit(j2p_batch *b, const j2p_job *job, int *ticket);
+int j2p_batch_wait(j2p_batch *b, int ticket);               /* the job's status; its error text in j2p_last_error() */
 
 /* test hook: compares the kernels' fast division / square root (the compiler's IEEE
  * sequences without range scaling) with `/` and sqrtf() on n pseudo-random operand pairs

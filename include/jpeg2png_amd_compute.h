@@ -63,13 +63,23 @@ struct coef {
  *  - re-entrant and thread-safe (callers: jpeg2png.c:144, :147-152 inside omp parallel);
  *  - errors: prints "jpeg2png: <message>" to stderr and exit(EXIT_FAILURE), like die()
  *    (utils.c:20-28).  There is NO CPU fallback: without a gfx950 device it dies.
- * Device selection: environment variable J2P_DEVICE (default 0). */
+ * Device selection: environment variable J2P_DEVICE (default 0); or J2P_DEVICES=a,b,...: a canvas of at least
+ * 48 rows per listed GPU is then cut into row bands, one per GPU (j2p_compute_tiled), with results that do not
+ * depend on the number of GPUs; smaller canvases run on the first GPU of the list. */
 void compute(unsigned nchannel, struct coef coefs[], struct logger *log, struct progressbar *pb,
              float weight, float pweight[], unsigned iterations);
 
 /* same, with an explicit device and an error code instead of exit(); 0 on success */
 int j2p_compute(int device, unsigned nchannel, struct coef coefs[], struct logger *log,
                 struct progressbar *pb, float weight, const float pweight[], unsigned iterations);
+
+
+/* compute() with the canvas cut into `nband` row bands, band i on devices[i] (ids may repeat: several bands on
+ * one GPU).  One process, one host thread per band; the bands exchange their edge rows and gradient-norm row
+ * sums over peer access every iteration (reference loop: compute.c:427-453).  Same contract and — bit for bit —
+ * the same planes as j2p_compute(); 0 on success. */
+int j2p_compute_tiled(unsigned nband, const int devices[], unsigned nchannel, struct coef coefs[], struct logger *log,
+                      struct progressbar *pb, float weight, const float pweight[], unsigned iterations);
 
 #ifdef __cplusplus
 }

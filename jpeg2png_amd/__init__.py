@@ -44,6 +44,18 @@ class _CLogRow(ctypes.Structure):
                 ("tv", ctypes.c_double), ("tv2", ctypes.c_double)]
 
 
+_ROWS_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.POINTER(_CLogRow))
+_PROGRESS_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_uint)
+
+
+class _CJob(ctypes.Structure):
+    _fields_ = [("nchannel", ctypes.c_uint), ("planes", _CPlane * 3), ("separate", ctypes.c_int),
+                ("weight", ctypes.c_float * 3), ("pweight", ctypes.c_float * 3), ("iterations", ctypes.c_uint * 3),
+                ("out_bits", ctypes.c_uint), ("out_w", ctypes.c_uint), ("out_h", ctypes.c_uint),
+                ("out_rgb", ctypes.c_void_p), ("out_planes", ctypes.c_void_p * 3),
+                ("on_rows", _ROWS_CB), ("on_progress", _PROGRESS_CB), ("user", ctypes.c_void_p)]
+
+
 class _CExchange(ctypes.Structure):
     _fields_ = [("partials_local", ctypes.c_void_p), ("local_tile_rows", ctypes.c_uint),
                 ("partials_all", ctypes.c_void_p), ("global_tile_rows", ctypes.c_uint),
@@ -63,8 +75,14 @@ C_ABI_SYMBOLS = [
     "j2p_solver_download_gradient", "j2p_solver_set_logging", "j2p_log_rows_from_sums",
     "j2p_solver_plane_ptr", "j2p_solver_sync", "j2p_solver_kernel_times", "j2p_solver_enable_timing",
     "j2p_decode_plane", "j2p_dct8x8_blocks", "j2p_math_selftest", "j2p_planes_to_rgb", "j2p_sqrt_exhaustive",
-    "compute", "j2p_compute",
+    "j2p_pool_trim", "j2p_solver_debug_option", "j2p_solver_stream", "j2p_solver_halo_rows",
+    "j2p_solver_norm_from_bands", "j2p_solver_copy_rows",
+    "j2p_tiled_create", "j2p_tiled_destroy", "j2p_tiled_canvas", "j2p_tiled_band", "j2p_tiled_run", "j2p_tiled_reset", "j2p_tiled_sync",
+    "j2p_tiled_download",
+    "j2p_batch_create", "j2p_batch_destroy", "j2p_batch_submit", "j2p_batch_wait",
+    "compute", "j2p_compute", "j2p_compute_tiled",
 ]
+J2P_OPT_NORM_FOLD, J2P_OPT_JOINT_INWAVE = 1, 2
 
 _lib = None
 
@@ -149,6 +167,26 @@ def load_library():
     lib.j2p_device_count.argtypes = [ctypes.POINTER(ctypes.c_int)]
     lib.j2p_math_selftest.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_uint,
                                       ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
+    lib.j2p_solver_debug_option.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.j2p_pool_trim.restype = None
+    lib.j2p_tiled_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint, ctypes.POINTER(ctypes.c_int),
+                                     ctypes.POINTER(ctypes.c_uint), ctypes.c_uint, ctypes.POINTER(_CPlane), ctypes.c_float,
+                                     ctypes.POINTER(ctypes.c_float), ctypes.c_uint]
+    lib.j2p_tiled_destroy.argtypes = [ctypes.c_void_p]
+    lib.j2p_tiled_destroy.restype = None
+    lib.j2p_tiled_canvas.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint),
+                                     ctypes.POINTER(ctypes.c_uint)]
+    lib.j2p_tiled_band.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint),
+                                   ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_void_p)]
+    lib.j2p_tiled_run.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.POINTER(_CLogRow)]
+    lib.j2p_tiled_sync.argtypes = [ctypes.c_void_p]
+    lib.j2p_tiled_reset.argtypes = [ctypes.c_void_p]
+    lib.j2p_tiled_download.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p]
+    lib.j2p_batch_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint, ctypes.POINTER(ctypes.c_int), ctypes.c_uint]
+    lib.j2p_batch_destroy.argtypes = [ctypes.c_void_p]
+    lib.j2p_batch_destroy.restype = None
+    lib.j2p_batch_submit.argtypes = [ctypes.c_void_p, ctypes.POINTER(_CJob), ctypes.POINTER(ctypes.c_int)]
+    lib.j2p_batch_wait.argtypes = [ctypes.c_void_p, ctypes.c_int]
     _lib = lib
     return lib
 
@@ -231,9 +269,9 @@ class Solver:
         self.row_begin, self.row_end = r0.value, r1.value
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not getattr(self, "_borrowed", False):
             self._lib.j2p_solver_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         self.close()
@@ -305,6 +343,10 @@ class Solver:
         _check(self._lib.j2p_solver_plane_ptr(self._h, c, ctypes.byref(p)))
         return p.value
 
+    def debug_option(self, option, value):
+        """schedule switches (J2P_OPT_*): speed only, never results"""
+        _check(self._lib.j2p_solver_debug_option(self._h, int(option), int(value)))
+
     def enable_timing(self, every=1):
         """record HIP events around the two phase kernels of every `every`-th iteration (0 = off)."""
         _check(self._lib.j2p_solver_enable_timing(self._h, int(every)))
@@ -313,6 +355,152 @@ class Solver:
         g, p, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint()
         _check(self._lib.j2p_solver_kernel_times(self._h, ctypes.byref(g), ctypes.byref(p), ctypes.byref(n)))
         return g.value, p.value, n.value
+
+
+def _c_planes(planes):
+    keep = []
+    cpl = (_CPlane * len(planes))()
+    for i, p in enumerate(planes):
+        d = np.ascontiguousarray(p.data, dtype=np.int16)
+        q = np.ascontiguousarray(p.quant_table, dtype=np.uint16)
+        f = None if p.fdata is None else np.ascontiguousarray(p.fdata, dtype=np.float32)
+        keep += [d, q, f]
+        cpl[i] = _CPlane(p.w, p.h, p.w_samp, p.h_samp, d.ctypes.data, None if f is None else f.ctypes.data, q.ctypes.data)
+    return cpl, keep
+
+
+class TiledSolver:
+    """One plane set cut into row bands, band i on devices[i] (ids may repeat), driven from C by one host thread
+    per band (include/jpeg2png_amd.h: j2p_tiled_*).  cuts = band boundaries or None for near-equal bands."""
+
+    def __init__(self, planes, weight, pweight, iterations, devices, cuts=None):
+        lib = load_library()
+        self._lib = lib
+        self._h = None
+        self.nch = len(planes)
+        cpl, keep = _c_planes(planes)
+        n = len(devices)
+        devs = (ctypes.c_int * n)(*[int(d) for d in devices])
+        ccuts = None if cuts is None else (ctypes.c_uint * (n + 1))(*[int(c) for c in cuts])
+        pw = (ctypes.c_float * self.nch)(*[float(x) for x in pweight])
+        h = ctypes.c_void_p()
+        _check(lib.j2p_tiled_create(ctypes.byref(h), n, devs, ccuts, self.nch, cpl, float(weight), pw, int(iterations)))
+        self._h = h
+        del keep
+        W, H, nb = ctypes.c_uint(), ctypes.c_uint(), ctypes.c_uint()
+        _check(lib.j2p_tiled_canvas(h, ctypes.byref(W), ctypes.byref(H), ctypes.byref(nb)))
+        self.W, self.H, self.nband = W.value, H.value, nb.value
+
+    def bands(self):
+        out = []
+        for b in range(self.nband):
+            d, r0, r1 = ctypes.c_int(), ctypes.c_uint(), ctypes.c_uint()
+            _check(self._lib.j2p_tiled_band(self._h, b, ctypes.byref(d), ctypes.byref(r0), ctypes.byref(r1), None))
+            out.append((d.value, r0.value, r1.value))
+        return out
+
+    def run(self, n, log=False):
+        if not log:
+            _check(self._lib.j2p_tiled_run(self._h, n, None))
+            return None
+        rows = (_CLogRow * max(n, 1))()
+        _check(self._lib.j2p_tiled_run(self._h, n, rows))
+        return np.array([[r.objective, r.prob_dist, r.tv, r.tv2] for r in rows[:n]], dtype=np.float64).reshape(n, 4)
+
+    def sync(self):
+        _check(self._lib.j2p_tiled_sync(self._h))
+
+    def reset(self):
+        _check(self._lib.j2p_tiled_reset(self._h))
+
+    def band_solver(self, b):
+        """borrowed handle of band b's j2p_solver (kernel timing in bench.py); owned by the TiledSolver"""
+        h = ctypes.c_void_p()
+        _check(self._lib.j2p_tiled_band(self._h, b, None, None, None, ctypes.byref(h)))
+        s = Solver.__new__(Solver)
+        s._lib, s._h, s._borrowed = self._lib, h, True
+        return s
+
+    def download(self, c):
+        out = np.empty((self.H, self.W), dtype=np.float32)
+        _check(self._lib.j2p_tiled_download(self._h, c, out.ctypes.data))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.j2p_tiled_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class Batch:
+    """Images in flight over slots_per_device worker threads per GPU (include/jpeg2png_amd.h: j2p_batch_*).
+    submit() returns a ticket; wait(ticket) returns the job's output: RGB samples [h, w, 3] (bits 8 / 16) or the
+    list of float canvas planes (bits 0)."""
+
+    def __init__(self, devices=(0,), slots_per_device=3):
+        lib = load_library()
+        self._lib = lib
+        self._h = None
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        h = ctypes.c_void_p()
+        _check(lib.j2p_batch_create(ctypes.byref(h), len(devices), devs, int(slots_per_device)))
+        self._h = h
+        self._pending = {}
+
+    def submit(self, planes, weight, pweight, iterations, separate=False, width=None, height=None, bits=0):
+        n = len(planes)
+        job = _CJob()
+        job.nchannel = n
+        cpl, keep = _c_planes(planes)
+        for c in range(n):
+            job.planes[c] = cpl[c]
+        job.separate = 1 if separate else 0
+        ws = list(weight) if isinstance(weight, (list, tuple)) else [weight] * n
+        its = list(iterations) if isinstance(iterations, (list, tuple)) else [iterations] * n
+        for c in range(n):
+            job.weight[c], job.pweight[c], job.iterations[c] = float(ws[c]), float(pweight[c]), int(its[c])
+        W = max(p.w * p.w_samp for p in planes)
+        H = max(p.h * p.h_samp for p in planes)
+        if bits:
+            out = np.empty((height, width, 3), dtype=np.uint8 if bits == 8 else ">u2")
+            job.out_bits, job.out_w, job.out_h = bits, width, height
+            job.out_rgb = out.ctypes.data
+        else:
+            out = [np.empty((H, W), dtype=np.float32) for _ in range(n)]
+            for c in range(n):
+                job.out_planes[c] = out[c].ctypes.data
+        t = ctypes.c_int()
+        _check(self._lib.j2p_batch_submit(self._h, ctypes.byref(job), ctypes.byref(t)))
+        self._pending[t.value] = (out, keep)
+        return t.value
+
+    def wait(self, ticket):
+        out, _keep = self._pending.pop(ticket)
+        _check(self._lib.j2p_batch_wait(self._h, ticket))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.j2p_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def log_rows_from_sums(nch, weight, pweight, sums):

@@ -32,32 +32,50 @@ def _newer(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+HIP_UNITS = ("j2p_solver.hip", "j2p_tiled.hip", "j2p_batch.hip")
+HEADERS = ("j2p_kernels.hip.h", "j2p_internal.h")
+
+
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("build failed: " + " ".join(cmd))
+    if verbose and (r.stdout or r.stderr):
+        print(r.stdout + r.stderr)
+
+
 def build(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, f) for f in ("j2p_solver.hip", "j2p_kernels.hip.h", "compute_host.c")]
-    srcs += [os.path.join(INCLUDE, f) for f in ("jpeg2png_amd.h", "jpeg2png_amd_compute.h")]
-    srcs.append(os.path.abspath(__file__))
-    if not force and not _newer(LIB, srcs):
-        return LIB
+    units = [u for u in HIP_UNITS if os.path.exists(os.path.join(CSRC, u))]
+    common = [os.path.join(CSRC, f) for f in HEADERS]
+    common += [os.path.join(INCLUDE, f) for f in ("jpeg2png_amd.h", "jpeg2png_amd_compute.h")]
+    common.append(os.path.abspath(__file__))
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     gcc = shutil.which("gcc") or "gcc"
-    obj = os.path.join(CSRC, "compute_host.o")
-    hobj = os.path.join(CSRC, "j2p_solver.o")
-    cmds = [
-        [gcc, "-std=c11", "-O2", "-fPIC", "-Wall", "-Wextra", "-ffp-contract=off", "-I", INCLUDE,
-         "-c", os.path.join(CSRC, "compute_host.c"), "-o", obj],
-        [hipcc, *HIP_FLAGS, *os.environ.get("J2P_CXXFLAGS", "").split(), "-I", INCLUDE, "-I", CSRC, "-c",
-         os.path.join(CSRC, "j2p_solver.hip"), "-o", hobj],
-        [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", hobj, obj, "-lpthread", "-o", LIB],
-    ]
-    for cmd in cmds:
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            sys.stderr.write(r.stdout + r.stderr)
-            raise RuntimeError("build failed: " + " ".join(cmd))
-        if verbose and (r.stdout or r.stderr):
-            print(r.stdout + r.stderr)
+    objs = []
+    extra = os.environ.get("J2P_CXXFLAGS", "").split()
+    jobs = []
+    for u in units:
+        src, obj = os.path.join(CSRC, u), os.path.join(CSRC, u.replace(".hip", ".o"))
+        objs.append(obj)
+        # only j2p_solver.hip holds device code (it includes the kernels header); the others are host code
+        deps = [src] + (common if u == "j2p_solver.hip" else common[1:])
+        if force or _newer(obj, deps):
+            jobs.append([hipcc, *HIP_FLAGS, *extra, "-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj])
+    csrc, cobj = os.path.join(CSRC, "compute_host.c"), os.path.join(CSRC, "compute_host.o")
+    objs.append(cobj)
+    if force or _newer(cobj, [csrc] + common[1:]):
+        jobs.append([gcc, "-std=c11", "-O2", "-fPIC", "-Wall", "-Wextra", "-ffp-contract=off", "-I", INCLUDE, "-c", csrc, "-o", cobj])
+    if not jobs and not _newer(LIB, objs):
+        return LIB
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(lambda c: _run(c, verbose), jobs))
+    # SONAME so that programs linked with -ljpeg2png_amd find the library through their RUNPATH ($ORIGIN),
+    # wherever the checkout lives
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lpthread", "-Wl,-soname,libjpeg2png_amd.so", "-o", LIB], verbose)
     return LIB
 
 
@@ -79,7 +97,7 @@ def build_cli(force=False, verbose=False, prefix=None):
     # the image libraries are named by full path and found at run time through RUNPATH (direct
     # dependencies only), so that the HIP runtime keeps resolving libstdc++ from the system
     cmd = [gcc, "-std=c11", "-O2", "-Wall", "-Wextra", "-I", INCLUDE, "-I", os.path.join(prefix, "include"), src, "-o", CLI,
-           lib, os.path.join(plib, "libjpeg.so"), os.path.join(plib, "libpng16.so"), os.path.join(plib, "libz.so"), "-lpthread",
+           "-L", HERE, "-ljpeg2png_amd", os.path.join(plib, "libjpeg.so"), os.path.join(plib, "libpng16.so"), os.path.join(plib, "libz.so"), "-lpthread",
            "-Wl,--enable-new-dtags", "-Wl,-rpath-link,/usr/lib/x86_64-linux-gnu:/opt/rocm/lib",
            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + plib]
     if verbose:

@@ -28,11 +28,13 @@ static pthread_mutex_t progress_lock = PTHREAD_MUTEX_INITIALIZER;
 extern void logger_log(struct logger *log, double objective, double prob_dist, double tv, double tv2) __attribute__((weak));
 extern void progressbar_inc(struct progressbar *pb) __attribute__((weak));
 
-int j2p_compute(int device, unsigned nchannel, struct coef coefs[], struct logger *log,
-                struct progressbar *pb, float weight, const float pweight[], unsigned iterations)
+/* The loop of compute.c:427-453 over either engine: one j2p_solver (whole canvas on one GPU) or one j2p_tiled
+ * (row bands over several GPUs).  Same chunking, callbacks and hand-back either way. */
+static int compute_on(unsigned nband, const int devices[], unsigned nchannel, struct coef coefs[], struct logger *log,
+                      struct progressbar *pb, float weight, const float pweight[], unsigned iterations)
 {
         assert(FLT_ROUNDS == 1);                               /* compute.c:408 */
-        if(nchannel == 0 || nchannel > J2P_MAX_CHANNELS || !coefs || !pweight) { return J2P_EINVAL; }
+        if(nchannel == 0 || nchannel > J2P_MAX_CHANNELS || !coefs || !pweight || !devices || nband == 0) { return J2P_EINVAL; }
         j2p_plane planes[J2P_MAX_CHANNELS];
         for(unsigned c = 0; c < nchannel; c++) {
                 planes[c].w = coefs[c].w;
@@ -44,8 +46,14 @@ int j2p_compute(int device, unsigned nchannel, struct coef coefs[], struct logge
                 planes[c].quant_table = coefs[c].quant_table;
         }
         j2p_solver *s = NULL;
-        j2p_band whole = {0, 0};
-        int rc = j2p_solver_create(&s, device, NULL, nchannel, planes, weight, pweight, iterations, whole, 0);
+        j2p_tiled *t = NULL;
+        int rc;
+        if(nband > 1) {
+                rc = j2p_tiled_create(&t, nband, devices, NULL, nchannel, planes, weight, pweight, iterations);
+        } else {
+                j2p_band whole = {0, 0};
+                rc = j2p_solver_create(&s, devices[0], NULL, nchannel, planes, weight, pweight, iterations, whole, 0);
+        }
         if(rc != J2P_OK) { return rc; }
         /* aux_init frees the input planes as soon as they are up-sampled (compute.c:304-305) */
         for(unsigned c = 0; c < nchannel; c++) {
@@ -58,9 +66,9 @@ int j2p_compute(int device, unsigned nchannel, struct coef coefs[], struct logge
         while(done < iterations) {
                 unsigned n = iterations - done;
                 if(n > J2P_CHUNK) { n = J2P_CHUNK; }
-                rc = j2p_solver_run(s, n, want_log ? rows : NULL);
-                if(rc == J2P_OK && !want_log && pb) { rc = j2p_solver_sync(s); }
-                if(rc != J2P_OK) { j2p_solver_destroy(s); return rc; }
+                rc = t ? j2p_tiled_run(t, n, want_log ? rows : NULL) : j2p_solver_run(s, n, want_log ? rows : NULL);
+                if(rc == J2P_OK && !want_log && pb) { rc = t ? j2p_tiled_sync(t) : j2p_solver_sync(s); }
+                if(rc != J2P_OK) { goto out; }
                 for(unsigned i = 0; i < n; i++) {
                         if(log) { log->iteration = done + i; }                     /* compute.c:428 */
                         if(want_log) { logger_log(log, rows[i].objective, rows[i].prob_dist, rows[i].tv, rows[i].tv2); }
@@ -73,28 +81,75 @@ int j2p_compute(int device, unsigned nchannel, struct coef coefs[], struct logge
                 done += n;
         }
         unsigned W = 0, H = 0;
-        j2p_solver_canvas(s, &W, &H);
+        if(t) { j2p_tiled_canvas(t, &W, &H, NULL); } else { j2p_solver_canvas(s, &W, &H); }
         for(unsigned c = 0; c < nchannel; c++) {
                 size_t bytes = sizeof(float) * (size_t)W * H;
                 float *plane = aligned_alloc(16, (bytes + 15) & ~(size_t)15);      /* alloc_simd, utils.h:89-98 */
-                if(!plane) { j2p_solver_destroy(s); return J2P_ENOMEM; }
-                rc = j2p_solver_download(s, c, plane);
-                if(rc != J2P_OK) { free(plane); j2p_solver_destroy(s); return rc; }
+                if(!plane) { rc = J2P_ENOMEM; goto out; }
+                rc = t ? j2p_tiled_download(t, c, plane) : j2p_solver_download(s, c, plane);
+                if(rc != J2P_OK) { free(plane); goto out; }
                 coefs[c].fdata = plane;                                            /* compute.c:458 */
                 coefs[c].w = W;                                                    /* compute.c:459-460 */
                 coefs[c].h = H;
         }
-        j2p_solver_destroy(s);
-        return J2P_OK;
+out:
+        if(t) { j2p_tiled_destroy(t); }
+        if(s) { j2p_solver_destroy(s); }
+        return rc;
 }
+
+int j2p_compute(int device, unsigned nchannel, struct coef coefs[], struct logger *log,
+                struct progressbar *pb, float weight, const float pweight[], unsigned iterations)
+{
+        return compute_on(1, &device, nchannel, coefs, log, pb, weight, pweight, iterations);
+}
+
+int j2p_compute_tiled(unsigned nband, const int devices[], unsigned nchannel, struct coef coefs[], struct logger *log,
+                      struct progressbar *pb, float weight, const float pweight[], unsigned iterations)
+{
+        return compute_on(nband, devices, nchannel, coefs, log, pb, weight, pweight, iterations);
+}
+
+/* rows a band must at least have before compute() spreads a canvas over the GPUs of J2P_DEVICES: three 16-row
+ * gradient segments, so that every band has an interior to hide the halo exchange behind */
+#define J2P_MIN_BAND_ROWS (3u * J2P_TILE_ROWS)
 
 void compute(unsigned nchannel, struct coef coefs[], struct logger *log, struct progressbar *pb,
              float weight, float pweight[], unsigned iterations)
 {
-        int device = 0;
-        const char *env = getenv("J2P_DEVICE");
-        if(env && *env) { device = atoi(env); }
-        int rc = j2p_compute(device, nchannel, coefs, log, pb, weight, pweight, iterations);
+        /* J2P_DEVICE=n: that GPU.  J2P_DEVICES=a,b,...: the canvas is row-tiled over those GPUs when it is tall
+         * enough, otherwise (and for the other calls of a multi-threaded host) the first one is used. */
+        int devs[32];
+        unsigned ndev = 0;
+        const char *list = getenv("J2P_DEVICES");
+        if(list && *list) {
+                const char *p = list;
+                while(*p && ndev < 32) {
+                        char *end = NULL;
+                        long v = strtol(p, &end, 10);
+                        if(end == p) { break; }
+                        devs[ndev++] = (int)v;
+                        p = *end == ',' ? end + 1 : end;
+                }
+        }
+        if(ndev == 0) {
+                const char *env = getenv("J2P_DEVICE");
+                devs[ndev++] = (env && *env) ? atoi(env) : 0;
+        }
+        unsigned nband = 1;
+        if(ndev > 1 && coefs && nchannel >= 1 && nchannel <= J2P_MAX_CHANNELS) {
+                unsigned H = 0, align = J2P_TILE_ROWS;
+                for(unsigned c = 0; c < nchannel; c++) {
+                        if(coefs[c].h * coefs[c].h_samp > H) { H = coefs[c].h * coefs[c].h_samp; }
+                        while(coefs[c].h_samp && align % (8 * coefs[c].h_samp)) { align += J2P_TILE_ROWS; }
+                }
+                unsigned per = align > J2P_MIN_BAND_ROWS ? align : J2P_MIN_BAND_ROWS;
+                per = (per + align - 1) / align * align;
+                nband = H / per;
+                if(nband > ndev) { nband = ndev; }
+                if(nband < 1) { nband = 1; }
+        }
+        int rc = compute_on(nband, devs, nchannel, coefs, log, pb, weight, pweight, iterations);
         if(rc != J2P_OK) {
                 const char *msg = j2p_last_error();
                 /* die(), utils.c:20-28 */

@@ -1,0 +1,229 @@
+// jpeg2png_amd — image batches over streams and GPUs (BASELINE.json configs[4]; the file loop jpeg2png.c:330-337
+// and decode_file's compute calls, jpeg2png.c:141-152).
+//
+// A j2p_batch owns `slots_per_device` worker threads per GPU.  A job is one image — what decode_file() does
+// between read_jpeg() and write_png(): one joint compute(3, ...) or three separate compute(1, ...) calls, then the
+// planes handed back as floats or, converted on the device (png.c:37-62), as RGB samples.  Every worker drives its
+// jobs on streams of its own, so while one slot's image is being solved the next slot's coefficients go up and a
+// third one's pixels come down: H2D / solve / D2H overlap without any of them knowing about the others.  Device
+// memory comes from the library's pool (one arena per solver, recycled between jobs): after the first few images
+// a job performs no hipMalloc / hipFree — the device-wide synchronisation inside hipFree is what used to
+// serialise concurrent compute() calls.
+#include <hip/hip_runtime.h>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+#include <string.h>
+
+#include "jpeg2png_amd.h"
+#include "j2p_internal.h"
+
+namespace {
+
+struct Job {
+        j2p_job desc;
+        int ticket = 0;
+        int rc = J2P_OK;
+        bool finished = false;
+        char err[256] = "";
+};
+
+}  // namespace
+
+struct j2p_batch {
+        std::vector<int> worker_device;
+        std::vector<std::thread> workers;
+        std::mutex lock;
+        std::condition_variable work, finished;
+        std::deque<Job *> queue;
+        std::map<int, Job *> jobs;          // every job not yet collected by j2p_batch_wait
+        int next_ticket = 1;
+        bool quit = false;
+};
+
+namespace {
+
+constexpr unsigned kChunk = 32;         // iterations per round trip when a job wants progress or log rows
+
+#define JOB_TRY(expr)                                                                              \
+        do {                                                                                       \
+                rc = (expr);                                                                       \
+                if(rc != J2P_OK) { goto out; }                                                     \
+        } while(0)
+
+int run_job(const j2p_job &d, int device)
+{
+        j2p_solver *s[J2P_MAX_CHANNELS] = {nullptr, nullptr, nullptr};
+        unsigned nsolver = 0;
+        unsigned its[J2P_MAX_CHANNELS] = {0, 0, 0}, done[J2P_MAX_CHANNELS] = {0, 0, 0};
+        int rc = J2P_OK;
+        const j2p_band whole = {0, 0};
+        const bool chunked = d.on_rows || d.on_progress;
+        if(d.nchannel == 0 || d.nchannel > J2P_MAX_CHANNELS) { return j2p_fail(J2P_EINVAL, "job: nchannel must be 1..3"); }
+        if(d.out_bits != 0 && d.out_bits != 8 && d.out_bits != 16) { return j2p_fail(J2P_EINVAL, "job: out_bits must be 0, 8 or 16"); }
+        if(d.out_bits && (!d.out_rgb || d.nchannel != 3)) { return j2p_fail(J2P_EINVAL, "job: RGB output needs three channels and out_rgb"); }
+        if(d.separate) {
+                // jpeg2png.c:147-152: one compute(1, ...) per component, each with its own weight and iteration count
+                nsolver = d.nchannel;
+                for(unsigned c = 0; c < nsolver; c++) {
+                        its[c] = d.iterations[c];
+                        JOB_TRY(j2p_solver_create(&s[c], device, nullptr, 1, &d.planes[c], d.weight[c], &d.pweight[c], its[c], whole, 0));
+                }
+        } else {
+                // jpeg2png.c:144: compute(3, ...) with the first weight and iteration count
+                nsolver = 1;
+                its[0] = d.iterations[0];
+                JOB_TRY(j2p_solver_create(&s[0], device, nullptr, d.nchannel, d.planes, d.weight[0], d.pweight, its[0], whole, 0));
+        }
+        if(!chunked) {
+                for(unsigned c = 0; c < nsolver; c++) { JOB_TRY(j2p_solver_run(s[c], its[c], nullptr)); }
+        } else {
+                // compute.c:427-453 in chunks so that the caller's bar and CSV keep moving; without log rows the
+                // chunks of the (up to three) solvers are issued back to back and overlap on the GPU
+                j2p_log_row rows[kChunk];
+                for(;;) {
+                        unsigned step[J2P_MAX_CHANNELS] = {0, 0, 0};
+                        bool any = false;
+                        for(unsigned c = 0; c < nsolver; c++) {
+                                const unsigned left = its[c] - done[c];
+                                step[c] = left < kChunk ? left : kChunk;
+                                if(!step[c]) { continue; }
+                                any = true;
+                                JOB_TRY(j2p_solver_run(s[c], step[c], d.on_rows ? rows : nullptr));
+                                if(d.on_rows) { d.on_rows(d.user, d.separate ? c : 3u, done[c], step[c], rows); }   // channel 3 = joint, jpeg2png.c:143
+                        }
+                        if(!any) { break; }
+                        for(unsigned c = 0; c < nsolver; c++) {
+                                if(!step[c]) { continue; }
+                                if(!d.on_rows) { JOB_TRY(j2p_solver_sync(s[c])); }
+                                if(d.on_progress) { d.on_progress(d.user, step[c]); }
+                                done[c] += step[c];
+                        }
+                }
+        }
+        if(d.out_bits) {
+                j2p_plane_ref ref[3];
+                for(unsigned c = 0; c < 3; c++) {
+                        ref[c].solver = d.separate ? s[c] : s[0];
+                        ref[c].channel = d.separate ? 0 : c;
+                }
+                JOB_TRY(j2p_planes_to_rgb(ref, d.out_w, d.out_h, d.out_bits, d.out_rgb));
+        } else {
+                for(unsigned c = 0; c < d.nchannel; c++) {
+                        if(!d.out_planes[c]) { continue; }
+                        JOB_TRY(j2p_solver_download(d.separate ? s[c] : s[0], d.separate ? 0 : c, d.out_planes[c]));
+                }
+        }
+out:
+        for(unsigned c = 0; c < J2P_MAX_CHANNELS; c++) {
+                if(s[c]) { j2p_solver_destroy(s[c]); }
+        }
+        return rc;
+}
+
+void worker_main(j2p_batch *b, int device)
+{
+        (void)hipSetDevice(device);
+        for(;;) {
+                Job *job = nullptr;
+                {
+                        std::unique_lock<std::mutex> g(b->lock);
+                        b->work.wait(g, [&] { return b->quit || !b->queue.empty(); });
+                        if(b->queue.empty()) { return; }          // quit, and nothing left to do
+                        job = b->queue.front();
+                        b->queue.pop_front();
+                }
+                const int rc = run_job(job->desc, device);
+                {
+                        std::lock_guard<std::mutex> g(b->lock);
+                        job->rc = rc;
+                        if(rc != J2P_OK) { strncpy(job->err, j2p_last_error(), sizeof(job->err) - 1); }
+                        job->finished = true;
+                }
+                b->finished.notify_all();
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+int j2p_batch_create(j2p_batch **out, unsigned ndev, const int devices[], unsigned slots_per_device)
+{
+        if(!out || !devices) { return j2p_fail(J2P_EINVAL, "NULL argument"); }
+        *out = nullptr;
+        if(ndev == 0 || ndev > 64 || slots_per_device == 0 || slots_per_device > 16) {
+                return j2p_fail(J2P_EINVAL, "batch: 1..64 devices, 1..16 slots per device");
+        }
+        int have = 0;
+        if(hipGetDeviceCount(&have) != hipSuccess || have <= 0) {
+                return j2p_fail(J2P_EDEVICE, "no HIP device available: the jpeg2png_amd solver has no CPU fallback");
+        }
+        for(unsigned i = 0; i < ndev; i++) {
+                if(devices[i] < 0 || devices[i] >= have) { return j2p_fail(J2P_EINVAL, "device %d out of range (0..%d)", devices[i], have - 1); }
+        }
+        j2p_batch *b = new(std::nothrow) j2p_batch();
+        if(!b) { return j2p_fail(J2P_ENOMEM, "host allocation failed"); }
+        // slot-major order: the first ndev workers sit on different GPUs, so few images spread out first
+        for(unsigned k = 0; k < slots_per_device; k++) {
+                for(unsigned i = 0; i < ndev; i++) { b->worker_device.push_back(devices[i]); }
+        }
+        for(int dev : b->worker_device) { b->workers.emplace_back(worker_main, b, dev); }
+        *out = b;
+        return J2P_OK;
+}
+
+void j2p_batch_destroy(j2p_batch *b)
+{
+        if(!b) { return; }
+        {
+                std::lock_guard<std::mutex> g(b->lock);
+                b->quit = true;
+        }
+        b->work.notify_all();
+        for(std::thread &t : b->workers) { t.join(); }          // queued jobs are finished first
+        for(auto &kv : b->jobs) { delete kv.second; }
+        delete b;
+}
+
+int j2p_batch_submit(j2p_batch *b, const j2p_job *job, int *ticket)
+{
+        if(!b || !job || !ticket) { return j2p_fail(J2P_EINVAL, "NULL argument"); }
+        Job *j = new(std::nothrow) Job();
+        if(!j) { return j2p_fail(J2P_ENOMEM, "host allocation failed"); }
+        j->desc = *job;
+        {
+                std::lock_guard<std::mutex> g(b->lock);
+                if(b->quit) { delete j; return j2p_fail(J2P_ESTATE, "batch is shutting down"); }
+                j->ticket = b->next_ticket++;
+                b->jobs[j->ticket] = j;
+                b->queue.push_back(j);
+                *ticket = j->ticket;
+        }
+        b->work.notify_one();
+        return J2P_OK;
+}
+
+int j2p_batch_wait(j2p_batch *b, int ticket)
+{
+        if(!b) { return j2p_fail(J2P_EINVAL, "batch is NULL"); }
+        Job *j = nullptr;
+        {
+                std::unique_lock<std::mutex> g(b->lock);
+                auto it = b->jobs.find(ticket);
+                if(it == b->jobs.end()) { return j2p_fail(J2P_EINVAL, "unknown ticket %d", ticket); }
+                j = it->second;
+                b->finished.wait(g, [&] { return j->finished; });
+                b->jobs.erase(it);
+        }
+        const int rc = j->rc;
+        if(rc != J2P_OK) { j2p_fail(rc, "%s", j->err); }
+        delete j;
+        return rc;
+}
+
+}  // extern "C"

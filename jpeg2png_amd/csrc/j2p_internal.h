@@ -1,0 +1,11 @@
+// jpeg2png_amd — declarations shared by the translation units of libjpeg2png_amd.so; not part of the C-ABI.
+#pragma once
+#include "jpeg2png_amd.h"
+
+// error text of the calling thread (what j2p_last_error() returns); returns `code`
+int j2p_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// log rows from per-iteration sums like j2p_log_rows_from_sums(), but continuing a run: carried[] holds the prob
+// distance per channel of the state entering the first of the n iterations and is updated (all 0 at iteration 0)
+void j2p_rows_from_sums_carry(unsigned nch, float weight, const float *pweight, unsigned n, const double *sums,
+                              double *carried, j2p_log_row *rows);

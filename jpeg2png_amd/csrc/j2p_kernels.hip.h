@@ -171,6 +171,15 @@ struct GradArgs {
         float a_tgv;        // alpha/sqrt(nchannel) (compute.c:154)
         double *part_g2;    // [c][local tile row][tile col]
         double *part_tv;    // [local tile row][tile col][2]  (LOG only)
+        // norm reduction folded into this kernel (see fold_tile_row): the last strip to deliver its partial of a
+        // 16-row tile row sums that row's partials; the last tile row of the launch to finish runs the tree
+        unsigned *row_ticket;   // [local tile rows], zero between launches; NULL = no fold (separate kernels reduce)
+        unsigned *done_ticket;  // one counter, zero between launches
+        double *rowsum;         // [local tile row][channel]: the level-1 sums (what the bands of a tiled run exchange)
+        float *norm_out;        // [channel]; NULL = stop after level 1 (band solvers, canvases above kFoldMaxRows tile rows)
+        unsigned nch_total;     // channels of the solver (partials per strip and tile row)
+        unsigned fold_rows;     // tile rows this launch completes
+        unsigned ntr_global;    // tile rows of the whole canvas (length of the tree's input)
 };
 
 struct ProjArgs {
@@ -323,15 +332,9 @@ __device__ __forceinline__ v2f sqrt_fast(v2f x)
 }
 
 constexpr int kStripCols = 124;   // output columns per wavefront strip
-#ifndef J2P_RING
-#define J2P_RING 4
-#endif
-#ifndef J2P_RING_TURNS
-#define J2P_RING_TURNS 1
-#endif
-constexpr int kRingTurns = J2P_RING_TURNS;   // ring turns unrolled into one loop iteration
-constexpr int kRing = J2P_RING;   // row slots = hand-unroll factor of the marching loop (1 channel; 3 otherwise: registers);
-                                  // rows are fetched (slots - 1) trips ahead
+constexpr int kRing = 4;          // row slots = hand-unroll factor of the marching loop (1 channel; 3 otherwise: registers);
+                                  // rows are fetched (slots - 1) trips ahead (3 slots: 12 % slower; 2 or 5 ring turns per
+                                  // loop iteration: slower too)
 
 // compile-time description of a strip for k_gradient's march: `value` = it touches no image / band / coverage
 // edge (clamps and masks are the identity), `unit` = additionally every channel of the wavefront is sampled 1x1
@@ -547,21 +550,105 @@ __device__ __forceinline__ void source_terms_joint(int cidx, int lane, int parit
         }
 }
 
-#ifndef J2P_GRAD_WAVES1
-#define J2P_GRAD_WAVES1 4      // waves per SIMD the 1-channel gradient kernel is register-limited to
-#endif
-#ifndef J2P_GRAD_WAVES3
-#define J2P_GRAD_WAVES3 2
-#endif
+// ---------------------------------------------------------------------------
+// Norm reduction folded into k_gradient (no separate launch, nothing serial between the two phases).
+// Same arithmetic as strip_sum / tree_sum_lds below — a fixed function of the partial array, whoever
+// evaluates it — so the norm is bit-identical to the stand-alone kernels' and independent of the order in
+// which wavefronts arrive.  Cross-workgroup hand-over: writer = store, release fence, ticket; last arriver =
+// ticket, acquire fence, loads (agent scope: the XCDs' L2s are not coherent with each other otherwise).
+// ---------------------------------------------------------------------------
+constexpr unsigned kFoldMaxRows = 1024;      // tile rows the in-kernel tree handles (canvas height <= 16384)
+
+// lanes 8c..8c+7 of the calling wavefront: the eight interleaved running sums of strip_sum for channel c
+__device__ __forceinline__ void fold_tile_row(const GradArgs &a, unsigned tr, size_t nparts, int lane)
+{
+        const unsigned ntx = a.geo.ntx, nch = a.nch_total;
+        const int c = lane >> 3, j = lane & 7;
+        double s = 0.;
+        if(c < (int)nch) {
+                const double *p = a.part_g2 + (size_t)c * nparts + (size_t)tr * ntx;
+                // element i belongs to running sum i % 8, added in increasing i (strip_sum's order); loads batched
+                for(unsigned i0 = (unsigned)j; i0 < ntx; i0 += 64) {
+                        double v[8];
+#pragma unroll
+                        for(int u = 0; u < 8; u++) {
+                                const unsigned i = i0 + 8u * u;
+                                v[u] = __hip_atomic_load(p + (i < ntx ? i : i0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+#pragma unroll
+                        for(int u = 0; u < 8; u++) {
+                                if(i0 + 8u * u < ntx) { s += v[u]; }
+                        }
+                }
+        }
+        // ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)), evaluated by the lane with j == 0
+        double t[8];
+#pragma unroll
+        for(int u = 0; u < 8; u++) { t[u] = __shfl(s, (lane & ~7) + u, 64); }
+        const double sum = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        if(j == 0 && c < (int)nch) {
+                __hip_atomic_store(a.rowsum + (size_t)tr * nch + c, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+}
+
+// one wavefront: norm[c] = sqrtf((float) tree(rowsums of channel c))  (compute.c:200-207); buf >= P doubles of LDS
+__device__ __forceinline__ void fold_tree(const GradArgs &a, double *buf, int lane)
+{
+        const unsigned n = a.ntr_global, nch = a.nch_total;
+        unsigned P = 1;
+        while(P < n) { P <<= 1; }
+        for(unsigned c = 0; c < nch; c++) {
+                for(unsigned i = (unsigned)lane; i < P; i += 64) {
+                        buf[i] = i < n ? __hip_atomic_load(a.rowsum + (size_t)i * nch + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.;
+                }
+                for(unsigned st = P >> 1; st > 0; st >>= 1) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        for(unsigned i = (unsigned)lane; i < st; i += 64) { buf[i] = buf[i] + buf[i + st]; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if(lane == 0) { a.norm_out[c] = sqrtf((float)buf[0]); }
+                __builtin_amdgcn_wave_barrier();
+        }
+}
+
+// called by a wavefront that has just stored `mine` partials of tile row tr (wave-uniform arguments)
+__device__ __forceinline__ void fold_arrive(const GradArgs &a, unsigned tr, unsigned mine, size_t nparts, double *buf, int lane)
+{
+        unsigned old = 0;
+        if(lane == 0) { old = __hip_atomic_fetch_add(a.row_ticket + tr, mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+        old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+        if(old + mine != a.geo.ntx * a.nch_total) { return; }
+        // last strip of this tile row: everybody else's partials are visible after the acquire
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        fold_tile_row(a, tr, nparts, lane);
+        if(lane == 0) { __hip_atomic_store(a.row_ticket + tr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // ready for the next launch
+        if(!a.norm_out) { return; }
+        unsigned done = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");           // the row sums of lanes 0, 8, 16 before the ticket
+        if(lane == 0) { done = __hip_atomic_fetch_add(a.done_ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+        done = (unsigned)__builtin_amdgcn_readfirstlane((int)done);
+        if(done + 1 != a.fold_rows) { return; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        fold_tree(a, buf, lane);
+        if(lane == 0) { __hip_atomic_store(a.done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}
+
+constexpr int kGradWaves1 = 4;    // waves per SIMD the 1-channel gradient kernel is register-limited to (5 needs <= 96 VGPRs: spills)
+constexpr int kGradWaves3 = 2;    // ... the three-channels-in-one-wavefront schedule
 // NCH channels are handled inside one wavefront (J == 1, workgroup = 4 strips), or — for a
 // jointly optimised image — J wavefronts of a workgroup take one channel each of the same strip
 // and only exchange their norm contributions through LDS (J > 1, NCH == 1).
 template <int NCH, bool TGV, bool LOG, int J = 1>
-__global__ __launch_bounds__((J == 1 ? 256 : 64 * J), (NCH == 1 ? J2P_GRAD_WAVES1 : NCH == 2 ? 3 : J2P_GRAD_WAVES3))
+__global__ __launch_bounds__((J == 1 ? 256 : 64 * J), (NCH == 1 ? kGradWaves1 : NCH == 2 ? 3 : kGradWaves3))
 void k_gradient(GradArgs a)
 {
         static_assert(J == 1 || NCH == 1, "channel-per-wavefront mode keeps one channel per wavefront");
         __shared__ __attribute__((aligned(16))) v2f xchg[J == 1 ? 1 : 2 * J * 64 * 3];
+        __shared__ double fold_buf[kFoldMaxRows];               // the norm tree of the launch's last wavefront
         const int lane = (int)threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // uniform: keeps row/strip arithmetic scalar
         // XCD-aware order (speed only): workgroup b runs on XCD b % 8, so give every XCD a contiguous,
@@ -644,9 +731,6 @@ void k_gradient(GradArgs a)
                 constexpr unsigned kLo = 0x35800000u, kHi = 0x54000000u;      // bits of 2^-20 and 2^41
                 const unsigned long long out_of_range = __builtin_amdgcn_ballot_w64(hi >= kHi) | __builtin_amdgcn_ballot_w64(lo < kLo - 1u);
                 suspect = (unsigned)out_of_range | (unsigned)(out_of_range >> 32);   // wave-uniform, non-zero = suspect
-#ifdef J2P_FORCE_IEEE_GRADIENT   /* debugging aid: every row of phase A on the plain `/` + sqrtf() path */
-                suspect = 1u;
-#endif
         };
         // forward differences of row gr given rows gr and gr+1 (compute.c:79,81)
         auto diffs = [&](auto free_tag, int gr, const v2f (&yc)[NCH], const v2f (&yn)[NCH], v2f (&gx)[NCH], v2f (&gy)[NCH]) {
@@ -702,6 +786,9 @@ void k_gradient(GradArgs a)
         };
 
         double tv_acc = 0., tv2_acc = 0.;
+        double g2[NCH];                                  // sum of g*g over the strip's rows (one 16-row tile row)
+#pragma unroll
+        for(int c = 0; c < NCH; c++) { g2[c] = 0.; }
         const size_t ntiles_row = a.geo.ntx;
         const size_t nparts = (size_t)((rows + kTY - 1) / kTY) * ntiles_row;
         constexpr int R = NCH == 1 ? kRing : 3;
@@ -733,11 +820,6 @@ void k_gradient(GradArgs a)
                         bad1 = b0;
                         diffs(free_tag, row0 + t0 - 2, ym, Y[0], GX[R - 1], GY[R - 1]);
                 }
-                double g2[NCH];
-        #pragma unroll
-                for(int c = 0; c < NCH; c++) { g2[c] = 0.; }
-                int next_flush = (t0 | (kTY - 1)) < t1 - 1 ? (t0 | (kTY - 1)) : t1 - 1;   // last row of the first tile row
-
                 // one trip: source terms of row r into slot P, then target row r-1
                 auto trip = [&](auto phase, int r) {
                         constexpr int P = decltype(phase)::value, P1 = (P + 1) % R, PM1 = (P + R - 1) % R, PM2 = (P + R - 2) % R;
@@ -807,19 +889,6 @@ void k_gradient(GradArgs a)
                                                 g2[c] += (double)sq.y;
                                         }
                                 }
-                                // one partial per 16-row tile row and strip: the granularity of the GPU-count
-                                // invariant norm reduction
-                                if(t == next_flush) {                 // (t & 15) == 15 || t == t1 - 1, as one compare
-        #pragma unroll
-                                        for(int c = 0; c < NCH; c++) {
-                                                double v = g2[c];
-        #pragma unroll
-                                                for(int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); }
-                                                if(lane == 0) { a.part_g2[(cbase + c) * nparts + (size_t)(t / kTY) * ntiles_row + wcol] = v; }
-                                                g2[c] = 0.;
-                                        }
-                                        next_flush = t + kTY < t1 - 1 ? t + kTY : t1 - 1;
-                                }
                         }
                 };
 
@@ -840,16 +909,8 @@ void k_gradient(GradArgs a)
                         }
                         return r + R <= t1;
                 };
-                // kRingTurns turns per loop iteration: the compiler drains every outstanding load at the loop
-                // header (s_waitcnt vmcnt(0)), so the fewer headers a strip passes, the fewer times its prefetched
-                // rows have to land all at once
-                for(int r = t0 - 1; r <= t1; r += R * kRingTurns) {
-                        bool more = true;
-        #pragma unroll
-                        for(int u = 0; u < kRingTurns; u++) {
-                                if(more) { more = ring(r + u * R); }
-                        }
-                        if(!more) { break; }
+                for(int r = t0 - 1; r <= t1; r += R) {
+                        if(!ring(r)) { break; }
                 }
         };
         {
@@ -870,6 +931,20 @@ void k_gradient(GradArgs a)
                 if(__builtin_amdgcn_readfirstlane(unit ? 1 : 0)) { march(MarchTag<true, true>{}); }
                 else if(__builtin_amdgcn_readfirstlane(seg_free ? 1 : 0)) { march(MarchTag<true, false>{}); }
                 else { march(MarchTag<false, false>{}); }
+        }
+        // One partial per strip and 16-row tile row — a segment IS one tile row — the granularity of the
+        // GPU-count invariant norm reduction; then the strip reports in (fold_arrive) and, if it is the last
+        // of its tile row / of the launch, finishes the reduction.
+        {
+                const unsigned tr = (unsigned)t0 / kTY;
+#pragma unroll
+                for(int c = 0; c < NCH; c++) {
+                        double v = g2[c];
+#pragma unroll
+                        for(int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); }
+                        if(lane == 0) { a.part_g2[(cbase + c) * nparts + (size_t)tr * ntiles_row + wcol] = v; }
+                }
+                if(a.row_ticket) { fold_arrive(a, tr, (unsigned)NCH, nparts, fold_buf, lane); }
         }
         if(LOG) {
 #pragma unroll
@@ -1010,6 +1085,54 @@ __global__ __launch_bounds__(256) void k_norm_whole(const double *part, unsigned
         (void)nch;
 }
 
+// ---------------------------------------------------------------------------
+// Row-tiled runs inside one process (j2p_tiled): the two per-iteration exchanges as kernels that READ the other
+// bands' memory directly (peer access over xGMI, or plain device memory when bands share a GPU).
+// ---------------------------------------------------------------------------
+constexpr int kMaxBands = 32;
+struct BandRowsums {
+        const double *rowsum[kMaxBands];   // band b's [tile row][channel] level-1 sums (GradArgs::rowsum)
+        unsigned first[kMaxBands];         // its first global tile row
+        unsigned count[kMaxBands];         // its tile rows
+        unsigned nband;
+};
+
+// level 2 of the norm reduction over the bands' row sums: the same padded pairwise tree as k_norm_finish over the
+// same global array, so the norm — and the result — does not depend on how the canvas was cut.  One block per channel.
+__global__ __launch_bounds__(256) void k_norm_bands(BandRowsums t, unsigned nrows_global, unsigned nch, float *norm)
+{
+        extern __shared__ __attribute__((aligned(16))) float smem[];
+        double *buf = reinterpret_cast<double *>(smem);
+        unsigned P = 1;
+        while(P < nrows_global) { P <<= 1; }
+        const unsigned c = blockIdx.x;
+        for(unsigned i = threadIdx.x; i < P; i += 256) { buf[i] = 0.; }
+        __syncthreads();
+        for(unsigned b = 0; b < t.nband; b++) {
+                const double *src = t.rowsum[b];
+                for(unsigned i = threadIdx.x; i < t.count[b]; i += 256) { buf[t.first[b] + i] = src[(size_t)i * nch + c]; }
+        }
+        const double s = tree_sum_lds(buf, nrows_global, P);
+        if(threadIdx.x == 0) { norm[c] = sqrtf((float)s); }
+}
+
+// up to 2 * kMaxCh row blocks copied into this band's halo rows from the neighbours' edge rows
+struct RowCopies {
+        float *dst[2 * kMaxCh];
+        const float *src[2 * kMaxCh];
+        unsigned n;
+        unsigned floats;                   // per copy; a multiple of 2 (W is even)
+};
+__global__ __launch_bounds__(256) void k_copy_rows(RowCopies t)
+{
+        const unsigned pairs = t.floats / 2;
+        for(unsigned k = 0; k < t.n; k++) {
+                const v2f *src = reinterpret_cast<const v2f *>(t.src[k]);
+                v2f *dst = reinterpret_cast<v2f *>(t.dst[k]);
+                for(unsigned i = blockIdx.x * 256 + threadIdx.x; i < pairs; i += gridDim.x * 256) { dst[i] = src[i]; }
+        }
+}
+
 // log sums: tv / tv2 from the gradient tiles and per-channel prob distance from the
 // projection strips, plain fixed-order tree (values only feed the CSV log)
 __global__ __launch_bounds__(256) void k_log_sums(const double *part_tv, unsigned ntiles,
@@ -1060,9 +1183,6 @@ __device__ __forceinline__ float stepped(const ChanDev &k, ptrdiff_t off, float 
 // numerator screen of the short division: 0 < |x| < 2^-100, |x| >= 2^61, or NaN
 __device__ __forceinline__ bool num_suspect(v2f x)
 {
-#ifdef J2P_FORCE_IEEE_PROJECT    /* debugging aid: every division of phase B on the plain `/` path */
-        return true;
-#endif
         return !(in_fast_range(x.x, 0x1p-100f, 0x1p61f) && in_fast_range(x.y, 0x1p-100f, 0x1p61f));
 }
 __device__ __forceinline__ bool den_ok(float d) { return d >= 0x1p-20f && d <= 0x1p26f; }

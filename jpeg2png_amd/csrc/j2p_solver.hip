@@ -11,9 +11,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 
 #include "jpeg2png_amd.h"
+#include "j2p_internal.h"
 #include "j2p_kernels.hip.h"
 
 using namespace j2p;
@@ -30,6 +32,19 @@ int fail(int code, const char *fmt, ...)
         va_end(l);
         return code;
 }
+
+}  // namespace
+
+int j2p_fail(int code, const char *fmt, ...)
+{
+        va_list l;
+        va_start(l, fmt);
+        vsnprintf(g_err, sizeof(g_err), fmt, l);
+        va_end(l);
+        return code;
+}
+
+namespace {
 
 #define HIP_TRY(expr)                                                                              \
         do {                                                                                       \
@@ -74,7 +89,13 @@ struct j2p_solver {
         int cur = 0;             // xbuf[cur] is x_k
         bool grad_done = false;
         bool proj_boundary_done = false;   // between the two parts of a split projection phase
+        void *arena = nullptr;   // the one device allocation everything below is carved from (pooled, see pool_take)
+        size_t arena_bytes = 0;
         // reductions
+        bool fold = true;        // norm reduction folded into k_gradient (J2P_OPT_NORM_FOLD)
+        bool joint_inwave = false;   // J2P_OPT_JOINT_INWAVE
+        bool norm_ready = false; // the gradient launch of this iteration also produced norm[]
+        unsigned *tickets = nullptr;     // device: [ntr_local] per-tile-row arrival counters + [1] finished-rows counter
         unsigned rpw = 16;
         unsigned *seg_row = nullptr;     // device: [nseg + 1] segment start rows
         unsigned *seg_map = nullptr;     // device: [nseg] identity, then [nseg - 2] interior, then [2] first/last
@@ -117,6 +138,88 @@ struct DeviceGuard {
         ~DeviceGuard()
         {
                 if(prev >= 0) { (void)hipSetDevice(prev); }
+        }
+};
+
+// ---------------------------------------------------------------------------
+// Device-memory pool.  hipMalloc / hipFree cost milliseconds and hipFree synchronises the whole device, which
+// serialises the concurrent compute() calls of a multi-threaded host (jpeg2png.c:147,330) far more than the
+// solves themselves at 1080p.  A solver therefore makes ONE allocation (its arena) and returns it here when it
+// is destroyed; the next solver on that device takes the smallest cached block that fits.  Bounded: at most
+// kPoolBlocks blocks / kPoolBytes bytes stay cached per process, the rest is released; j2p_pool_trim() drops all.
+// ---------------------------------------------------------------------------
+struct PoolBlock {
+        int device;
+        void *ptr;
+        size_t bytes;
+};
+std::mutex g_pool_lock;
+std::vector<PoolBlock> g_pool;
+constexpr size_t kPoolBlocks = 32;
+constexpr size_t kPoolBytes = (size_t)24 << 30;
+
+hipError_t pool_take(int device, size_t bytes, void **out, size_t *got)
+{
+        {
+                std::lock_guard<std::mutex> g(g_pool_lock);
+                size_t best = g_pool.size();
+                for(size_t i = 0; i < g_pool.size(); i++) {
+                        const PoolBlock &b = g_pool[i];
+                        // a block more than twice the size asked for stays for a larger customer
+                        if(b.device == device && b.bytes >= bytes && b.bytes <= 2 * bytes + (1u << 20) &&
+                           (best == g_pool.size() || b.bytes < g_pool[best].bytes)) { best = i; }
+                }
+                if(best != g_pool.size()) {
+                        *out = g_pool[best].ptr;
+                        *got = g_pool[best].bytes;
+                        g_pool.erase(g_pool.begin() + (ptrdiff_t)best);
+                        return hipSuccess;
+                }
+        }
+        hipError_t e = hipMalloc(out, bytes);
+        if(e == hipErrorOutOfMemory) {
+                // give the cache back to the device and try once more
+                std::vector<PoolBlock> drop;
+                {
+                        std::lock_guard<std::mutex> g(g_pool_lock);
+                        drop.swap(g_pool);
+                }
+                for(const PoolBlock &b : drop) {
+                        DeviceGuard guard(b.device);
+                        (void)hipFree(b.ptr);
+                }
+                (void)hipGetLastError();
+                e = hipMalloc(out, bytes);
+        }
+        *got = bytes;
+        return e;
+}
+
+void pool_give(int device, void *ptr, size_t bytes)
+{
+        if(!ptr) { return; }
+        {
+                std::lock_guard<std::mutex> g(g_pool_lock);
+                size_t total = bytes;
+                for(const PoolBlock &b : g_pool) { total += b.bytes; }
+                if(g_pool.size() < kPoolBlocks && total <= kPoolBytes) {
+                        g_pool.push_back(PoolBlock{device, ptr, bytes});
+                        return;
+                }
+        }
+        (void)hipFree(ptr);
+}
+
+// bump allocator over the arena: pass 1 (base == nullptr) only adds the sizes up
+struct Carver {
+        char *base = nullptr;
+        size_t used = 0;
+        template <typename T>
+        void take(T *&p, size_t count)
+        {
+                used = (used + 255) & ~(size_t)255;
+                p = base ? reinterpret_cast<T *>(base + used) : nullptr;
+                used += count * sizeof(T);
         }
 };
 
@@ -163,7 +266,7 @@ template <int NCH, int J>
 void launch_gradient_n(const GradArgs &a, unsigned ntx, unsigned nseg, hipStream_t st, bool tgv, bool log)
 {
         // J == 1: 4 strips per 256-thread workgroup; J > 1: one strip per workgroup of J wavefronts
-        static const unsigned wpb = getenv("J2P_GRAD_WPB") ? (unsigned)atoi(getenv("J2P_GRAD_WPB")) : 4u;   // strips per workgroup
+        constexpr unsigned wpb = 4;     // strips per workgroup
         const dim3 grid = J == 1 ? dim3((ntx + wpb - 1) / wpb, nseg) : dim3(ntx, nseg);
         const dim3 block = J == 1 ? dim3(64 * wpb) : dim3(64 * J);
         if(tgv) {
@@ -262,14 +365,23 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         a.a_tgv = (float)((double)alpha * 1. / (double)sqrtf((float)s->nch));   // compute.c:154
         a.part_g2 = s->part_g2;
         a.part_tv = s->part_tv;
+        // the norm reduction rides on this launch: level 1 (row sums) always, level 2 (tree -> norm) when the
+        // launch covers the whole canvas
+        const bool fold_norm = s->fold && s->whole && part == 0 && s->ntr_global <= kFoldMaxRows;
+        a.row_ticket = s->fold ? s->tickets : nullptr;
+        a.done_ticket = s->tickets + s->ntr_local;
+        a.rowsum = s->rowsum_local;
+        a.norm_out = fold_norm ? s->norm : nullptr;
+        a.nch_total = s->nch;
+        a.fold_rows = s->ntr_local;
+        a.ntr_global = s->ntr_global;
         const bool tgv = s->weight != 0.f;
         if(part != 2) { mark(s); }     // event timing covers the main launch only (the edge part runs on another stream)
         // joint images: one wavefront per channel, the norms exchanged through LDS (three times the
         // wavefronts at 4 per SIMD), beats all channels in one wavefront (248 VGPRs, 2 per SIMD) at every
         // size measured: 198 vs 293 us at 12 Mpixel 4:2:0, 494 vs 717 us at 36 Mpixel.  J2P_JOINT_INWAVE=1
         // selects the in-wavefront kernel (kept: it is the same arithmetic in another schedule, and tested).
-        const char *jenv = getenv("J2P_JOINT_INWAVE");
-        const bool inwave = jenv ? atoi(jenv) != 0 : false;
+        const bool inwave = s->joint_inwave;
         switch(s->nch) {
         case 1: launch_gradient_n<1, 1>(a, s->ntx, nseg_launch, st, tgv, log); break;
         case 2:
@@ -288,12 +400,13 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
                 return J2P_OK;
         }
         s->interior_done = false;
-        if(part == 0 && !s->whole) {
+        s->norm_ready = fold_norm;
+        if(part == 0 && !s->whole && !s->fold) {
                 launch_rowsums(s);
                 HIP_TRY(hipGetLastError());
         }
         s->grad_done = true;
-        s->rowsums_pending = part == 2 && !s->whole;
+        s->rowsums_pending = part == 2 && !s->whole && !s->fold;
         // band sums for the CSV row: behind the last launch of the phase (for a split phase that is
         // j2p_solver_phase_rowsums(), once the solver's stream has joined the edge part)
         s->bandlog_pending = false;
@@ -330,8 +443,12 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
         if(part != 2 && s->proj_boundary_done) { return fail(J2P_ESTATE, "boundary part of phase_project issued twice"); }
         unsigned P = 1;
         while(P < s->ntr_global) { P <<= 1; }
-        if(part == 2) {
+        if(part == 2 || s->norm_ready) {
                 // the norm is already there
+        } else if(s->fold) {
+                // level 1 came with the gradient launch (band solvers: the caller has gathered all bands' row sums)
+                hipLaunchKernelGGL(k_norm_finish, dim3(s->nch), dim3(256), P * sizeof(double), s->stream,
+                                   (const double *)s->rowsum_all, s->ntr_global, s->nch, s->norm);
         } else if(s->whole) {
                 // stage as many of the partials at once as the CU's LDS holds (P <= 4096)
                 unsigned stage = 0;                                  // narrow canvases: direct form (4.6 vs 5.4 us at 4096^2)
@@ -426,6 +543,7 @@ int launch_init(j2p_solver *s)
         s->grad_done = false;
         s->interior_done = false;
         s->rowsums_pending = false;
+        s->norm_ready = false;
         s->proj_boundary_done = false;
         s->bandlog_pending = false;
         for(unsigned c = 0; c < kMaxCh; c++) { s->carried_prob[c] = 0.; }
@@ -454,29 +572,25 @@ void j2p_solver_destroy(j2p_solver *s)
         if(!s) { return; }
         DeviceGuard guard(s->device);
         if(s->stream) { (void)hipStreamSynchronize(s->stream); }
-        for(unsigned c = 0; c < kMaxCh; c++) {
-                ChanHost &h = s->ch[c];
-                (void)hipFree(h.xbuf[0]);
-                (void)hipFree(h.xbuf[1]);
-                (void)hipFree(h.grad);
-                (void)hipFree(h.pg);
-                (void)hipFree(h.d);
-                (void)hipFree(h.q);
-                (void)hipFree(h.decoded);
-        }
-        (void)hipFree(s->part_g2);
-        (void)hipFree(s->seg_row);
-        (void)hipFree(s->seg_map);
-        (void)hipFree(s->rowsum_local);
-        if(s->rowsum_all != s->rowsum_local) { (void)hipFree(s->rowsum_all); }
-        (void)hipFree(s->norm);
-        (void)hipFree(s->part_tv);
-        (void)hipFree(s->part_prob);
+        pool_give(s->device, s->arena, s->arena_bytes);
         (void)hipFree(s->logsums);
         (void)hipFree(s->log_band);
         for(hipEvent_t e : s->ev) { (void)hipEventDestroy(e); }
         if(s->own_stream && s->stream) { (void)hipStreamDestroy(s->stream); }
         delete s;
+}
+
+void j2p_pool_trim(void)
+{
+        std::vector<PoolBlock> drop;
+        {
+                std::lock_guard<std::mutex> g(g_pool_lock);
+                drop.swap(g_pool);
+        }
+        for(const PoolBlock &b : drop) {
+                DeviceGuard guard(b.device);
+                (void)hipFree(b.ptr);
+        }
 }
 
 int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchannel, const j2p_plane planes[],
@@ -517,7 +631,8 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         DeviceGuard guard(device);
         if(!guard.ok) { return fail(J2P_EDEVICE, "hipSetDevice(%d) failed", device); }
 
-        // k_norm_whole stages the norm partials in up to 156 KiB of dynamic LDS (per device: idempotent)
+        // k_norm_whole (only the A/B baseline of the folded reduction, J2P_OPT_NORM_FOLD = 0) stages the norm
+        // partials in up to 156 KiB of dynamic LDS (per device: idempotent)
         if(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_norm_whole), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)kNormLdsBytes) != hipSuccess) {
                 return fail(J2P_EDEVICE, "hipFuncSetAttribute(k_norm_whole, %u bytes of LDS) failed", kNormLdsBytes);
@@ -534,6 +649,12 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         s->band_local = !whole && band_local_arrays != 0;
         s->weight = weight;
         s->iterations = iterations;
+        {
+                // the one schedule switch tests reach through the environment (read once, here): all channels of a
+                // joint image inside one wavefront instead of one wavefront per channel — same bits, slower
+                const char *env = getenv("J2P_JOINT_INWAVE");
+                s->joint_inwave = env && atoi(env) != 0;
+        }
         int rc = J2P_OK;
 #define CREATE_TRY(expr)                                                                           \
         do {                                                                                       \
@@ -551,7 +672,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 s->own_stream = true;
         }
 
-        const size_t plane_floats = (size_t)(s->rows + 2 * kHalo) * W;
+        // ---- geometry of every buffer ----
         for(unsigned c = 0; c < nchannel; c++) {
                 const j2p_plane &p = planes[c];
                 ChanHost &h = s->ch[c];
@@ -582,108 +703,15 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                         h.frow0 = f0;
                         h.frows = f1 - f0;
                 }
-                CREATE_TRY(hipMalloc(&h.xbuf[0], plane_floats * sizeof(float)));
-                CREATE_TRY(hipMalloc(&h.xbuf[1], plane_floats * sizeof(float)));
-                CREATE_TRY(hipMalloc(&h.grad, (size_t)s->rows * W * sizeof(float)));
-                CREATE_TRY(hipMalloc(&h.q, 64 * sizeof(float)));
-                CREATE_TRY(hipMalloc(&h.decoded, (size_t)h.frows * h.cw * sizeof(float)));
-                // the prob state always has at least one (zero) row: the gradient kernel reads it unconditionally
-                CREATE_TRY(hipMalloc(&h.pg, (size_t)(h.crows ? h.crows : 1) * h.cw * sizeof(float)));
-                CREATE_TRY(hipMemset(h.pg, 0, (size_t)(h.crows ? h.crows : 1) * h.cw * sizeof(float)));
-                if(h.crows) { CREATE_TRY(hipMalloc(&h.d, (size_t)h.crows * h.cw * sizeof(int16_t))); }
-                float qf[64];
-                for(int j = 0; j < 64; j++) { qf[j] = (float)p.quant_table[j]; }
-                CREATE_TRY(hipMemcpy(h.q, qf, sizeof(qf), hipMemcpyHostToDevice));
-                // host arrays: whole-image unless band_local
-                const size_t host_row0 = s->band_local ? h.crow0 : 0;
-                if(h.crows) {
-                        // block-major: coefficient row r lives in block row r/8; rows are block aligned
-                        const int16_t *src = p.data + (size_t)(h.crow0 - host_row0) * h.cw;
-                        CREATE_TRY(hipMemcpy(h.d, src, (size_t)h.crows * h.cw * sizeof(int16_t), hipMemcpyHostToDevice));
-                }
-                if(p.fdata) {
-                        const float *src = p.fdata + (size_t)(h.frow0 - host_row0) * h.cw;
-                        CREATE_TRY(hipMemcpy(h.decoded, src, (size_t)h.frows * h.cw * sizeof(float), hipMemcpyHostToDevice));
-                } else {
-                        // decode on the device (jpeg.c:83-92 + box.c:5-19); needs block-aligned row window
-                        const unsigned b0 = h.frow0 / 8, b1 = (h.frow0 + h.frows + 7) / 8;
-                        const size_t nb_rows = b1 - b0;
-                        int16_t *dtmp = nullptr;
-                        float *ftmp = nullptr;
-                        CREATE_TRY(hipMalloc(&dtmp, nb_rows * 8 * h.cw * sizeof(int16_t)));
-                        hipError_t e2 = hipMalloc(&ftmp, nb_rows * 8 * h.cw * sizeof(float));
-                        if(e2 != hipSuccess) { (void)hipFree(dtmp); CREATE_TRY(e2); }
-                        const int16_t *src = p.data + (size_t)(b0 * 8 - host_row0) * h.cw;
-                        hipError_t e3 = hipMemcpy(dtmp, src, nb_rows * 8 * h.cw * sizeof(int16_t), hipMemcpyHostToDevice);
-                        if(e3 == hipSuccess) {
-                                const unsigned groups = ((h.cw / 8 + 7) / 8) * (unsigned)nb_rows;
-                                hipLaunchKernelGGL(k_decode, dim3((groups + 3) / 4), dim3(256), 0, s->stream,
-                                                   (const int16_t *)dtmp, (const float *)h.q, ftmp, h.cw, (unsigned)nb_rows);
-                                e3 = hipMemcpyAsync(h.decoded, ftmp + (size_t)(h.frow0 - b0 * 8) * h.cw,
-                                                    (size_t)h.frows * h.cw * sizeof(float), hipMemcpyDeviceToDevice, s->stream);
-                                if(e3 == hipSuccess) { e3 = hipStreamSynchronize(s->stream); }
-                        }
-                        (void)hipFree(dtmp);
-                        (void)hipFree(ftmp);
-                        CREATE_TRY(e3);
-                }
         }
         // reductions: tile rows are counted on the canvas, the band owns a contiguous range
         s->ntx = W <= 4 ? 1 : (W - 4 + kStripCols - 1) / kStripCols;   // n strips cover 124 n + 4 columns
-        {
-                // rows per gradient strip: a multiple of the 16-row partial granularity
-                const char *env = getenv("J2P_RPW");
-                unsigned rpw = env ? (unsigned)atoi(env) : 16u;
-                if(rpw < (unsigned)kTY) { rpw = kTY; }
-                s->rpw = rpw / kTY * kTY;
-        }
-        {
-                // Row segments of the gradient kernel: uniform segments of rpw rows.  J2P_NLONG=n makes the
-                // first n segments (spread over the 8 XCD bands) twice as long — an experiment knob: mixing
-                // wavefront lengths did not shorten the kernel's tail on MI355X.  Segment
-                // boundaries stay multiples of kTY, so the norm partials — and the results — do not depend
-                // on this choice.
-                const unsigned units = (s->rows + s->rpw - 1) / s->rpw;       // uniform segments
-                const char *env = getenv("J2P_NLONG");
-                unsigned nlong_total = env ? (unsigned)atoi(env) : 0u;
-                if(nlong_total * 2 > units) { nlong_total = units / 2; }
-                std::vector<unsigned> seg;
-                seg.push_back(0);
-                const unsigned bands = units >= 64 ? 8 : 1;
-                unsigned u = 0;
-                for(unsigned b = 0; b < bands; b++) {
-                        const unsigned u_end = (unsigned)((unsigned long long)units * (b + 1) / bands);
-                        unsigned nl = nlong_total / bands + (b < nlong_total % bands ? 1 : 0);
-                        while(u < u_end) {
-                                unsigned take = (nl > 0 && u + 2 <= u_end) ? 2 : 1;
-                                if(take == 2) { nl--; }
-                                u += take;
-                                const unsigned row = u * s->rpw;
-                                seg.push_back(row < s->rows ? row : s->rows);
-                        }
-                }
-                s->nseg = (unsigned)seg.size() - 1;
-                CREATE_TRY(hipMalloc(&s->seg_row, seg.size() * sizeof(unsigned)));
-                CREATE_TRY(hipMemcpy(s->seg_row, seg.data(), seg.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-                // launch lists: all segments | interior segments | the two edge segments
-                std::vector<unsigned> map;
-                for(unsigned i = 0; i < s->nseg; i++) { map.push_back(i); }
-                for(unsigned i = 1; i + 1 < s->nseg; i++) { map.push_back(i); }
-                map.push_back(0);
-                map.push_back(s->nseg - 1);
-                CREATE_TRY(hipMalloc(&s->seg_map, map.size() * sizeof(unsigned)));
-                CREATE_TRY(hipMemcpy(s->seg_map, map.data(), map.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-        }
+        s->rpw = kTY;                                                  // rows per gradient strip (32/48/64 measured no faster)
+        s->nseg = (s->rows + s->rpw - 1) / s->rpw;
         s->ntr_local = (s->rows + kTY - 1) / kTY;
         s->ntr_global = (H + kTY - 1) / kTY;
         s->first_tr = row0 / kTY;
         const size_t ntiles = (size_t)s->ntx * s->ntr_local;
-        CREATE_TRY(hipMalloc(&s->part_g2, ntiles * nchannel * sizeof(double)));
-        CREATE_TRY(hipMalloc(&s->rowsum_local, (size_t)s->ntr_local * nchannel * sizeof(double)));
-        if(whole) { s->rowsum_all = s->rowsum_local; }
-        else { CREATE_TRY(hipMalloc(&s->rowsum_all, (size_t)s->ntr_global * nchannel * sizeof(double))); }
-        CREATE_TRY(hipMalloc(&s->norm, kMaxCh * sizeof(float)));
-        CREATE_TRY(hipMalloc(&s->part_tv, ntiles * 2 * sizeof(double)));
         unsigned max_strips = 0;
         for(unsigned c = 0; c < nchannel; c++) {
                 const ChanHost &h = s->ch[c];
@@ -691,12 +719,130 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 if(strips > max_strips) { max_strips = strips; }
         }
         s->strips_stride = max_strips;
-        CREATE_TRY(hipMalloc(&s->part_prob, (size_t)max_strips * nchannel * sizeof(double)));
-        CREATE_TRY(hipMemset(s->part_prob, 0, (size_t)max_strips * nchannel * sizeof(double)));
+        // launch lists: all segments | interior segments | the two edge segments
+        std::vector<unsigned> seg, map;
+        for(unsigned i = 0; i <= s->nseg; i++) { seg.push_back(i * s->rpw < s->rows ? i * s->rpw : s->rows); }
+        for(unsigned i = 0; i < s->nseg; i++) { map.push_back(i); }
+        for(unsigned i = 1; i + 1 < s->nseg; i++) { map.push_back(i); }
+        map.push_back(0);
+        map.push_back(s->nseg - 1);
+
+        // ---- one arena for everything (sizes first, then the pointers) ----
+        const size_t plane_floats = (size_t)(s->rows + 2 * kHalo) * W;
+        float *q_all = nullptr;
+        Carver carve;
+        for(int pass = 0; pass < 2; pass++) {
+                if(pass == 1) {
+                        CREATE_TRY(pool_take(device, carve.used + 256, &s->arena, &s->arena_bytes));
+                        carve.base = static_cast<char *>(s->arena);
+                        carve.used = 0;
+                }
+                for(unsigned c = 0; c < nchannel; c++) {
+                        ChanHost &h = s->ch[c];
+                        carve.take(h.xbuf[0], plane_floats);
+                        carve.take(h.xbuf[1], plane_floats);
+                        carve.take(h.grad, (size_t)s->rows * W);
+                        // the prob state always has at least one (zero) row: the gradient kernel reads it unconditionally
+                        carve.take(h.pg, (size_t)(h.crows ? h.crows : 1) * h.cw);
+                        carve.take(h.decoded, (size_t)h.frows * h.cw);
+                        carve.take(h.d, (size_t)(h.crows ? h.crows : 1) * h.cw);
+                }
+                carve.take(q_all, 64 * kMaxCh);
+                carve.take(s->seg_row, seg.size());
+                carve.take(s->seg_map, map.size());
+                carve.take(s->part_g2, ntiles * nchannel);
+                carve.take(s->rowsum_local, (size_t)s->ntr_local * nchannel);
+                if(whole) { s->rowsum_all = s->rowsum_local; }
+                else { carve.take(s->rowsum_all, (size_t)s->ntr_global * nchannel); }
+                carve.take(s->norm, kMaxCh);
+                carve.take(s->tickets, (size_t)s->ntr_local + 1);
+                carve.take(s->part_tv, ntiles * 2);
+                carve.take(s->part_prob, (size_t)max_strips * nchannel);
+        }
+
+        // ---- uploads (host arrays: whole-image unless band_local) ----
+        float qf[64 * kMaxCh];
+        for(unsigned c = 0; c < nchannel; c++) {
+                s->ch[c].q = q_all + 64 * c;
+                for(int j = 0; j < 64; j++) { qf[64 * c + j] = (float)planes[c].quant_table[j]; }
+        }
+        CREATE_TRY(hipMemcpyAsync(q_all, qf, sizeof(float) * 64 * nchannel, hipMemcpyHostToDevice, s->stream));
+        CREATE_TRY(hipMemcpyAsync(s->seg_row, seg.data(), seg.size() * sizeof(unsigned), hipMemcpyHostToDevice, s->stream));
+        CREATE_TRY(hipMemcpyAsync(s->seg_map, map.data(), map.size() * sizeof(unsigned), hipMemcpyHostToDevice, s->stream));
+        CREATE_TRY(hipMemsetAsync(s->tickets, 0, ((size_t)s->ntr_local + 1) * sizeof(unsigned), s->stream));
+        CREATE_TRY(hipMemsetAsync(s->part_prob, 0, (size_t)max_strips * nchannel * sizeof(double), s->stream));
+        for(unsigned c = 0; c < nchannel; c++) {
+                const j2p_plane &p = planes[c];
+                ChanHost &h = s->ch[c];
+                const size_t host_row0 = s->band_local ? h.crow0 : 0;
+                if(h.crows) {
+                        // block-major: coefficient row r lives in block row r/8; rows are block aligned
+                        const int16_t *src = p.data + (size_t)(h.crow0 - host_row0) * h.cw;
+                        CREATE_TRY(hipMemcpyAsync(h.d, src, (size_t)h.crows * h.cw * sizeof(int16_t), hipMemcpyHostToDevice, s->stream));
+                }
+                if(p.fdata) {
+                        const float *src = p.fdata + (size_t)(h.frow0 - host_row0) * h.cw;
+                        CREATE_TRY(hipMemcpyAsync(h.decoded, src, (size_t)h.frows * h.cw * sizeof(float), hipMemcpyHostToDevice, s->stream));
+                } else {
+                        // decode on the device (jpeg.c:83-92 + box.c:5-19): whole block rows [b0, b1) of the input
+                        // window.  Band rows are block aligned, so when the window has no halo rows (band_local, or
+                        // a whole canvas) the blocks are already in h.d; otherwise the coefficients of the
+                        // window go up once more into the (not yet initialised) gradient plane as scratch.
+                        const unsigned b0 = h.frow0 / 8, b1 = (h.frow0 + h.frows + 7) / 8;
+                        const unsigned nb_rows = b1 - b0;
+                        const unsigned groups = ((h.cw / 8 + 7) / 8) * nb_rows;
+                        const int16_t *dsrc = nullptr;
+                        if(h.crows && b0 * 8 >= h.crow0 && b1 * 8 <= h.crow0 + h.crows) {
+                                dsrc = h.d + (size_t)(b0 * 8 - h.crow0) * h.cw;
+                        } else {
+                                // scratch: the first x buffer holds (rows + 4) * W floats >= the window's int16 data
+                                if((size_t)nb_rows * 8 * h.cw * sizeof(int16_t) > plane_floats * sizeof(float)) {
+                                        rc = fail(J2P_EINVAL, "channel %u: decode window does not fit the scratch plane", c);
+                                        j2p_solver_destroy(s);
+                                        return rc;
+                                }
+                                int16_t *dtmp = reinterpret_cast<int16_t *>(h.xbuf[0]);
+                                const int16_t *src = p.data + (size_t)(b0 * 8 - host_row0) * h.cw;
+                                CREATE_TRY(hipMemcpyAsync(dtmp, src, (size_t)nb_rows * 8 * h.cw * sizeof(int16_t), hipMemcpyHostToDevice, s->stream));
+                                dsrc = dtmp;
+                        }
+                        if(h.frow0 == b0 * 8 && h.frows == nb_rows * 8) {
+                                hipLaunchKernelGGL(k_decode, dim3((groups + 3) / 4), dim3(256), 0, s->stream, dsrc,
+                                                   (const float *)h.q, h.decoded, h.cw, nb_rows);
+                        } else {
+                                // window not block aligned (halo rows of a band): decode into the second x buffer, copy the rows
+                                if((size_t)nb_rows * 8 * h.cw > plane_floats) {
+                                        rc = fail(J2P_EINVAL, "channel %u: decode window does not fit the scratch plane", c);
+                                        j2p_solver_destroy(s);
+                                        return rc;
+                                }
+                                float *ftmp = h.xbuf[1];
+                                hipLaunchKernelGGL(k_decode, dim3((groups + 3) / 4), dim3(256), 0, s->stream, dsrc,
+                                                   (const float *)h.q, ftmp, h.cw, nb_rows);
+                                CREATE_TRY(hipMemcpyAsync(h.decoded, ftmp + (size_t)(h.frow0 - b0 * 8) * h.cw,
+                                                          (size_t)h.frows * h.cw * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+                        }
+                        CREATE_TRY(hipGetLastError());
+                }
+        }
+        // the host arrays (and the stack tables above) may go away as soon as this returns
+        CREATE_TRY(hipStreamSynchronize(s->stream));
 #undef CREATE_TRY
         rc = launch_init(s);
         if(rc != J2P_OK) { j2p_solver_destroy(s); return rc; }
         *out = s;
+        return J2P_OK;
+}
+
+int j2p_solver_debug_option(j2p_solver *s, int option, int value)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        if(s->grad_done || s->interior_done) { return fail(J2P_ESTATE, "options change between iterations only"); }
+        switch(option) {
+        case J2P_OPT_NORM_FOLD: s->fold = value != 0; break;
+        case J2P_OPT_JOINT_INWAVE: s->joint_inwave = value != 0; break;
+        default: return fail(J2P_EINVAL, "unknown option %d", option);
+        }
         return J2P_OK;
 }
 
@@ -791,6 +937,16 @@ static void rows_from_sums(unsigned nch, float weight, const float *pweight, uns
         }
 }
 
+}  // extern "C"
+
+void j2p_rows_from_sums_carry(unsigned nch, float weight, const float *pweight, unsigned n, const double *sums,
+                              double *carried, j2p_log_row *rows)
+{
+        rows_from_sums(nch, weight, pweight, n, sums, carried, true, rows);
+}
+
+extern "C" {
+
 int j2p_log_rows_from_sums(unsigned nchannel, float weight, const float pweight[], unsigned n, const double *sums,
                            j2p_log_row *rows)
 {
@@ -882,6 +1038,71 @@ int j2p_solver_exchange_info(j2p_solver *s, j2p_exchange *info)
                 info->send_bottom[c] = base + (size_t)s->rows * s->W;
                 info->recv_bottom[c] = base + (size_t)(s->rows + kHalo) * s->W;
         }
+        return J2P_OK;
+}
+
+int j2p_solver_stream(j2p_solver *s, void **stream)
+{
+        if(!s || !stream) { return fail(J2P_EINVAL, "NULL argument"); }
+        *stream = (void *)s->stream;
+        return J2P_OK;
+}
+
+int j2p_solver_halo_rows(j2p_solver *s, int buffer, j2p_exchange *info)
+{
+        if(!s || !info || (buffer != 0 && buffer != 1)) { return fail(J2P_EINVAL, "bad argument"); }
+        memset(info, 0, sizeof(*info));
+        info->halo_floats = (size_t)kHalo * s->W;
+        for(unsigned c = 0; c < s->nch; c++) {
+                float *base = s->ch[c].xbuf[buffer];
+                info->recv_top[c] = base;
+                info->send_top[c] = base + (size_t)kHalo * s->W;
+                info->send_bottom[c] = base + (size_t)s->rows * s->W;
+                info->recv_bottom[c] = base + (size_t)(s->rows + kHalo) * s->W;
+        }
+        return J2P_OK;
+}
+
+int j2p_solver_norm_from_bands(j2p_solver *s, unsigned nband, const double *const rowsums[], const unsigned first_tile_row[],
+                               const unsigned tile_rows[])
+{
+        if(!s || !rowsums || !first_tile_row || !tile_rows) { return fail(J2P_EINVAL, "NULL argument"); }
+        if(nband == 0 || nband > (unsigned)kMaxBands) { return fail(J2P_EINVAL, "1..%d bands", kMaxBands); }
+        if(!s->grad_done || s->rowsums_pending) { return fail(J2P_ESTATE, "norm_from_bands needs a finished gradient phase"); }
+        DeviceGuard guard(s->device);
+        BandRowsums t;
+        unsigned covered = 0;
+        for(unsigned b = 0; b < nband; b++) {
+                if(first_tile_row[b] + tile_rows[b] > s->ntr_global) { return fail(J2P_EINVAL, "band %u: tile rows out of range", b); }
+                t.rowsum[b] = rowsums[b];
+                t.first[b] = first_tile_row[b];
+                t.count[b] = tile_rows[b];
+                covered += tile_rows[b];
+        }
+        if(covered != s->ntr_global) { return fail(J2P_EINVAL, "the bands cover %u of %u tile rows", covered, s->ntr_global); }
+        t.nband = nband;
+        unsigned P = 1;
+        while(P < s->ntr_global) { P <<= 1; }
+        hipLaunchKernelGGL(k_norm_bands, dim3(s->nch), dim3(256), P * sizeof(double), s->stream, t, s->ntr_global, s->nch, s->norm);
+        HIP_TRY(hipGetLastError());
+        s->norm_ready = true;
+        return J2P_OK;
+}
+
+int j2p_solver_copy_rows(j2p_solver *s, unsigned n, float *const dst[], const float *const src[], size_t floats)
+{
+        if(!s || !dst || !src) { return fail(J2P_EINVAL, "NULL argument"); }
+        if(n == 0) { return J2P_OK; }
+        if(n > 2u * kMaxCh || (floats & 1) || floats > 0xfffffffeu) { return fail(J2P_EINVAL, "copy_rows: bad count / size"); }
+        DeviceGuard guard(s->device);
+        RowCopies t;
+        for(unsigned k = 0; k < n; k++) { t.dst[k] = dst[k]; t.src[k] = src[k]; }
+        t.n = n;
+        t.floats = (unsigned)floats;
+        unsigned blocks = (unsigned)((floats / 2 + 255) / 256);
+        if(blocks > 64) { blocks = 64; }
+        hipLaunchKernelGGL(k_copy_rows, dim3(blocks ? blocks : 1), dim3(256), 0, s->stream, t);
+        HIP_TRY(hipGetLastError());
         return J2P_OK;
 }
 
@@ -1040,13 +1261,14 @@ int j2p_planes_to_rgb(const j2p_plane_ref planes[3], unsigned w, unsigned h, uns
                 if(planes[i].solver != s0) { HIP_TRY(hipStreamSynchronize(planes[i].solver->stream)); }
         }
         const size_t bytes = (size_t)w * h * (bits == 8 ? 3 : 6);
-        uint8_t *dout = nullptr;
-        HIP_TRY(hipMalloc(&dout, bytes));
+        void *dout = nullptr;
+        size_t dout_bytes = 0;
+        HIP_TRY(pool_take(s0->device, bytes, &dout, &dout_bytes));       // pooled like the solvers' arenas: no hipFree per image
         hipLaunchKernelGGL(k_to_rgb, dim3(2048), dim3(256), 0, s0->stream, ptr[0], stride[0], ptr[1], stride[1], ptr[2], stride[2],
-                           w, h, bits, dout);
+                           w, h, bits, static_cast<uint8_t *>(dout));
         hipError_t e = hipMemcpyAsync(out_host, dout, bytes, hipMemcpyDeviceToHost, s0->stream);
         if(e == hipSuccess) { e = hipStreamSynchronize(s0->stream); }
-        (void)hipFree(dout);
+        pool_give(s0->device, dout, dout_bytes);
         if(e != hipSuccess) { return fail(J2P_EDEVICE, "planes_to_rgb: %s", hipGetErrorString(e)); }
         return J2P_OK;
 }

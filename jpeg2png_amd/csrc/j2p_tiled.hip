@@ -1,0 +1,436 @@
+// jpeg2png_amd — one plane set row-tiled over several GPUs from ONE process (BASELINE.json configs[3]).
+//
+// The canvas is cut into contiguous row bands (multiples of 8*h_samp and of the 16-row gradient tile, so that no
+// DCT block and no gradient tile straddles two bands); band i is a j2p_solver on devices[i] — device ids may
+// repeat, several bands then share a GPU.  One host thread per band issues that band's launches, so the eight
+// GPUs of a node are fed in parallel and there is no interpreter in the iteration loop.  Per iteration the bands
+// meet twice (reference loop compute.c:427-453):
+//
+//   1. ||g|| (compute.c:200-207) needs every band's gradient: each band records an event behind its gradient
+//      phase (whose last wavefronts have already reduced the band's 16-row tile rows), waits for the other bands'
+//      events and reduces ALL bands' row sums — read in place over xGMI — with the same fixed tree over the same
+//      global array as the single-GPU solver.  The result therefore does not depend on the number of bands.
+//   2. the next gradient reaches 2 rows into the neighbouring bands (TGV2, compute.c:137-143,165-183): the
+//      projection does the band's first and last block row first and records an event; the neighbours pull those
+//      rows into their halo rows after the interior of THEIR next gradient phase, which reads no halo row, so the
+//      copy and the cross-GPU wait hide behind roughly two thirds of an iteration of compute.
+//
+// Ordering between GPUs is by HIP events only (kernel-boundary visibility); no flag is polled on a device.
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+#include <stdint.h>
+#include <string.h>
+
+#include "jpeg2png_amd.h"
+#include "j2p_internal.h"
+
+namespace {
+
+constexpr unsigned kLogCols = 2 + J2P_MAX_CHANNELS;
+
+struct Band {
+        int device = 0;
+        j2p_solver *solver = nullptr;
+        hipStream_t stream = nullptr;
+        unsigned row0 = 0, row1 = 0;
+        bool split = false;                    // long enough for the two-part phases
+        hipEvent_t ev_grad[2] = {nullptr, nullptr};    // behind the gradient phase of iteration it (slot it & 1)
+        hipEvent_t ev_edge[2] = {nullptr, nullptr};    // behind the projection of the band's first/last block rows
+        std::atomic<uint64_t> grad_recorded{0}, edge_recorded{0};   // iterations whose event has been recorded
+        j2p_exchange rows[2];                  // halo / edge row addresses of x buffer 0 and 1
+        const double *rowsum = nullptr;
+        unsigned first_tr = 0, ntr = 0;
+        double *log_dev = nullptr;             // the band's {tv, tv2, prob[3]} of the iteration just finished
+        double *log_host = nullptr;            // pinned: [chunk][kLogCols]
+        unsigned log_cap = 0;
+        std::thread thread;
+        int rc = J2P_OK;
+        char err[256] = "";
+};
+
+}  // namespace
+
+struct j2p_tiled {
+        unsigned nband = 0, nch = 0, W = 0, H = 0;
+        float weight = 0.f, pweight[J2P_MAX_CHANNELS] = {0.f, 0.f, 0.f};
+        std::vector<Band *> bands;
+        uint64_t iter = 0;                     // iterations issued so far
+        double carried[J2P_MAX_CHANNELS] = {0., 0., 0.};
+        // command hand-over to the band threads
+        std::mutex lock;
+        std::condition_variable wake, done;
+        uint64_t generation = 0;
+        unsigned cmd_n = 0;
+        bool cmd_log = false, quit = false;
+        unsigned finished = 0;
+        std::atomic<bool> abort{false};
+};
+
+namespace {
+
+#define BAND_TRY(expr)                                                                             \
+        do {                                                                                       \
+                int rc_ = (expr);                                                                  \
+                if(rc_ != J2P_OK) { return rc_; }                                                  \
+        } while(0)
+#define BAND_HIP(expr)                                                                             \
+        do {                                                                                       \
+                hipError_t e_ = (expr);                                                            \
+                if(e_ != hipSuccess) { return j2p_fail(J2P_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); } \
+        } while(0)
+
+// wait (host) until band p has recorded its event of iteration `it`, then make `me`'s stream wait for it
+int wait_for(j2p_tiled *t, Band *me, Band *p, bool edge, uint64_t it)
+{
+        std::atomic<uint64_t> &seq = edge ? p->edge_recorded : p->grad_recorded;
+        unsigned spins = 0;
+        while(seq.load(std::memory_order_acquire) <= it) {
+                if(t->abort.load(std::memory_order_relaxed)) { return j2p_fail(J2P_ESTATE, "another band failed"); }
+                if(++spins > 64) { std::this_thread::yield(); }
+        }
+        BAND_HIP(hipStreamWaitEvent(me->stream, edge ? p->ev_edge[it & 1] : p->ev_grad[it & 1], 0));
+        return J2P_OK;
+}
+
+// the neighbours' edge rows of the iterate produced by iteration `it` into this band's halo rows
+int pull_halos(j2p_tiled *t, unsigned b, uint64_t it)
+{
+        Band *me = t->bands[b];
+        Band *up = b > 0 ? t->bands[b - 1] : nullptr, *down = b + 1 < t->nband ? t->bands[b + 1] : nullptr;
+        if(!up && !down) { return J2P_OK; }
+        const int buf = (int)((it + 1) & 1);
+        float *dst[2 * J2P_MAX_CHANNELS];
+        const float *src[2 * J2P_MAX_CHANNELS];
+        unsigned n = 0;
+        if(up) { BAND_TRY(wait_for(t, me, up, true, it)); }
+        if(down) { BAND_TRY(wait_for(t, me, down, true, it)); }
+        for(unsigned c = 0; c < t->nch; c++) {
+                if(up) { dst[n] = me->rows[buf].recv_top[c]; src[n++] = up->rows[buf].send_bottom[c]; }
+                if(down) { dst[n] = me->rows[buf].recv_bottom[c]; src[n++] = down->rows[buf].send_top[c]; }
+        }
+        return j2p_solver_copy_rows(me->solver, n, dst, src, me->rows[buf].halo_floats);
+}
+
+int band_iterations(j2p_tiled *t, unsigned b, unsigned n, bool log)
+{
+        Band *me = t->bands[b];
+        BAND_HIP(hipSetDevice(me->device));
+        const double *rowsums[32];
+        unsigned first[32], count[32];
+        for(unsigned p = 0; p < t->nband; p++) {
+                rowsums[p] = t->bands[p]->rowsum;
+                first[p] = t->bands[p]->first_tr;
+                count[p] = t->bands[p]->ntr;
+        }
+        for(unsigned i = 0; i < n; i++) {
+                const uint64_t it = t->iter + i;
+                // ---- phase A; the rows of the neighbours arrive behind the interior segments ----
+                if(me->split) {
+                        BAND_TRY(j2p_solver_phase_gradient_part(me->solver, J2P_GRADIENT_INTERIOR, nullptr));
+                        if(it > 0) { BAND_TRY(pull_halos(t, b, it - 1)); }
+                        BAND_TRY(j2p_solver_phase_gradient_part(me->solver, J2P_GRADIENT_EDGES, nullptr));
+                        BAND_TRY(j2p_solver_phase_rowsums(me->solver));
+                } else {
+                        if(it > 0) { BAND_TRY(pull_halos(t, b, it - 1)); }
+                        BAND_TRY(j2p_solver_phase_gradient(me->solver));
+                }
+                BAND_HIP(hipEventRecord(me->ev_grad[it & 1], me->stream));
+                me->grad_recorded.store(it + 1, std::memory_order_release);
+                // ---- the global norm: every band's row sums, same tree everywhere ----
+                for(unsigned p = 0; p < t->nband; p++) {
+                        if(p != b) { BAND_TRY(wait_for(t, me, t->bands[p], false, it)); }
+                }
+                BAND_TRY(j2p_solver_norm_from_bands(me->solver, t->nband, rowsums, first, count));
+                // ---- phase B, edge block rows first ----
+                if(me->split) {
+                        BAND_TRY(j2p_solver_phase_project_part(me->solver, J2P_PROJECT_BOUNDARY));
+                        BAND_HIP(hipEventRecord(me->ev_edge[it & 1], me->stream));
+                        me->edge_recorded.store(it + 1, std::memory_order_release);
+                        BAND_TRY(j2p_solver_phase_project_part(me->solver, J2P_PROJECT_INTERIOR));
+                } else {
+                        BAND_TRY(j2p_solver_phase_project(me->solver));
+                        BAND_HIP(hipEventRecord(me->ev_edge[it & 1], me->stream));
+                        me->edge_recorded.store(it + 1, std::memory_order_release);
+                }
+                if(log) {
+                        BAND_HIP(hipMemcpyAsync(me->log_host + (size_t)i * kLogCols, me->log_dev, kLogCols * sizeof(double),
+                                                hipMemcpyDeviceToHost, me->stream));
+                }
+        }
+        return J2P_OK;
+}
+
+void band_main(j2p_tiled *t, unsigned b)
+{
+        uint64_t seen = 0;
+        for(;;) {
+                unsigned n;
+                bool log;
+                {
+                        std::unique_lock<std::mutex> g(t->lock);
+                        t->wake.wait(g, [&] { return t->quit || t->generation != seen; });
+                        if(t->quit) { return; }
+                        seen = t->generation;
+                        n = t->cmd_n;
+                        log = t->cmd_log;
+                }
+                Band *me = t->bands[b];
+                me->rc = band_iterations(t, b, n, log);
+                if(me->rc != J2P_OK) {
+                        strncpy(me->err, j2p_last_error(), sizeof(me->err) - 1);
+                        t->abort.store(true);
+                }
+                {
+                        std::lock_guard<std::mutex> g(t->lock);
+                        t->finished++;
+                }
+                t->done.notify_one();
+        }
+}
+
+unsigned gcd_u(unsigned a, unsigned b) { return b ? gcd_u(b, a % b) : a; }
+
+}  // namespace
+
+extern "C" {
+
+void j2p_tiled_destroy(j2p_tiled *t)
+{
+        if(!t) { return; }
+        {
+                std::lock_guard<std::mutex> g(t->lock);
+                t->quit = true;
+        }
+        t->wake.notify_all();
+        for(Band *b : t->bands) {
+                if(b->thread.joinable()) { b->thread.join(); }
+        }
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        for(Band *b : t->bands) {
+                (void)hipSetDevice(b->device);
+                if(b->solver) { j2p_solver_destroy(b->solver); }        // synchronises the band's stream first
+                for(int k = 0; k < 2; k++) {
+                        if(b->ev_grad[k]) { (void)hipEventDestroy(b->ev_grad[k]); }
+                        if(b->ev_edge[k]) { (void)hipEventDestroy(b->ev_edge[k]); }
+                }
+                if(b->log_host) { (void)hipHostFree(b->log_host); }
+                delete b;
+        }
+        if(prev >= 0) { (void)hipSetDevice(prev); }
+        delete t;
+}
+
+int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const unsigned cuts[], unsigned nchannel,
+                     const j2p_plane planes[], float weight, const float pweight[], unsigned iterations)
+{
+        if(!out || !devices || !planes || !pweight) { return j2p_fail(J2P_EINVAL, "NULL argument"); }
+        *out = nullptr;
+        if(nband == 0 || nband > 32) { return j2p_fail(J2P_EINVAL, "1..32 bands, got %u", nband); }
+        if(nchannel == 0 || nchannel > J2P_MAX_CHANNELS) { return j2p_fail(J2P_EINVAL, "nchannel must be 1..3 (compute.c:118)"); }
+        unsigned W = 0, H = 0, align = J2P_TILE_ROWS;
+        for(unsigned c = 0; c < nchannel; c++) {
+                const j2p_plane &p = planes[c];
+                if(p.w_samp == 0 || p.h_samp == 0 || p.w == 0 || p.h == 0) { return j2p_fail(J2P_EINVAL, "channel %u: empty plane", c); }
+                if(p.w * p.w_samp > W) { W = p.w * p.w_samp; }
+                if(p.h * p.h_samp > H) { H = p.h * p.h_samp; }
+                align = align / gcd_u(align, 8 * p.h_samp) * (8 * p.h_samp);
+        }
+        // band boundaries: the caller's, or near-equal multiples of the alignment
+        std::vector<unsigned> edge(nband + 1);
+        if(cuts) {
+                for(unsigned b = 0; b <= nband; b++) { edge[b] = cuts[b]; }
+                if(edge[0] != 0 || edge[nband] != H) { return j2p_fail(J2P_EINVAL, "cuts must run from 0 to the canvas height %u", H); }
+        } else {
+                const unsigned units = (H + align - 1) / align;
+                if(units < nband) { return j2p_fail(J2P_EINVAL, "a canvas of %u rows has only %u bands of %u rows for %u devices", H, units, align, nband); }
+                unsigned start = 0;
+                for(unsigned b = 0; b < nband; b++) {
+                        edge[b] = start * align;
+                        start += units / nband + (b < units % nband ? 1 : 0);
+                }
+                edge[nband] = H;
+        }
+        for(unsigned b = 0; b < nband; b++) {
+                if(edge[b] >= edge[b + 1] || edge[b] % align) { return j2p_fail(J2P_EINVAL, "band %u: rows [%u,%u) not aligned to %u", b, edge[b], edge[b + 1], align); }
+        }
+        j2p_tiled *t = new(std::nothrow) j2p_tiled();
+        if(!t) { return j2p_fail(J2P_ENOMEM, "host allocation failed"); }
+        t->nband = nband;
+        t->nch = nchannel;
+        t->W = W;
+        t->H = H;
+        t->weight = weight;
+        for(unsigned c = 0; c < nchannel; c++) { t->pweight[c] = pweight[c]; }
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        int rc = J2P_OK;
+        for(unsigned b = 0; b < nband && rc == J2P_OK; b++) {
+                Band *bd = new(std::nothrow) Band();
+                if(!bd) { rc = j2p_fail(J2P_ENOMEM, "host allocation failed"); break; }
+                t->bands.push_back(bd);
+                bd->device = devices[b];
+                bd->row0 = edge[b];
+                bd->row1 = edge[b + 1];
+                const j2p_band band = {edge[b], edge[b + 1]};
+                rc = j2p_solver_create(&bd->solver, bd->device, nullptr, nchannel, planes, weight, pweight, iterations,
+                                       nband == 1 ? j2p_band{0, 0} : band, 0);
+                if(rc != J2P_OK) { break; }
+                if(hipSetDevice(bd->device) != hipSuccess) { rc = j2p_fail(J2P_EDEVICE, "hipSetDevice(%d) failed", bd->device); break; }
+                void *st = nullptr;
+                j2p_solver_stream(bd->solver, &st);
+                bd->stream = (hipStream_t)st;
+                j2p_exchange e;
+                j2p_solver_exchange_info(bd->solver, &e);
+                bd->rowsum = e.partials_local;
+                bd->first_tr = e.first_tile_row;
+                bd->ntr = e.local_tile_rows;
+                j2p_solver_halo_rows(bd->solver, 0, &bd->rows[0]);
+                j2p_solver_halo_rows(bd->solver, 1, &bd->rows[1]);
+                // the two-part phases need an interior: three 16-row segments and three block rows of every channel
+                bd->split = nband > 1 && bd->row1 - bd->row0 >= 3 * align && bd->row1 - bd->row0 >= 3 * J2P_TILE_ROWS;
+                for(int k = 0; k < 2 && rc == J2P_OK; k++) {
+                        if(hipEventCreateWithFlags(&bd->ev_grad[k], hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&bd->ev_edge[k], hipEventDisableTiming) != hipSuccess) {
+                                rc = j2p_fail(J2P_EDEVICE, "hipEventCreate failed");
+                        }
+                }
+        }
+        // every band reads every other band's row sums and its neighbours' edge rows in place
+        for(unsigned a = 0; a < t->bands.size() && rc == J2P_OK; a++) {
+                for(unsigned b = 0; b < t->bands.size() && rc == J2P_OK; b++) {
+                        const int da = t->bands[a]->device, db = t->bands[b]->device;
+                        if(da == db) { continue; }
+                        int can = 0;
+                        if(hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can) {
+                                rc = j2p_fail(J2P_EDEVICE, "device %d cannot access device %d's memory (no peer access)", da, db);
+                                break;
+                        }
+                        (void)hipSetDevice(da);
+                        const hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+                        if(e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                                rc = j2p_fail(J2P_EDEVICE, "hipDeviceEnablePeerAccess(%d -> %d): %s", da, db, hipGetErrorString(e));
+                        }
+                        (void)hipGetLastError();
+                }
+        }
+        if(prev >= 0) { (void)hipSetDevice(prev); }
+        if(rc != J2P_OK) {
+                j2p_tiled_destroy(t);
+                return rc;
+        }
+        for(unsigned b = 0; b < nband; b++) { t->bands[b]->thread = std::thread(band_main, t, b); }
+        *out = t;
+        return J2P_OK;
+}
+
+int j2p_tiled_canvas(const j2p_tiled *t, unsigned *W, unsigned *H, unsigned *nband)
+{
+        if(!t) { return j2p_fail(J2P_EINVAL, "tiled solver is NULL"); }
+        if(W) { *W = t->W; }
+        if(H) { *H = t->H; }
+        if(nband) { *nband = t->nband; }
+        return J2P_OK;
+}
+
+int j2p_tiled_band(const j2p_tiled *t, unsigned band, int *device, unsigned *row_begin, unsigned *row_end, j2p_solver **solver)
+{
+        if(!t || band >= t->nband) { return j2p_fail(J2P_EINVAL, "bad band index"); }
+        const Band *b = t->bands[band];
+        if(device) { *device = b->device; }
+        if(row_begin) { *row_begin = b->row0; }
+        if(row_end) { *row_end = b->row1; }
+        if(solver) { *solver = b->solver; }
+        return J2P_OK;
+}
+
+int j2p_tiled_sync(j2p_tiled *t)
+{
+        if(!t) { return j2p_fail(J2P_EINVAL, "tiled solver is NULL"); }
+        for(Band *b : t->bands) { BAND_TRY(j2p_solver_sync(b->solver)); }
+        return J2P_OK;
+}
+
+int j2p_tiled_reset(j2p_tiled *t)
+{
+        if(!t) { return j2p_fail(J2P_EINVAL, "tiled solver is NULL"); }
+        if(t->abort.load()) { return j2p_fail(J2P_ESTATE, "a band failed earlier; the tiled solver is unusable"); }
+        // the band threads are idle between run() calls; every band back to iteration 0 from its resident inputs
+        for(Band *b : t->bands) {
+                BAND_TRY(j2p_solver_reset(b->solver));
+                b->grad_recorded.store(0);
+                b->edge_recorded.store(0);
+        }
+        // a band's reset must not overtake a neighbour still pulling its edge rows: drain, this is not a hot path
+        BAND_TRY(j2p_tiled_sync(t));
+        t->iter = 0;
+        for(unsigned c = 0; c < J2P_MAX_CHANNELS; c++) { t->carried[c] = 0.; }
+        return J2P_OK;
+}
+
+int j2p_tiled_run(j2p_tiled *t, unsigned n, j2p_log_row *rows)
+{
+        if(!t) { return j2p_fail(J2P_EINVAL, "tiled solver is NULL"); }
+        if(n == 0) { return J2P_OK; }
+        if(t->abort.load()) { return j2p_fail(J2P_ESTATE, "a band failed earlier; the tiled solver is unusable"); }
+        const bool log = rows != nullptr;
+        if(log) {
+                int prev = -1;
+                (void)hipGetDevice(&prev);
+                for(Band *b : t->bands) {
+                        (void)hipSetDevice(b->device);
+                        if(!b->log_dev) {
+                                BAND_TRY(j2p_solver_set_logging(b->solver, 1));
+                                j2p_exchange e;
+                                BAND_TRY(j2p_solver_exchange_info(b->solver, &e));
+                                b->log_dev = e.log_local;
+                        }
+                        if(b->log_cap < n) {
+                                if(b->log_host) { (void)hipHostFree(b->log_host); b->log_host = nullptr; }
+                                BAND_HIP(hipHostMalloc((void **)&b->log_host, (size_t)n * kLogCols * sizeof(double), hipHostMallocDefault));
+                                b->log_cap = n;
+                        }
+                }
+                if(prev >= 0) { (void)hipSetDevice(prev); }
+        }
+        {
+                std::lock_guard<std::mutex> g(t->lock);
+                t->cmd_n = n;
+                t->cmd_log = log;
+                t->finished = 0;
+                t->generation++;
+        }
+        t->wake.notify_all();
+        {
+                std::unique_lock<std::mutex> g(t->lock);
+                t->done.wait(g, [&] { return t->finished == t->nband; });
+        }
+        t->iter += n;
+        for(Band *b : t->bands) {
+                if(b->rc != J2P_OK) { return j2p_fail(b->rc, "band [%u,%u) on device %d: %s", b->row0, b->row1, b->device, b->err); }
+        }
+        if(log) {
+                BAND_TRY(j2p_tiled_sync(t));
+                // the bands' sums in band order (any fixed order: the values only feed the log)
+                std::vector<double> sums((size_t)n * kLogCols, 0.);
+                for(Band *b : t->bands) {
+                        for(size_t k = 0; k < sums.size(); k++) { sums[k] += b->log_host[k]; }
+                }
+                j2p_rows_from_sums_carry(t->nch, t->weight, t->pweight, n, sums.data(), t->carried, rows);
+        }
+        return J2P_OK;
+}
+
+int j2p_tiled_download(j2p_tiled *t, unsigned c, float *out)
+{
+        if(!t || !out) { return j2p_fail(J2P_EINVAL, "NULL argument"); }
+        for(Band *b : t->bands) { BAND_TRY(j2p_solver_download(b->solver, c, out + (size_t)b->row0 * t->W)); }
+        return J2P_OK;
+}
+
+}  // extern "C"

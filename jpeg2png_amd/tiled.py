@@ -163,6 +163,17 @@ class HipBandEngine:
     def project_done_event(self):
         return self.stream.record_event()
 
+    def comm_context(self, after):
+        """context in which the halo exchange is issued: the comm stream, behind the event `after`"""
+        self.comm.wait_event(after)
+        return torch.cuda.stream(self.comm)
+
+    def comm_done_event(self):
+        return self.comm.record_event()
+
+    def wait_halo(self, event):
+        self.stream.wait_event(event)
+
     def commit_initial_halo(self):
         self.solver.commit_initial_halo()
 
@@ -339,10 +350,9 @@ class RowTiledSolver:
         solver's stream; returns the event that marks the arrival of the neighbours' rows"""
         e = self.e
         done = e.project_done_event()
-        with torch.cuda.stream(e.comm):
-            e.comm.wait_event(done)
+        with e.comm_context(done):
             self.exchange_halo()
-            return e.comm.record_event()
+            return e.comm_done_event()
 
     def iterate(self, n):
         e = self.e
@@ -374,4 +384,4 @@ class RowTiledSolver:
                     self._gather_log()
         # leave the solver's stream consistent for whoever comes next (download, reset, ...)
         if self._halo_ready is not None:
-            e.stream.wait_event(self._halo_ready)
+            e.wait_halo(self._halo_ready)

@@ -21,6 +21,8 @@ def build(ref=True):
         subprocess.run(["make", "-s", "-C", _HERE, "ref"], check=True)
         # the whole reference program, for the end-to-end CLI test (needs libjpeg/libpng headers)
         subprocess.run(["make", "-s", "-C", _HERE, "ref-cli"], check=False)
+        # ... and the same program with compute.o replaced by libjpeg2png_amd.so (the drop-in proof)
+        subprocess.run(["make", "-s", "-C", _HERE, "ref-dropin"], check=False)
 
 
 class _OPlane(ctypes.Structure):

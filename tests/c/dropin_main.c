@@ -32,7 +32,7 @@ static void rd(void *p, size_t n, FILE *f)
 
 int main(int argc, char **argv)
 {
-        if(argc != 4) { fprintf(stderr, "usage: dropin in.bin out.bin log.csv\n"); return 2; }
+        if(argc != 4 && argc != 5) { fprintf(stderr, "usage: dropin in.bin out.bin log.csv [tiled:<nband>]\n"); return 2; }
         FILE *in = fopen(argv[1], "rb");
         if(!in) { perror("in"); return 2; }
         unsigned nch, iterations;
@@ -59,7 +59,16 @@ int main(int argc, char **argv)
         fprintf(log.f, "filename,channel,iteration,objective,prob_dist,tv,tv2\n");
         struct progressbar pb = {0, iterations};
 
-        compute(nch, coefs, &log, &pb, weight, pweight, iterations);
+        if(argc == 5 && strncmp(argv[4], "tiled:", 6) == 0) {
+                /* the multi-GPU entry point with <nband> row bands, all on device 0: the C-level row tiling as far
+                 * as a single-GPU box can exercise it */
+                extern const char *j2p_last_error(void);
+                int devs[32] = {0};
+                int rc = j2p_compute_tiled((unsigned)atoi(argv[4] + 6), devs, nch, coefs, &log, &pb, weight, pweight, iterations);
+                if(rc != 0) { fprintf(stderr, "jpeg2png: %s\n", j2p_last_error()); return 1; }
+        } else {
+                compute(nch, coefs, &log, &pb, weight, pweight, iterations);
+        }
 
         fclose(log.f);
         FILE *out = fopen(argv[2], "wb");

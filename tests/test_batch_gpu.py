@@ -1,0 +1,98 @@
+"""The image-batch engine (j2p_batch_*, jpeg2png_amd/csrc/j2p_batch.hip): jobs on several slots of one GPU must
+give exactly what one compute() call per image gives — float planes bit for bit, RGB samples byte for byte —
+whatever the interleaving, and the pool must recycle device memory between images."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import bit_equal, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batch_planes_equal_individual_computes(lib):
+    import jpeg2png_amd as j
+    cases = [make_case(120 + 16 * i, 88 + 8 * i, ["420", "444", "422"][i % 3], 10 + 5 * i, seed=60 + i) for i in range(7)]
+    its = 14
+    with j.Batch(devices=[0], slots_per_device=3) as b:
+        # device-side decode (fdata = None) for half of the jobs, host-decoded planes for the others
+        jobs = []
+        for i, planes in enumerate(cases):
+            sub = copy.deepcopy(planes)
+            if i % 2:
+                for p in sub:
+                    p.fdata = None
+            jobs.append(b.submit(sub, 0.3, [0.001] * 3, its))
+        outs = [b.wait(t) for t in jobs]
+    for planes, out in zip(cases, outs):
+        ref = copy.deepcopy(planes)
+        j.compute(ref, 0.3, [0.001] * 3, its)
+        for c in range(3):
+            assert bit_equal(out[c], ref[c].fdata)
+
+
+def test_batch_separate_components_and_rgb(lib):
+    """-s semantics (three compute(1, ...) with their own weights / iteration counts, jpeg2png.c:147-152) and the
+    RGB output path against three single solvers + j2p_planes_to_rgb"""
+    import ctypes
+    import jpeg2png_amd as j
+    planes = make_case(200, 136, "420", 10, seed=71)
+    weights, its = [0.3, 0.1, 0.0], [20, 9, 5]
+    with j.Batch(devices=[0], slots_per_device=2) as b:
+        t8 = b.submit(planes, weights, [0.001] * 3, its, separate=True, width=200, height=136, bits=8)
+        t16 = b.submit(planes, weights, [0.001] * 3, its, separate=True, width=200, height=136, bits=16)
+        tf = b.submit(planes, weights, [0.001] * 3, its, separate=True)
+        rgb8, rgb16, fl = b.wait(t8), b.wait(t16), b.wait(tf)
+    solvers = [j.Solver([planes[c]], weights[c], [0.001], its[c]) for c in range(3)]
+    for c, s in enumerate(solvers):
+        s.run(its[c])
+        assert bit_equal(fl[c], s.download(0))
+
+    class Ref(ctypes.Structure):
+        _fields_ = [("solver", ctypes.c_void_p), ("channel", ctypes.c_uint)]
+    lib.j2p_planes_to_rgb.argtypes = [ctypes.POINTER(Ref), ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p]
+    for bits, got in ((8, rgb8), (16, rgb16)):
+        refs = (Ref * 3)(*[Ref(s._h, 0) for s in solvers])
+        want = np.empty_like(got)
+        assert lib.j2p_planes_to_rgb(refs, 200, 136, bits, want.ctypes.data) == 0
+        assert np.array_equal(got, want)
+    for s in solvers:
+        s.close()
+
+
+def test_batch_reports_a_bad_job_and_carries_on(lib):
+    import jpeg2png_amd as j
+    good = make_case(64, 48, "444", 20, seed=3)
+    bad = copy.deepcopy(good)
+    bad[1].quant_table = np.zeros(64, np.uint16)               # jpeg.c:41-45
+    with j.Batch(devices=[0], slots_per_device=2) as b:
+        tb = b.submit(bad, 0.3, [0.001] * 3, 4)
+        tg = b.submit(good, 0.3, [0.001] * 3, 4)
+        with pytest.raises(j.J2PError, match="quantization table"):
+            b.wait(tb)
+        out = b.wait(tg)
+    ref = copy.deepcopy(good)
+    j.compute(ref, 0.3, [0.001] * 3, 4)
+    assert bit_equal(out[0], ref[0].fdata)
+
+
+def test_pool_recycles_arenas(lib):
+    """after a first solver of a given size, the next ones on the device get its memory back: same address"""
+    import jpeg2png_amd as j
+    planes = make_case(256, 192, "420", 10, seed=8)
+    lib.j2p_pool_trim()
+    s1 = j.Solver(planes, 0.3, [0.001] * 3, 4)
+    a1 = s1.plane_ptr(0)
+    s1.close()
+    s2 = j.Solver(planes, 0.3, [0.001] * 3, 4)
+    a2 = s2.plane_ptr(0)
+    s2.run(4)
+    out = [s2.download(c) for c in range(3)]
+    s2.close()
+    assert a1 == a2
+    ref = copy.deepcopy(planes)
+    j.compute(ref, 0.3, [0.001] * 3, 4)
+    for c in range(3):
+        assert bit_equal(out[c], ref[c].fdata)          # a recycled (dirty) arena changes nothing
+    lib.j2p_pool_trim()

@@ -112,3 +112,41 @@ def test_drop_in_compute_struct_layout(lib):
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
         out = subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()
     assert [int(x) for x in out] == [160, 12, 16, 24, 32, 24]
+
+
+def test_struct_layouts_against_the_reference_headers(lib, tmp_path):
+    """where /root/reference is present (this container): the same offsets printed once from the reference's own
+    headers (jpeg2png.h, logger.h, progressbar.h) and once from include/jpeg2png_amd_compute.h must agree — and a
+    translation unit that includes the reference's headers FIRST must still compile with ours on top (the include
+    guards then skip the re-definitions), with identical prototypes for compute()."""
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "jpeg2png.h")):
+        pytest.skip("/root/reference not present")
+    body = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    HEADERS
+    int main(void) {
+        printf("%zu %zu %zu %zu %zu %zu %zu %zu|", sizeof(struct coef), offsetof(struct coef, h), offsetof(struct coef, w),
+               offsetof(struct coef, h_samp), offsetof(struct coef, w_samp), offsetof(struct coef, data),
+               offsetof(struct coef, fdata), offsetof(struct coef, quant_table));
+        printf("%zu %zu %zu %zu %zu|", sizeof(struct logger), offsetof(struct logger, f), offsetof(struct logger, filename),
+               offsetof(struct logger, channel), offsetof(struct logger, iteration));
+        printf("%zu %zu %zu\n", sizeof(struct progressbar), offsetof(struct progressbar, current), offsetof(struct progressbar, max));
+        return 0;
+    }'''
+    outs = []
+    variants = {
+        "ref": '#include "jpeg2png.h"\n#include "logger.h"\n#include "progressbar.h"\n#include "compute.h"',
+        "ours": '#include "jpeg2png_amd_compute.h"',
+        # both: the reference's first, ours on top — also checks that the two compute() prototypes are compatible
+        "both": '#include "jpeg2png.h"\n#include "logger.h"\n#include "progressbar.h"\n#include "compute.h"\n#include "jpeg2png_amd_compute.h"',
+    }
+    for name, headers in variants.items():
+        c = tmp_path / f"{name}.c"
+        c.write_text(body.replace("HEADERS", headers))
+        exe = tmp_path / name
+        subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-iquote", ref, "-I", ref, str(c), "-o", str(exe)],
+                       check=True)
+        outs.append(subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout)
+    assert outs[0] == outs[1] == outs[2], outs

@@ -148,3 +148,89 @@ def test_default_and_long_iteration_counts(cli):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_long.py")], cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+REF_DROPIN = os.path.join(ROOT, "oracle", "_ref", "jpeg2png_ref_dropin")
+
+
+def _csv_rows(path):
+    rows = np.loadtxt(path, delimiter=",", skiprows=1, usecols=(1, 2, 3, 4, 5, 6), ndmin=2)
+    names = [line.split(",")[0] for line in open(path).read().splitlines()[1:]]
+    order = sorted(range(len(names)), key=lambda i: (names[i], rows[i, 0], rows[i, 1]))
+    return [names[i] for i in order], rows[order]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [["-i", "21"], ["-s", "-i", "40,9,5", "-w", "0.3,0.1,0"], ["-i", "6", "-w", "0", "-1"]],
+                         ids=["joint", "separate", "tv_only_16bit"])
+@pytest.mark.parametrize("threads", ["1", "4"])
+def test_the_reference_program_itself_runs_on_the_library(tmp_path, flags, threads):
+    """THE DROP-IN PROOF.  oracle/_ref/jpeg2png_ref_dropin is the reference's own main(), option parser, JPEG
+    reader, PNG writer, logger.c and progressbar.c — every reference source except compute.c — linked against
+    libjpeg2png_amd.so (the change INTEGRATION.md §2 shows for the reference Makefile:32-33).  Same JPEGs
+    through it and through the unmodified reference program: PNG bytes identical, CSV rows identical to the 6
+    decimals logger.c:23 prints.  With -t 4 the reference's nested OpenMP regions (jpeg2png.c:147 components,
+    :330 files) call the library's compute() from several threads at once, sharing its progress bar."""
+    if not (os.path.exists(REF_CLI) and os.path.exists(REF_DROPIN)):
+        pytest.skip("oracle/_ref/jpeg2png_ref(_dropin) not built (needs /root/reference)")
+    sys.path.insert(0, ROOT)
+    names = []
+    for i, (w, h, q, sub) in enumerate([(200, 136, 10, 2), (96, 64, 30, 0), (133, 77, 12, 1), (64, 48, 50, 2)]):
+        p = tmp_path / f"img{i}.jpg"
+        make_jpeg(p, w, h, q, sub, seed=40 + i)
+        names.append(str(p))
+    outs = {}
+    for tag, exe in (("ref", REF_CLI), ("dropin", REF_DROPIN)):
+        d = tmp_path / tag
+        d.mkdir()
+        args = []
+        for i, n in enumerate(names):
+            args += ["-o", str(d / f"o{i}.png")]
+        r = run(exe, *names, *args, "-c", str(d / "log.csv"), "-t", threads, *flags)
+        assert r.returncode == 0, r.stderr
+        assert "100%" in r.stdout                      # the reference's own progress bar ran to the end
+        outs[tag] = d
+    for i in range(len(names)):
+        assert (outs["ref"] / f"o{i}.png").read_bytes() == (outs["dropin"] / f"o{i}.png").read_bytes(), f"file {i}"
+    rn, rr = _csv_rows(outs["ref"] / "log.csv")
+    dn, dr = _csv_rows(outs["dropin"] / "log.csv")
+    assert rn == dn and rr.shape == dr.shape
+    np.testing.assert_allclose(dr, rr, rtol=0, atol=2e-6 * max(1.0, np.abs(rr).max()))
+
+
+@pytest.mark.gpu
+def test_truncated_jpeg_warns_and_carries_on_like_the_reference(cli, tmp_path):
+    """libjpeg reports a premature end of file through output_message; the reference prints it
+    (`jpeg2png: libjpeg error: ...`, jpeg.c:14-19) and decodes what is there.  So must the CLI — and the drop-in."""
+    if not os.path.exists(REF_CLI):
+        pytest.skip("oracle/_ref/jpeg2png_ref not built (needs /root/reference)")
+    jpg = tmp_path / "full.jpg"
+    make_jpeg(jpg, 160, 120, 30, 2, seed=5)
+    data = jpg.read_bytes()
+    cut = tmp_path / "cut.jpg"
+    cut.write_bytes(data[: len(data) * 2 // 3])
+    r = run(REF_CLI, str(cut), "-o", str(tmp_path / "ref.png"), "-q", "-i", "5")
+    g = run(cli, str(cut), "-o", str(tmp_path / "gpu.png"), "-q", "-i", "5")
+    assert r.returncode == 0 and g.returncode == 0, (r.stderr, g.stderr)
+    assert "libjpeg error" in r.stderr
+    assert g.stderr == r.stderr
+    assert (tmp_path / "ref.png").read_bytes() == (tmp_path / "gpu.png").read_bytes()
+    if os.path.exists(REF_DROPIN):
+        d = run(REF_DROPIN, str(cut), "-o", str(tmp_path / "dropin.png"), "-q", "-i", "5")
+        assert d.returncode == 0 and d.stderr == r.stderr
+        assert (tmp_path / "ref.png").read_bytes() == (tmp_path / "dropin.png").read_bytes()
+
+
+def test_truncated_jpeg_message_without_a_gpu(cli, tmp_path):
+    """CPU half of the above: the warning is printed in the reference's format and is not fatal by itself (what
+    follows — creating the solver — is, on a box without a GPU)"""
+    jpg = tmp_path / "full.jpg"
+    make_jpeg(jpg, 160, 120, 30, 2, seed=5)
+    data = jpg.read_bytes()
+    cut = tmp_path / "cut.jpg"
+    cut.write_bytes(data[: len(data) * 2 // 3])
+    g = run(cli, str(cut), "-o", str(tmp_path / "gpu.png"), "-q", "-i", "2")
+    lines = g.stderr.strip().splitlines()
+    assert lines and lines[0].startswith("jpeg2png: libjpeg error: ")
+    if g.returncode != 0:      # no GPU here: the next line must be the loud "no device" failure, not the warning
+        assert len(lines) >= 2 and "HIP device" in lines[-1]

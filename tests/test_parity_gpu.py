@@ -197,10 +197,12 @@ def test_band_split_matches_whole(lib, oracle):
     assert bit_equal(got, want)
 
 
-def test_drop_in_compute_from_c(lib, oracle, tmp_path):
+@pytest.mark.parametrize("mode", ["compute", "tiled:2", "tiled:3"])
+def test_drop_in_compute_from_c(lib, oracle, tmp_path, mode):
     """the C `compute()` with the reference's signature, called from a C host program that
     provides logger_log / progressbar_inc like jpeg2png.c does: planes, canvas size rewrite,
-    one log row and one progress tick per iteration (compute.c:428,272,449-452,455-461)."""
+    one log row and one progress tick per iteration (compute.c:428,272,449-452,455-461).
+    mode tiled:<n>: the same call through j2p_compute_tiled with n row bands on device 0."""
     import os
     import struct
     import subprocess
@@ -209,7 +211,7 @@ def test_drop_in_compute_from_c(lib, oracle, tmp_path):
     exe = tmp_path / "dropin"
     subprocess.run(["gcc", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "dropin_main.c"),
                     "-o", str(exe), j.LIB_PATH, "-Wl,-rpath," + os.path.dirname(j.LIB_PATH)], check=True)
-    planes = make_case(72, 40, "420", 10, seed=31)
+    planes = make_case(72, 40 if mode == "compute" else 150, "420", 10, seed=31)
     its, weight, pw = 37, 0.3, [0.001, 0.001, 0.001]       # 37: not a multiple of the host chunk size
     blob = struct.pack("<IIf3f", len(planes), its, weight, *pw)
     for p in planes:
@@ -217,7 +219,8 @@ def test_drop_in_compute_from_c(lib, oracle, tmp_path):
         blob += np.ascontiguousarray(p.data, np.int16).tobytes() + np.ascontiguousarray(p.fdata, np.float32).tobytes()
         blob += np.ascontiguousarray(p.quant_table, np.uint16).tobytes()
     (tmp_path / "in.bin").write_bytes(blob)
-    subprocess.run([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "log.csv")], check=True)
+    extra = [] if mode == "compute" else [mode]
+    subprocess.run([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "log.csv"), *extra], check=True)
     want, want_log = oracle.oracle_compute(planes, weight, pw, its, log=True)
     raw = (tmp_path / "out.bin").read_bytes()
     ticks = struct.unpack_from("<I", raw, 0)[0]
@@ -659,19 +662,6 @@ def test_extreme_shapes_against_the_compiled_reference(lib, oracle):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "extreme_shapes.py")], cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-
-
-@pytest.mark.skipif(os.environ.get("J2P_SLOW_TESTS", "0") != "1", reason="~90 s of CPU for the reference; set J2P_SLOW_TESTS=1")
-def test_the_bench_workload_itself_is_bit_identical(lib, oracle):
-    """tools/headline_parity.py: 4096x4096 Y Q10 -i 500 (the configuration bench.py times) against the unmodified
-    reference.  Measured on MI355X: bit-identical; 89.0 s in the reference's compute() vs 0.096 s host to host."""
-    if not oracle.have_ref():
-        pytest.skip("oracle/_ref not built (needs /root/reference)")
-    import subprocess
-    import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "headline_parity.py")], cwd=ROOT,
-                       capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0 and "bit-identical True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_wide_randomised_sweep_against_the_compiled_reference(lib, oracle):

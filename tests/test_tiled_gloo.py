@@ -93,6 +93,86 @@ class CpuBandEngine:
     def result(self):
         return self.buf[self.cur][HALO:HALO + self.rows].clone()
 
+    # ---- the two-part phases of the overlap schedule (tiled.RowTiledSolver(overlap=True)) ----
+    # Same arithmetic as above cut at the same places as the HIP engine: the gradient's interior 16-row segments
+    # read no halo row; the projection's first and last 8 rows (the rows the neighbours need) come first and
+    # halo() then refers to the iterate being written.
+    @property
+    def can_split(self):
+        return self.rows >= 3 * TILE
+
+    def _fista(self):
+        tn = (1 + np.sqrt(1 + 4 * self.t * self.t)) / 2
+        self.factor = np.float32((self.t - 1) / tn)
+        self.t = tn
+
+    def _gradient_rows(self, a, b):
+        x, xp = self.buf[self.cur], self.buf[self.cur ^ 1]
+        lo, hi = a + HALO - 2, b + HALO + 2                       # buffer rows needed for band rows [a, b)
+        y = x[lo:hi] + self.factor * (x[lo:hi] - xp[lo:hi])
+        n = b - a
+        c = y[2:2 + n]
+        g = torch.zeros(n, self.W)
+        g += 6 * c - 4 * (y[1:1 + n] + y[3:3 + n])
+        g += y[0:n] + y[4:4 + n]                                   # same association as phase_gradient
+        g[:, 1:] += c[:, 1:] - c[:, :-1]
+        self.g[a:b] = g
+        self.y[a:b] = c
+        sq = (g.double() ** 2).reshape((b - a) // TILE, TILE * self.W)
+        self.partials_local[a // TILE:b // TILE] = sq.sum(dim=1)
+
+    def gradient_interior(self):
+        self._fista()
+        self.y = torch.zeros(self.rows, self.W)
+        self.g = torch.zeros(self.rows, self.W)
+        self._gradient_rows(TILE, self.rows - TILE)
+
+    def gradient_edges_inline(self, halo_ready=None):
+        self._gradient_rows(0, TILE)
+        self._gradient_rows(self.rows - TILE, self.rows)
+
+    def finish_gradient(self):
+        pass
+
+    def _norm(self):
+        v = self.partials_all.clone()
+        n = 1
+        while n < v.numel():
+            n *= 2
+        v = torch.cat([v, torch.zeros(n - v.numel(), dtype=torch.float64)])
+        while v.numel() > 1:
+            h = v.numel() // 2
+            v = v[:h] + v[h:]
+        return torch.sqrt(v[0].float())
+
+    def _project_rows(self, a, b):
+        new = self.y[a:b] - np.float32(self.step) * (self.g[a:b] / self.norm)
+        self.buf[self.cur ^ 1][HALO + a:HALO + b] = new
+
+    def project_boundary(self):
+        self.norm = self._norm()
+        self._project_rows(0, 8)
+        self._project_rows(self.rows - 8, self.rows)
+        self.cur ^= 1               # halo() now addresses the new iterate; project_interior writes the same buffer
+
+    def project_interior(self):
+        self.cur ^= 1
+        self._project_rows(8, self.rows - 8)
+        self.cur ^= 1
+
+    def project_done_event(self):
+        return None
+
+    def comm_context(self, after):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def comm_done_event(self):
+        return None
+
+    def wait_halo(self, event):
+        pass
+
 
 def _free_port():
     s = socket.socket()
@@ -102,7 +182,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, H, W, its, bands, out_dir):
+def _worker(rank, world, port, H, W, its, bands, out_dir, overlap=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -111,16 +191,17 @@ def _worker(rank, world, port, H, W, its, bands, out_dir):
     torch.manual_seed(0)
     full = torch.randn(H, W, dtype=torch.float32) * 20
     eng = CpuBandEngine(full, bands[rank], its)
-    drv = tiled.RowTiledSolver(eng)
+    drv = tiled.RowTiledSolver(eng, overlap=overlap)
+    assert drv.overlap == overlap
     drv.start()
     drv.iterate(its)
     np.save(os.path.join(out_dir, f"band{rank}.npy"), eng.result().numpy())
     dist.destroy_process_group()
 
 
-def _run(world, H, W, its, bands, tmp_path):
+def _run(world, H, W, its, bands, tmp_path, overlap=False):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, H, W, its, bands, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, H, W, its, bands, str(tmp_path), overlap), nprocs=world, join=True)
     return np.concatenate([np.load(os.path.join(tmp_path, f"band{r}.npy")) for r in range(world)], axis=0)
 
 
@@ -145,4 +226,19 @@ def test_two_ranks_equal_one_rank(tmp_path, bands2):
     a = _run(1, H, W, its, [(0, H)], one)
     b = _run(2, H, W, its, bands2, two)
     assert a.shape == b.shape == (H, W)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("bands2", [[(0, 64), (64, 128)], [(0, 48), (48, 128)]], ids=["equal", "unequal"])
+def test_overlap_schedule_with_two_ranks(tmp_path, bands2):
+    """RowTiledSolver(overlap=True) with world_size 2: the projection's edge rows first, the halo exchange issued
+    behind them, the interior of the next gradient phase before the edge segments — against the plain schedule
+    on one rank"""
+    H, W, its = 128, 40, 6
+    one = tmp_path / "one"
+    two = tmp_path / "two"
+    one.mkdir()
+    two.mkdir()
+    a = _run(1, H, W, its, [(0, H)], one)
+    b = _run(2, H, W, its, bands2, two, overlap=True)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
