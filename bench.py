@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--force-tiled", action="store_true", help="run the row-tiled path even with one rank (debug)")
     ap.add_argument("--bands", type=int, default=0, help="--force-tiled on one GPU: number of bands on device 0")
     ap.add_argument("--tiled-impl", choices=["c", "rccl"], default="c")
-    ap.add_argument("--norm-fold", type=int, default=1, help="0: the round-1 stand-alone norm kernels (A/B)")
+    ap.add_argument("--norm-fold", type=int, default=0, help="0: the round-1 stand-alone norm kernels (A/B)")
     return ap.parse_args()
 
 
@@ -121,7 +121,7 @@ def cpu_baseline(width, seed):
     # jpeg2png.c:330): the 4096-row plane cut into 512-row pieces, each thread solves one piece, 20 iterations
     ncores = os.cpu_count() or 1
     nthreads = min(ncores, 256)
-    piece_rows, its_all = 512, 20
+    piece_rows, its_all = 512, 10
     pieces = []
     for k in range(8):
         pl = synth.make_planes(width, 4096, "444", 10, seed=seed, y_only=True, rows=(k * piece_rows, (k + 1) * piece_rows))

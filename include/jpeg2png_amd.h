@@ -94,8 +94,9 @@ void j2p_pool_trim(void);
 
 /* diagnostics: schedule switches that change speed, never results (A/B timing and the parity tests of both
  * schedules).  Only between iterations. */
-#define J2P_OPT_NORM_FOLD     1   /* 1 (default): ||g|| is reduced inside the gradient kernel by its last-arriving
-                                     wavefronts; 0: separate reduction kernels (the round-1 schedule) */
+#define J2P_OPT_NORM_FOLD     1   /* 1 (default for band solvers): ||g|| is reduced inside the gradient kernel by its
+                                     last-arriving wavefronts; 0 (default for whole-canvas solvers): separate
+                                     reduction kernels — same bits, and on a whole canvas the same speed */
 #define J2P_OPT_JOINT_INWAVE  2   /* 1: all channels of a joint image in one wavefront; 0 (default): one wavefront
                                      per channel.  Environment J2P_JOINT_INWAVE sets the default at create time */
 int j2p_solver_debug_option(j2p_solver *s, int option, int value);
@@ -171,9 +172,13 @@ int j2p_solver_exchange_info(j2p_solver *s, j2p_exchange *info);
  *                       iteration k (0-based) lives in buffer (k + 1) & 1 — independent of the solver's state
  *   norm_from_bands   : between the two phases: ||g|| from every band's level-1 sums (partials_local), read in
  *                       place; replaces the all-gather into partials_all
+ *   alternate_rowsums : band solvers: from now on iteration k leaves its level-1 sums in buffers[k & 1] (returned;
+ *                       buffers[0] is partials_local), so that a band may start its next gradient phase while
+ *                       slower bands are still reading this iteration's sums
  *   copy_rows         : n row blocks copied on the solver's stream (the neighbours' edge rows into its halo rows) */
 int j2p_solver_stream(j2p_solver *s, void **stream);
 int j2p_solver_halo_rows(j2p_solver *s, int buffer, j2p_exchange *info);
+int j2p_solver_alternate_rowsums(j2p_solver *s, const double *buffers[2]);
 int j2p_solver_norm_from_bands(j2p_solver *s, unsigned nband, const double *const rowsums[],
                                const unsigned first_tile_row[], const unsigned tile_rows[]);
 int j2p_solver_copy_rows(j2p_solver *s, unsigned n, float *const dst[], const float *const src[], size_t floats);
@@ -258,8 +263,9 @@ typedef struct j2p_job {
         float pweight[J2P_MAX_CHANNELS];
         unsigned iterations[J2P_MAX_CHANNELS];
         /* output: out_bits 8 / 16 = RGB samples (png.c:37-62 incl. the luma +128 of jpeg2png.c:156-159), cropped to
-         * out_w x out_h, into out_rgb (h*w*3 or h*w*6 bytes); out_bits 0 = the W*H float canvas planes into
-         * out_planes[c] (NULL entries are skipped) */
+         * out_w x out_h, into out_rgb (h*w*3 or h*w*6 bytes); out_bits 0 = the float canvas planes into
+         * out_planes[c] (NULL entries are skipped): W*H floats of the joint canvas, or — separate — of component
+         * c's own canvas, w*w_samp x h*h_samp (compute.c:410-416 per call) */
         unsigned out_bits, out_w, out_h;
         uint8_t *out_rgb;
         float *out_planes[J2P_MAX_CHANNELS];

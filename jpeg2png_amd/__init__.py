@@ -76,7 +76,7 @@ C_ABI_SYMBOLS = [
     "j2p_solver_plane_ptr", "j2p_solver_sync", "j2p_solver_kernel_times", "j2p_solver_enable_timing",
     "j2p_decode_plane", "j2p_dct8x8_blocks", "j2p_math_selftest", "j2p_planes_to_rgb", "j2p_sqrt_exhaustive",
     "j2p_pool_trim", "j2p_solver_debug_option", "j2p_solver_stream", "j2p_solver_halo_rows",
-    "j2p_solver_norm_from_bands", "j2p_solver_copy_rows",
+    "j2p_solver_norm_from_bands", "j2p_solver_copy_rows", "j2p_solver_alternate_rowsums",
     "j2p_tiled_create", "j2p_tiled_destroy", "j2p_tiled_canvas", "j2p_tiled_band", "j2p_tiled_run", "j2p_tiled_reset", "j2p_tiled_sync",
     "j2p_tiled_download",
     "j2p_batch_create", "j2p_batch_destroy", "j2p_batch_submit", "j2p_batch_wait",
@@ -468,14 +468,17 @@ class Batch:
         its = list(iterations) if isinstance(iterations, (list, tuple)) else [iterations] * n
         for c in range(n):
             job.weight[c], job.pweight[c], job.iterations[c] = float(ws[c]), float(pweight[c]), int(its[c])
+        # canvas of a compute() call (compute.c:410-416): all components' for a joint solve, its own for each of the
+        # separate calls of `-s` (jpeg2png.c:147-152)
         W = max(p.w * p.w_samp for p in planes)
         H = max(p.h * p.h_samp for p in planes)
+        shapes = [(p.h * p.h_samp, p.w * p.w_samp) if separate else (H, W) for p in planes]
         if bits:
             out = np.empty((height, width, 3), dtype=np.uint8 if bits == 8 else ">u2")
             job.out_bits, job.out_w, job.out_h = bits, width, height
             job.out_rgb = out.ctypes.data
         else:
-            out = [np.empty((H, W), dtype=np.float32) for _ in range(n)]
+            out = [np.empty(shapes[c], dtype=np.float32) for c in range(n)]
             for c in range(n):
                 job.out_planes[c] = out[c].ctypes.data
         t = ctypes.c_int()

@@ -158,8 +158,8 @@ struct Geo {
         unsigned row0;      // first canvas row of the band
         unsigned rows;      // band rows
         unsigned ntx;       // gradient strips (wavefronts) per row of strips
-        unsigned rpw;       // rows per gradient strip (multiple of kTY)
-        const unsigned *seg_row;   // [nseg + 1] first band-local row of every row segment (multiples of kTY)
+        unsigned rpw;       // rows per gradient strip = rows per norm partial: 16, or 8 / 4 on small canvases
+        const unsigned *seg_row;   // [nseg + 1] first band-local row of every row segment (multiples of rpw)
         const unsigned *seg_map;   // [gridDim.y] segments this launch processes (all, interior only, or the two edge ones)
 };
 
@@ -196,7 +196,8 @@ struct ProjArgs {
         unsigned by_offset, by_mul, nby;
 };
 
-// rows per norm partial: the granularity of the GPU-count invariant reduction (J2P_TILE_ROWS)
+// rows per norm partial on canvases large enough to fill the chip: the granularity of the GPU-count invariant
+// reduction, and what band boundaries are aligned to (J2P_TILE_ROWS).  Small canvases use 8 or 4 (Geo::rpw).
 constexpr int kTY = 16;
 
 // deterministic block-wide sum of one double per thread (256 threads); result valid in thread 0
@@ -554,8 +555,7 @@ __device__ __forceinline__ void source_terms_joint(int cidx, int lane, int parit
 // Norm reduction folded into k_gradient (no separate launch, nothing serial between the two phases).
 // Same arithmetic as strip_sum / tree_sum_lds below — a fixed function of the partial array, whoever
 // evaluates it — so the norm is bit-identical to the stand-alone kernels' and independent of the order in
-// which wavefronts arrive.  Cross-workgroup hand-over: writer = store, release fence, ticket; last arriver =
-// ticket, acquire fence, loads (agent scope: the XCDs' L2s are not coherent with each other otherwise).
+// which wavefronts arrive.  Cross-workgroup hand-over: see fold_arrive.
 // ---------------------------------------------------------------------------
 constexpr unsigned kFoldMaxRows = 1024;      // tile rows the in-kernel tree handles (canvas height <= 16384)
 
@@ -615,24 +615,38 @@ __device__ __forceinline__ void fold_tree(const GradArgs &a, double *buf, int la
         }
 }
 
-// called by a wavefront that has just stored `mine` partials of tile row tr (wave-uniform arguments)
+// Hand-over between wavefronts on different CUs / XCDs WITHOUT cache maintenance.  A release fence at agent scope
+// costs a write-back of the XCD's whole L2 (buffer_wbl2) per wavefront — measured: k_gradient 64 -> 379 us at
+// 4096^2 with one fence per strip.  Instead every value that crosses (partials, row sums, tickets) is written and
+// read with agent-scope atomic accesses (sc1: performed at the device-coherent level, not in the XCD's L2), the
+// producer waits for its stores to be acknowledged (s_waitcnt) before it draws its ticket, and the consumer's
+// loads depend on the ticket's value — so no other cached data has to move.
+__device__ __forceinline__ void publish_double(double *p, double v)
+{
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stores_acknowledged()
+{
+        __builtin_amdgcn_s_waitcnt(0);         // vmcnt(0) expcnt(0) lgkmcnt(0): every store of this wavefront has been acknowledged
+}
+
+// called by a wavefront whose lane 0 has just published `mine` partials of tile row tr (wave-uniform arguments)
 __device__ __forceinline__ void fold_arrive(const GradArgs &a, unsigned tr, unsigned mine, size_t nparts, double *buf, int lane)
 {
         unsigned old = 0;
-        if(lane == 0) { old = __hip_atomic_fetch_add(a.row_ticket + tr, mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+        stores_acknowledged();
+        if(lane == 0) { old = __hip_atomic_fetch_add(a.row_ticket + tr, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
         if(old + mine != a.geo.ntx * a.nch_total) { return; }
-        // last strip of this tile row: everybody else's partials are visible after the acquire
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // last strip of this tile row: every other strip's partials were acknowledged before its ticket
         fold_tile_row(a, tr, nparts, lane);
         if(lane == 0) { __hip_atomic_store(a.row_ticket + tr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // ready for the next launch
         if(!a.norm_out) { return; }
         unsigned done = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");           // the row sums of lanes 0, 8, 16 before the ticket
-        if(lane == 0) { done = __hip_atomic_fetch_add(a.done_ticket, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+        stores_acknowledged();                                       // the row sums of lanes 0, 8, 16 before the ticket
+        if(lane == 0) { done = __hip_atomic_fetch_add(a.done_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         done = (unsigned)__builtin_amdgcn_readfirstlane((int)done);
         if(done + 1 != a.fold_rows) { return; }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         fold_tree(a, buf, lane);
         if(lane == 0) { __hip_atomic_store(a.done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
@@ -790,7 +804,7 @@ void k_gradient(GradArgs a)
 #pragma unroll
         for(int c = 0; c < NCH; c++) { g2[c] = 0.; }
         const size_t ntiles_row = a.geo.ntx;
-        const size_t nparts = (size_t)((rows + kTY - 1) / kTY) * ntiles_row;
+        const size_t nparts = (size_t)((rows + (int)a.geo.rpw - 1) / (int)a.geo.rpw) * ntiles_row;
         constexpr int R = NCH == 1 ? kRing : 3;
 
         // The march over the strip's rows, compiled twice: once general, once for strips that touch neither an
@@ -932,17 +946,17 @@ void k_gradient(GradArgs a)
                 else if(__builtin_amdgcn_readfirstlane(seg_free ? 1 : 0)) { march(MarchTag<true, false>{}); }
                 else { march(MarchTag<false, false>{}); }
         }
-        // One partial per strip and 16-row tile row — a segment IS one tile row — the granularity of the
+        // One partial per strip and tile row (16 rows; 8 or 4 on small canvases) — a segment IS one tile row — the granularity of the
         // GPU-count invariant norm reduction; then the strip reports in (fold_arrive) and, if it is the last
         // of its tile row / of the launch, finishes the reduction.
         {
-                const unsigned tr = (unsigned)t0 / kTY;
+                const unsigned tr = (unsigned)t0 / a.geo.rpw;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
                         double v = g2[c];
 #pragma unroll
                         for(int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); }
-                        if(lane == 0) { a.part_g2[(cbase + c) * nparts + (size_t)tr * ntiles_row + wcol] = v; }
+                        if(lane == 0) { publish_double(&a.part_g2[(cbase + c) * nparts + (size_t)tr * ntiles_row + wcol], v); }
                 }
                 if(a.row_ticket) { fold_arrive(a, tr, (unsigned)NCH, nparts, fold_buf, lane); }
         }
@@ -1025,7 +1039,7 @@ __global__ __launch_bounds__(256) void k_rowsums(const double *part, double *row
         }
 }
 
-constexpr int kMaxTileRows = 4096;   // canvas height <= 65536 (JPEG limit) / kTY
+constexpr int kMaxTileRows = 4096;   // canvas height <= 65536 (JPEG limit) / kTY; shorter tile rows only on small canvases
 
 __device__ __forceinline__ double tree_sum_lds(double *buf, unsigned n, unsigned P)
 {

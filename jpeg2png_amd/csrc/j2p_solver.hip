@@ -92,7 +92,7 @@ struct j2p_solver {
         void *arena = nullptr;   // the one device allocation everything below is carved from (pooled, see pool_take)
         size_t arena_bytes = 0;
         // reductions
-        bool fold = true;        // norm reduction folded into k_gradient (J2P_OPT_NORM_FOLD)
+        bool fold = false;       // norm reduction folded into k_gradient (J2P_OPT_NORM_FOLD); default: band solvers only
         bool joint_inwave = false;   // J2P_OPT_JOINT_INWAVE
         bool norm_ready = false; // the gradient launch of this iteration also produced norm[]
         unsigned *tickets = nullptr;     // device: [ntr_local] per-tile-row arrival counters + [1] finished-rows counter
@@ -103,6 +103,8 @@ struct j2p_solver {
         bool rowsums_pending = false;
         unsigned ntx = 0, nseg = 0, ntr_local = 0, ntr_global = 0, first_tr = 0;   // strips per row, row segments
         double *part_g2 = nullptr;       // [c][ntr_local][ntx]
+        double *rowsum_odd = nullptr;    // band solvers: second level-1 buffer, used by odd iterations once rowsum_alternate is on
+        bool rowsum_alternate = false;
         double *rowsum_local = nullptr;  // [ntr_local][c]
         double *rowsum_all = nullptr;    // [ntr_global][c]  (== rowsum_local when whole)
         float *norm = nullptr;           // [c]
@@ -370,7 +372,7 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         const bool fold_norm = s->fold && s->whole && part == 0 && s->ntr_global <= kFoldMaxRows;
         a.row_ticket = s->fold ? s->tickets : nullptr;
         a.done_ticket = s->tickets + s->ntr_local;
-        a.rowsum = s->rowsum_local;
+        a.rowsum = (s->rowsum_alternate && (s->iter & 1)) ? s->rowsum_odd : s->rowsum_local;
         a.norm_out = fold_norm ? s->norm : nullptr;
         a.nch_total = s->nch;
         a.fold_rows = s->ntr_local;
@@ -614,7 +616,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 if(p.h * p.h_samp > H) { H = p.h * p.h_samp; }
                 align = lcm_u(align, 8 * p.h_samp);
         }
-        if(H > (unsigned)kMaxTileRows * kTY) { return fail(J2P_EINVAL, "canvas height %u exceeds %u", H, kMaxTileRows * kTY); }
+        if(H > (unsigned)kMaxTileRows * kTY) { return fail(J2P_EINVAL, "canvas height %u exceeds %u", H, kMaxTileRows * kTY); }   // (shorter tile rows: only far below)
         bool whole = band.row_begin == 0 && (band.row_end == 0 || band.row_end >= H);
         unsigned row0 = whole ? 0 : band.row_begin, row1 = whole ? H : band.row_end;
         if(!whole) {
@@ -646,6 +648,10 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         s->row0 = row0;
         s->rows = row1 - row0;
         s->whole = whole;
+        // the in-kernel reduction is worth its serial tail only for band solvers, where it replaces a launch AND lets
+        // the row sums alternate between two buffers (measured on whole canvases: 4096^2 140.0 us per iteration either
+        // way, 512^2 4:2:0 42.0 vs 40.3 us — the tail costs what the k_norm_whole launch did)
+        s->fold = !whole;
         s->band_local = !whole && band_local_arrays != 0;
         s->weight = weight;
         s->iterations = iterations;
@@ -706,11 +712,22 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         }
         // reductions: tile rows are counted on the canvas, the band owns a contiguous range
         s->ntx = W <= 4 ? 1 : (W - 4 + kStripCols - 1) / kStripCols;   // n strips cover 124 n + 4 columns
-        s->rpw = kTY;                                                  // rows per gradient strip (32/48/64 measured no faster)
+        // Rows per gradient strip = rows per norm partial ("tile row").  16 on canvases that fill the chip (32/48/64
+        // measured no faster).  A small canvas is latency-bound INSIDE k_gradient — 512x512 4:2:0: 480
+        // wavefronts of 18 dependent row trips each on a chip with 4096 wavefront slots, 21 us; launch gaps are ~0
+        // (profiles/r02_small_planes.md) — so it gets more and shorter strips: 8 or 4 rows while the canvas has fewer
+        // than 1024 strips.  A function of the CANVAS only (never of the band), so that every band of a tiled run —
+        // and the whole-canvas solver — reduce ||g|| over the same partials in the same order.
+        {
+                const unsigned per_strip_row = s->ntx * nchannel;       // one wavefront per channel and strip
+                unsigned g = kTY;
+                while(g > 4 && (unsigned long long)per_strip_row * ((H + g - 1) / g) < 1024ull) { g >>= 1; }
+                s->rpw = g;
+        }
         s->nseg = (s->rows + s->rpw - 1) / s->rpw;
-        s->ntr_local = (s->rows + kTY - 1) / kTY;
-        s->ntr_global = (H + kTY - 1) / kTY;
-        s->first_tr = row0 / kTY;
+        s->ntr_local = s->nseg;
+        s->ntr_global = (H + s->rpw - 1) / s->rpw;
+        s->first_tr = row0 / s->rpw;
         const size_t ntiles = (size_t)s->ntx * s->ntr_local;
         unsigned max_strips = 0;
         for(unsigned c = 0; c < nchannel; c++) {
@@ -753,7 +770,10 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 carve.take(s->part_g2, ntiles * nchannel);
                 carve.take(s->rowsum_local, (size_t)s->ntr_local * nchannel);
                 if(whole) { s->rowsum_all = s->rowsum_local; }
-                else { carve.take(s->rowsum_all, (size_t)s->ntr_global * nchannel); }
+                else {
+                        carve.take(s->rowsum_all, (size_t)s->ntr_global * nchannel);
+                        carve.take(s->rowsum_odd, (size_t)s->ntr_local * nchannel);
+                }
                 carve.take(s->norm, kMaxCh);
                 carve.take(s->tickets, (size_t)s->ntr_local + 1);
                 carve.take(s->part_tv, ntiles * 2);
@@ -839,7 +859,10 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
         if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
         if(s->grad_done || s->interior_done) { return fail(J2P_ESTATE, "options change between iterations only"); }
         switch(option) {
-        case J2P_OPT_NORM_FOLD: s->fold = value != 0; break;
+        case J2P_OPT_NORM_FOLD:
+                if(s->rowsum_alternate && !value) { return fail(J2P_ESTATE, "alternating row sums need the folded norm reduction"); }
+                s->fold = value != 0;
+                break;
         case J2P_OPT_JOINT_INWAVE: s->joint_inwave = value != 0; break;
         default: return fail(J2P_EINVAL, "unknown option %d", option);
         }
@@ -1060,6 +1083,17 @@ int j2p_solver_halo_rows(j2p_solver *s, int buffer, j2p_exchange *info)
                 info->send_bottom[c] = base + (size_t)s->rows * s->W;
                 info->recv_bottom[c] = base + (size_t)(s->rows + kHalo) * s->W;
         }
+        return J2P_OK;
+}
+
+int j2p_solver_alternate_rowsums(j2p_solver *s, const double *buffers[2])
+{
+        if(!s || !buffers) { return fail(J2P_EINVAL, "NULL argument"); }
+        if(s->whole || !s->rowsum_odd) { return fail(J2P_ESTATE, "alternating row sums are for band solvers"); }
+        if(!s->fold) { return fail(J2P_ESTATE, "alternating row sums need the folded norm reduction"); }
+        s->rowsum_alternate = true;
+        buffers[0] = s->rowsum_local;
+        buffers[1] = s->rowsum_odd;
         return J2P_OK;
 }
 

@@ -43,7 +43,7 @@ struct Band {
         hipEvent_t ev_edge[2] = {nullptr, nullptr};    // behind the projection of the band's first/last block rows
         std::atomic<uint64_t> grad_recorded{0}, edge_recorded{0};   // iterations whose event has been recorded
         j2p_exchange rows[2];                  // halo / edge row addresses of x buffer 0 and 1
-        const double *rowsum = nullptr;
+        const double *rowsum[2] = {nullptr, nullptr};   // level-1 sums of even / odd iterations
         unsigned first_tr = 0, ntr = 0;
         double *log_dev = nullptr;             // the band's {tv, tv2, prob[3]} of the iteration just finished
         double *log_host = nullptr;            // pinned: [chunk][kLogCols]
@@ -120,10 +120,13 @@ int band_iterations(j2p_tiled *t, unsigned b, unsigned n, bool log)
 {
         Band *me = t->bands[b];
         BAND_HIP(hipSetDevice(me->device));
-        const double *rowsums[32];
+        // a band may run ahead of the others by up to one gradient phase, so the row sums alternate between two
+        // buffers: iteration it + 2 overwrites those of iteration it only after every band's norm(it) has run
+        const double *rowsums[2][32];
         unsigned first[32], count[32];
         for(unsigned p = 0; p < t->nband; p++) {
-                rowsums[p] = t->bands[p]->rowsum;
+                rowsums[0][p] = t->bands[p]->rowsum[0];
+                rowsums[1][p] = t->bands[p]->rowsum[1];
                 first[p] = t->bands[p]->first_tr;
                 count[p] = t->bands[p]->ntr;
         }
@@ -145,7 +148,7 @@ int band_iterations(j2p_tiled *t, unsigned b, unsigned n, bool log)
                 for(unsigned p = 0; p < t->nband; p++) {
                         if(p != b) { BAND_TRY(wait_for(t, me, t->bands[p], false, it)); }
                 }
-                BAND_TRY(j2p_solver_norm_from_bands(me->solver, t->nband, rowsums, first, count));
+                BAND_TRY(j2p_solver_norm_from_bands(me->solver, t->nband, rowsums[it & 1], first, count));
                 // ---- phase B, edge block rows first ----
                 if(me->split) {
                         BAND_TRY(j2p_solver_phase_project_part(me->solver, J2P_PROJECT_BOUNDARY));
@@ -287,7 +290,11 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                 bd->stream = (hipStream_t)st;
                 j2p_exchange e;
                 j2p_solver_exchange_info(bd->solver, &e);
-                bd->rowsum = e.partials_local;
+                bd->rowsum[0] = bd->rowsum[1] = e.partials_local;
+                if(nband > 1) {
+                        rc = j2p_solver_alternate_rowsums(bd->solver, bd->rowsum);
+                        if(rc != J2P_OK) { break; }
+                }
                 bd->first_tr = e.first_tile_row;
                 bd->ntr = e.local_tile_rows;
                 j2p_solver_halo_rows(bd->solver, 0, &bd->rows[0]);
