@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--bands", type=int, default=0, help="--force-tiled on one GPU: number of bands on device 0")
     ap.add_argument("--tiled-impl", choices=["c", "rccl"], default="c")
     ap.add_argument("--norm-fold", type=int, default=0, help="0: the round-1 stand-alone norm kernels (A/B)")
+    ap.add_argument("--proj-reverse", type=int, default=-1, help="A/B: projection phase bottom-up (1) or top-down (0)")
     return ap.parse_args()
 
 
@@ -277,6 +278,8 @@ def main():
         planes = synth.make_planes(W, H, "444", 10, seed=seed, y_only=True)
         solver = j.Solver(planes, WEIGHT, [PWEIGHT], its, device=local_rank)   # fdata=None: decoded on device
         solver.debug_option(j.J2P_OPT_NORM_FOLD, a.norm_fold)
+        if a.proj_reverse >= 0:
+            solver.debug_option(j.J2P_OPT_PROJECT_REVERSE, a.proj_reverse)
         del planes
         reset, solve, sync = solver.reset, (lambda: solver.run(its)), solver.sync
         eng = solver

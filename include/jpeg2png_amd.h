@@ -99,6 +99,8 @@ void j2p_pool_trim(void);
                                      reduction kernels — same bits, and on a whole canvas the same speed */
 #define J2P_OPT_JOINT_INWAVE  2   /* 1: all channels of a joint image in one wavefront; 0 (default): one wavefront
                                      per channel.  Environment J2P_JOINT_INWAVE sets the default at create time */
+#define J2P_OPT_PROJECT_REVERSE 3 /* 1: the projection phase walks the canvas bottom-up (the gradient phase top-down), so
+                                     each phase starts on what the previous one left in the Infinity Cache */
 int j2p_solver_debug_option(j2p_solver *s, int option, int value);
 
 /* canvas geometry (compute.c:410-416) and band bookkeeping */

@@ -194,6 +194,10 @@ struct ProjArgs {
         // block rows of the band handled by this launch: by = by_offset + i * by_mul for i < nby
         // (all: 0,1,brows; first and last only: 0,brows-1,2; all but those: 1,1,brows-2)
         unsigned by_offset, by_mul, nby;
+        // 1: strips are handed to workgroups in descending order, so that this phase starts on the rows the
+        // gradient phase finished last (and the next gradient phase starts on the rows this one finished last):
+        // what the previous launch touched last is what the 256 MiB Infinity Cache still holds
+        unsigned reverse;
 };
 
 // rows per norm partial on canvases large enough to fill the chip: the granularity of the GPU-count invariant
@@ -1333,8 +1337,9 @@ __global__ __launch_bounds__(256) void k_project(ProjArgs a)
         const unsigned ws = k.ws, hs = k.hs;
         const unsigned strips_x = (W + 64 * ws - 1) / (64 * ws);      // strips across the canvas
         const unsigned brows = (a.geo.rows + 8 * hs - 1) / (8 * hs);  // block rows in the band
-        const unsigned lstrip = blockIdx.x * 4 + wave;                // index within this launch
+        unsigned lstrip = blockIdx.x * 4 + wave;                      // index within this launch
         if(lstrip >= strips_x * a.nby) { return; }
+        if(a.reverse) { lstrip = strips_x * a.nby - 1 - lstrip; }
         const unsigned by = a.by_offset + (lstrip / strips_x) * a.by_mul, sx = lstrip % strips_x;
         const unsigned strip = by * strips_x + sx;                    // index within the band
         (void)brows;

@@ -94,6 +94,7 @@ struct j2p_solver {
         // reductions
         bool fold = false;       // norm reduction folded into k_gradient (J2P_OPT_NORM_FOLD); default: band solvers only
         bool joint_inwave = false;   // J2P_OPT_JOINT_INWAVE
+        bool proj_reverse = false;   // J2P_OPT_PROJECT_REVERSE
         bool norm_ready = false; // the gradient launch of this iteration also produced norm[]
         unsigned *tickets = nullptr;     // device: [ntr_local] per-tile-row arrival counters + [1] finished-rows counter
         unsigned rpw = 16;
@@ -473,6 +474,7 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
         a.norm = s->norm;
         a.part_prob = s->part_prob;
         a.strips_per_chan = s->strips_stride;
+        a.reverse = s->proj_reverse ? 1u : 0u;
         if(part != 1) { mark(s); }
         // one launch per sampling class present (usually: luma 1x1, both chroma 2x2)
         bool done[kMaxCh] = {false, false, false};
@@ -864,6 +866,7 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
                 s->fold = value != 0;
                 break;
         case J2P_OPT_JOINT_INWAVE: s->joint_inwave = value != 0; break;
+        case J2P_OPT_PROJECT_REVERSE: s->proj_reverse = value != 0; break;
         default: return fail(J2P_EINVAL, "unknown option %d", option);
         }
         return J2P_OK;
