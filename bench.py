@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--bands", type=int, default=0, help="--force-tiled on one GPU: number of bands on device 0")
     ap.add_argument("--tiled-impl", choices=["c", "rccl"], default="c")
     ap.add_argument("--norm-fold", type=int, default=0, help="0: the round-1 stand-alone norm kernels (A/B)")
+    ap.add_argument("--norm-in-project", type=int, default=-1, help="A/B: final norm tree inside k_project (needs --norm-fold 1)")
     ap.add_argument("--proj-reverse", type=int, default=-1, help="A/B: projection phase bottom-up (1) or top-down (0)")
     return ap.parse_args()
 
@@ -280,6 +281,8 @@ def main():
         solver.debug_option(j.J2P_OPT_NORM_FOLD, a.norm_fold)
         if a.proj_reverse >= 0:
             solver.debug_option(j.J2P_OPT_PROJECT_REVERSE, a.proj_reverse)
+        if a.norm_in_project >= 0:
+            solver.debug_option(j.J2P_OPT_NORM_IN_PROJECT, a.norm_in_project)
         del planes
         reset, solve, sync = solver.reset, (lambda: solver.run(its)), solver.sync
         eng = solver
@@ -304,18 +307,25 @@ def main():
         if dist is not None:
             dist.barrier()
         eng = None
+        c_ok = [True, ""]
         if rank == 0:
-            data = np.concatenate([np.load(f"{tag}_{b}.npy") for b in range(nband)])
-            plane = synth.Plane(W, H, 1, 1, data, qt)
-            devices = list(range(n_gpus)) if n_gpus > 1 else [local_rank] * nband
-            tsolver = j.TiledSolver([plane], WEIGHT, [PWEIGHT], its, devices=devices)
-            del data, plane
-            eng = tsolver.band_solver(0)
-            reset, solve, sync = tsolver.reset, (lambda: tsolver.run(its)), tsolver.sync
+            try:
+                data = np.concatenate([np.load(f"{tag}_{b}.npy") for b in range(nband)])
+                plane = synth.Plane(W, H, 1, 1, data, qt)
+                devices = list(range(n_gpus)) if n_gpus > 1 else [local_rank] * nband
+                tsolver = j.TiledSolver([plane], WEIGHT, [PWEIGHT], its, devices=devices)
+                del data, plane
+                eng = tsolver.band_solver(0)
+                reset, solve, sync = tsolver.reset, (lambda: tsolver.run(its)), tsolver.sync
+            except Exception as e:      # noqa: BLE001  (no peer access between the GPUs, a device this process cannot open ...)
+                if dist is None:
+                    raise
+                c_ok = [False, f"{type(e).__name__}: {e}"]
         else:
             reset = solve = sync = (lambda: None)
         if dist is not None:
-            dist.barrier()
+            # every rank has to agree on the engine: without peer access fall back to one process per GPU over RCCL
+            dist.broadcast_object_list(c_ok, src=0)
         for b in mine:
             try:
                 os.unlink(f"{tag}_{b}.npy")
@@ -323,7 +333,13 @@ def main():
                 pass
         parallelism = (f"row-tiled x{nband}: C engine (j2p_tiled), one process drives all GPUs, one host thread per band; "
                        "edge rows and norm row sums read over peer access, ordered by HIP events")
-    else:
+    fallback_note = ""
+    if c_tiled and not c_ok[0]:
+        c_tiled = False
+        fallback_note = f"; C engine unavailable ({c_ok[1]})"
+        if rank == 0:
+            print(f"bench: C row tiling unavailable, using the RCCL harness: {c_ok[1]}", file=sys.stderr, flush=True)
+    if tiled_mode and not c_tiled:
         from jpeg2png_amd import tiled
         if dist is None:
             import torch.distributed as dist
@@ -353,7 +369,8 @@ def main():
         eng = engine.solver
         reset()
         parallelism = (f"row-tiled x{n_gpus}, one process per GPU, RCCL halo send/recv + norm all-gather "
-                       f"({'librccl called on the solver streams' if driver.direct is not None else 'through torch.distributed'})")
+                       f"({'librccl called on the solver streams' if driver.direct is not None else 'through torch.distributed'})"
+                       + fallback_note)
 
     def barrier():
         if dist is not None and dist.is_initialized():

@@ -82,7 +82,7 @@ C_ABI_SYMBOLS = [
     "j2p_batch_create", "j2p_batch_destroy", "j2p_batch_submit", "j2p_batch_wait",
     "compute", "j2p_compute", "j2p_compute_tiled",
 ]
-J2P_OPT_NORM_FOLD, J2P_OPT_JOINT_INWAVE, J2P_OPT_PROJECT_REVERSE = 1, 2, 3
+J2P_OPT_NORM_FOLD, J2P_OPT_JOINT_INWAVE, J2P_OPT_PROJECT_REVERSE, J2P_OPT_NORM_IN_PROJECT, J2P_OPT_NT_GRADIENT, J2P_OPT_MIXED_PROJECT = 1, 2, 3, 4, 5, 6
 
 _lib = None
 

@@ -191,13 +191,18 @@ struct ProjArgs {
         double *part_prob;  // [c][strip]  (LOG only)
         unsigned strips_per_chan;   // stride of part_prob
         unsigned chan_of_z[kMaxCh]; // channel handled by blockIdx.z (channels are launched grouped by sampling)
-        // block rows of the band handled by this launch: by = by_offset + i * by_mul for i < nby
+        // block rows of the band handled by this launch, per blockIdx.z (they depend on the channel's vertical
+        // sampling): by = by_offset + i * by_mul for i < nby
         // (all: 0,1,brows; first and last only: 0,brows-1,2; all but those: 1,1,brows-2)
-        unsigned by_offset, by_mul, nby;
+        unsigned by_offset[kMaxCh], by_mul[kMaxCh], nby[kMaxCh];
         // 1: strips are handed to workgroups in descending order, so that this phase starts on the rows the
         // gradient phase finished last (and the next gradient phase starts on the rows this one finished last):
         // what the previous launch touched last is what the 256 MiB Infinity Cache still holds
         unsigned reverse;
+        // non-NULL: the norm is not read from `norm` but reduced by every wavefront itself from the level-1 row sums
+        // [tile row][channel] the gradient launch left behind (norm_tree_wave) — no reduction kernel between the phases
+        const double *norm_rowsums;
+        unsigned norm_rows, norm_nch;
 };
 
 // rows per norm partial on canvases large enough to fill the chip: the granularity of the GPU-count invariant
@@ -660,7 +665,11 @@ constexpr int kGradWaves3 = 2;    // ... the three-channels-in-one-wavefront sch
 // NCH channels are handled inside one wavefront (J == 1, workgroup = 4 strips), or — for a
 // jointly optimised image — J wavefronts of a workgroup take one channel each of the same strip
 // and only exchange their norm contributions through LDS (J > 1, NCH == 1).
-template <int NCH, bool TGV, bool LOG, int J = 1>
+// NTG: g is written with non-temporal stores (and read that way by k_project<.., NTG>): written once, read once,
+// it then stays out of the way of the data that IS re-used between the phases (x_k, x_{k-1}, prob state, d).  Pays
+// when the solver's working set exceeds the 256 MiB Infinity Cache only because of g (4096^2 Y: 288 MiB with g,
+// 224 MiB without: 137 -> 127 us per iteration); costs 1-5 % when everything fits anyway (see nt_policy).
+template <int NCH, bool TGV, bool LOG, int J = 1, bool NTG = false>
 __global__ __launch_bounds__((J == 1 ? 256 : 64 * J), (NCH == 1 ? kGradWaves1 : NCH == 2 ? 3 : kGradWaves3))
 void k_gradient(GradArgs a)
 {
@@ -901,7 +910,9 @@ void k_gradient(GradArgs a)
                                                 g += s.B[c];             // (x,   t+1)
                                         }
                                         if(pair_own) {
-                                                *reinterpret_cast<v2f *>(reinterpret_cast<char *>(k.grad + (size_t)t * W) + (unsigned)xl * 4u) = g;
+                                                v2f *gdst = reinterpret_cast<v2f *>(reinterpret_cast<char *>(k.grad + (size_t)t * W) + (unsigned)xl * 4u);
+                                                if constexpr(NTG) { __builtin_nontemporal_store(g, gdst); }
+                                                else { *gdst = g; }
                                                 const v2f sq = g * g;
                                                 g2[c] += (double)sq.x;   // compute.c:203
                                                 g2[c] += (double)sq.y;
@@ -1101,6 +1112,35 @@ __global__ __launch_bounds__(256) void k_norm_whole(const double *part, unsigned
         const double s = tree_sum_lds(buf, nrows, P);
         if(threadIdx.x == 0) { norm[c] = sqrtf((float)s); }
         (void)nch;
+}
+
+// Level 2 evaluated by ONE wavefront without LDS or barriers: the same padded pairwise tree (buf[i] + buf[i + s] for
+// s = P/2 ... 1, P = the power of two >= n) — lane l holds elements l, l + 64, l + 128, ...; the levels with s >= 64
+// add registers of one lane, the levels below move partner values between lanes.  Identical additions, hence the
+// identical double, as tree_sum_lds.  n <= 1024.  (Padding P up to 64 only adds exact zeros to sums that are >= 0.)
+constexpr unsigned kWaveTreeMax = 1024;
+__device__ __forceinline__ float norm_tree_wave(const double *rowsum, unsigned n, unsigned nch, unsigned c, int lane)
+{
+        unsigned P = 64;
+        while(P < n) { P <<= 1; }
+        double v[kWaveTreeMax / 64];
+#pragma unroll
+        for(unsigned j = 0; j < kWaveTreeMax / 64; j++) {
+                const unsigned i = (unsigned)lane + 64 * j;
+                v[j] = (j * 64 < P && i < n) ? rowsum[(size_t)i * nch + c] : 0.;
+        }
+#pragma unroll
+        for(unsigned half = kWaveTreeMax / 128; half >= 1; half >>= 1) {      // s = 64 * half
+                if(64 * half < P) {
+#pragma unroll
+                        for(unsigned j = 0; j < half; j++) { v[j] = v[j] + v[j + half]; }
+                }
+        }
+        double m = v[0];
+#pragma unroll
+        for(int off = 32; off > 0; off >>= 1) { m = m + __shfl_down(m, off, 64); }
+        m = __shfl(m, 0, 64);
+        return sqrtf((float)m);                                               // compute.c:206
 }
 
 // ---------------------------------------------------------------------------
@@ -1308,17 +1348,24 @@ __device__ __forceinline__ void sub_store_residual(const ChanDev &k, size_t base
 // WS, HS: the subsampling this instantiation has a register-resident fast path for
 // (1,1 = full-resolution channel; 0,0 = any other sampling, generic path only).  Strips that
 // stick out of the canvas or of the channel's coverage always take the generic path.
-template <bool LOG, int WS, int HS>
-__global__ __launch_bounds__(256) void k_project(ProjArgs a)
-{
-        __shared__ __attribute__((aligned(16))) float tp[4 * kTpWave];
-        __shared__ __attribute__((aligned(16))) float qs[64];    // q
-        __shared__ __attribute__((aligned(16))) float qq[64];    // q*q
-        __shared__ __attribute__((aligned(16))) float rqq[64];   // refined 1/(q*q)
-        __shared__ __attribute__((aligned(16))) float rq[64];    // refined 1/q   (log only)
-        __shared__ int q_fast;
+struct __attribute__((aligned(16))) ProjShared {
+        float tp[4 * kTpWave];
+        float qs[64];    // q
+        float qq[64];    // q*q
+        float rqq[64];   // refined 1/(q*q)
+        float rq[64];    // refined 1/q   (log only)
+        int q_fast;
+};
 
-        const int c = (int)a.chan_of_z[blockIdx.z];
+template <bool LOG, int WS, int HS, bool NTG>
+__device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
+{
+        float *const tp = sh.tp;
+        float *const qs = sh.qs, *const qq = sh.qq, *const rqq = sh.rqq, *const rq = sh.rq;
+        int &q_fast = sh.q_fast;
+
+        const unsigned zi = blockIdx.z;
+        const int c = (int)a.chan_of_z[zi];
         const ChanDev &k = a.ch[c];
         const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
         if(threadIdx.x < 64) {
@@ -1338,14 +1385,14 @@ __global__ __launch_bounds__(256) void k_project(ProjArgs a)
         const unsigned strips_x = (W + 64 * ws - 1) / (64 * ws);      // strips across the canvas
         const unsigned brows = (a.geo.rows + 8 * hs - 1) / (8 * hs);  // block rows in the band
         unsigned lstrip = blockIdx.x * 4 + wave;                      // index within this launch
-        if(lstrip >= strips_x * a.nby) { return; }
-        if(a.reverse) { lstrip = strips_x * a.nby - 1 - lstrip; }
-        const unsigned by = a.by_offset + (lstrip / strips_x) * a.by_mul, sx = lstrip % strips_x;
+        if(lstrip >= strips_x * a.nby[zi]) { return; }
+        if(a.reverse) { lstrip = strips_x * a.nby[zi] - 1 - lstrip; }
+        const unsigned by = a.by_offset[zi] + (lstrip / strips_x) * a.by_mul[zi], sx = lstrip % strips_x;
         const unsigned strip = by * strips_x + sx;                    // index within the band
         (void)brows;
         float *scratch = tp + wave * kTpWave;
 
-        const float norm = a.norm[c];
+        const float norm = a.norm_rowsums ? norm_tree_wave(a.norm_rowsums, a.norm_rows, a.norm_nch, (unsigned)c, lane) : a.norm[c];
         const unsigned cx = sx * 64 + lane;                           // coefficient column of this lane
         const unsigned cy0 = (a.geo.row0 / hs) + by * 8;              // first coefficient row (global)
         const bool covered = cx < k.cw && cy0 < k.ch;                 // block-granular: cw, ch multiples of 8
@@ -1378,7 +1425,8 @@ __global__ __launch_bounds__(256) void k_project(ProjArgs a)
                 const size_t base = (size_t)ly0 * W + cx;
 #pragma unroll
                 for(int r = 0; r < 8; r++) {
-                        gv[r] = k.grad[base + (size_t)r * W];
+                        if constexpr(NTG) { gv[r] = __builtin_nontemporal_load(&k.grad[base + (size_t)r * W]); }
+                        else { gv[r] = k.grad[base + (size_t)r * W]; }
                         xcv[r] = k.xcur[base + (size_t)r * W];
                         xpv[r] = k.xprev[base + (size_t)r * W];
                 }
@@ -1574,6 +1622,27 @@ __global__ __launch_bounds__(256) void k_project(ProjArgs a)
                         if(lane == 0) { a.part_prob[(size_t)c * a.strips_per_chan + strip] = dist; }
                 }
         }
+}
+
+template <bool LOG, int WS, int HS, bool NTG = false>
+__global__ __launch_bounds__(256) void k_project(ProjArgs a)
+{
+        __shared__ ProjShared sh;
+        project_strip<LOG, WS, HS, NTG>(a, sh);
+}
+
+// Small canvases are bound by the number of dependent launches per iteration, not by bytes: there ALL channels
+// of an image go into one launch whatever their sampling (blockIdx.z = channel; 1x1 and 2x2 keep their
+// register-resident paths, everything else takes the generic one).  Not for large images: the kernel needs the
+// registers of its hungriest path for every wavefront.
+template <bool LOG>
+__global__ __launch_bounds__(256) void k_project_mixed(ProjArgs a)
+{
+        __shared__ ProjShared sh;
+        const ChanDev &k = a.ch[a.chan_of_z[blockIdx.z]];
+        if(k.ws == 1 && k.hs == 1) { project_strip<LOG, 1, 1, false>(a, sh); }
+        else if(k.ws == 2 && k.hs == 2) { project_strip<LOG, 2, 2, false>(a, sh); }
+        else { project_strip<LOG, 0, 0, false>(a, sh); }
 }
 
 // ---------------------------------------------------------------------------

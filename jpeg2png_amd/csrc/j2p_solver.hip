@@ -95,7 +95,11 @@ struct j2p_solver {
         bool fold = false;       // norm reduction folded into k_gradient (J2P_OPT_NORM_FOLD); default: band solvers only
         bool joint_inwave = false;   // J2P_OPT_JOINT_INWAVE
         bool proj_reverse = false;   // J2P_OPT_PROJECT_REVERSE
+        bool norm_in_project = false;   // J2P_OPT_NORM_IN_PROJECT (with fold): level 2 of the norm inside k_project
+        bool ntg = false;               // g through non-temporal stores / loads (nt_policy; J2P_OPT_NT_GRADIENT)
+        bool mixed_project = true;      // small canvases: all samplings in one projection launch (J2P_OPT_MIXED_PROJECT)
         bool norm_ready = false; // the gradient launch of this iteration also produced norm[]
+        bool norm_by_project = false;   // ... or left level-1 row sums that k_project reduces itself
         unsigned *tickets = nullptr;     // device: [ntr_local] per-tile-row arrival counters + [1] finished-rows counter
         unsigned rpw = 16;
         unsigned *seg_row = nullptr;     // device: [nseg + 1] segment start rows
@@ -226,6 +230,9 @@ struct Carver {
         }
 };
 
+constexpr size_t kNtWorkingSet = (size_t)240 << 20;      // see nt_policy in j2p_solver_create
+constexpr size_t kMixedProjectPixels = (size_t)1 << 20;  // canvases up to this size project all channels in one launch
+
 unsigned gcd_u(unsigned a, unsigned b) { return b ? gcd_u(b, a % b) : a; }
 unsigned lcm_u(unsigned a, unsigned b) { return a / gcd_u(a, b) * b; }
 
@@ -266,12 +273,20 @@ Geo geo_of(const j2p_solver *s)
 }
 
 template <int NCH, int J>
-void launch_gradient_n(const GradArgs &a, unsigned ntx, unsigned nseg, hipStream_t st, bool tgv, bool log)
+void launch_gradient_n(const GradArgs &a, unsigned ntx, unsigned nseg, hipStream_t st, bool tgv, bool log, bool ntg)
 {
         // J == 1: 4 strips per 256-thread workgroup; J > 1: one strip per workgroup of J wavefronts
         constexpr unsigned wpb = 4;     // strips per workgroup
         const dim3 grid = J == 1 ? dim3((ntx + wpb - 1) / wpb, nseg) : dim3(ntx, nseg);
         const dim3 block = J == 1 ? dim3(64 * wpb) : dim3(64 * J);
+        if constexpr(NCH == 1) {
+                // non-temporal g (see nt_policy): the one-channel-per-wavefront kernels without logging
+                if(ntg && !log) {
+                        if(tgv) { hipLaunchKernelGGL((k_gradient<NCH, true, false, J, true>), grid, block, 0, st, a); }
+                        else { hipLaunchKernelGGL((k_gradient<NCH, false, false, J, true>), grid, block, 0, st, a); }
+                        return;
+                }
+        }
         if(tgv) {
                 if(log) { hipLaunchKernelGGL((k_gradient<NCH, true, true, J>), grid, block, 0, st, a); }
                 else { hipLaunchKernelGGL((k_gradient<NCH, true, false, J>), grid, block, 0, st, a); }
@@ -370,7 +385,8 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         a.part_tv = s->part_tv;
         // the norm reduction rides on this launch: level 1 (row sums) always, level 2 (tree -> norm) when the
         // launch covers the whole canvas
-        const bool fold_norm = s->fold && s->whole && part == 0 && s->ntr_global <= kFoldMaxRows;
+        const bool nip = s->norm_in_project && s->fold && s->whole && part == 0 && s->ntr_global <= kWaveTreeMax;
+        const bool fold_norm = !nip && s->fold && s->whole && part == 0 && s->ntr_global <= kFoldMaxRows;
         a.row_ticket = s->fold ? s->tickets : nullptr;
         a.done_ticket = s->tickets + s->ntr_local;
         a.rowsum = (s->rowsum_alternate && (s->iter & 1)) ? s->rowsum_odd : s->rowsum_local;
@@ -386,14 +402,14 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         // selects the in-wavefront kernel (kept: it is the same arithmetic in another schedule, and tested).
         const bool inwave = s->joint_inwave;
         switch(s->nch) {
-        case 1: launch_gradient_n<1, 1>(a, s->ntx, nseg_launch, st, tgv, log); break;
+        case 1: launch_gradient_n<1, 1>(a, s->ntx, nseg_launch, st, tgv, log, s->ntg); break;
         case 2:
-                if(inwave) { launch_gradient_n<2, 1>(a, s->ntx, nseg_launch, st, tgv, log); }
-                else { launch_gradient_n<1, 2>(a, s->ntx, nseg_launch, st, tgv, log); }
+                if(inwave) { launch_gradient_n<2, 1>(a, s->ntx, nseg_launch, st, tgv, log, false); }
+                else { launch_gradient_n<1, 2>(a, s->ntx, nseg_launch, st, tgv, log, s->ntg); }
                 break;
         default:
-                if(inwave) { launch_gradient_n<3, 1>(a, s->ntx, nseg_launch, st, tgv, log); }
-                else { launch_gradient_n<1, 3>(a, s->ntx, nseg_launch, st, tgv, log); }
+                if(inwave) { launch_gradient_n<3, 1>(a, s->ntx, nseg_launch, st, tgv, log, false); }
+                else { launch_gradient_n<1, 3>(a, s->ntx, nseg_launch, st, tgv, log, s->ntg); }
                 break;
         }
         if(part != 2) { mark(s); }
@@ -404,6 +420,7 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         }
         s->interior_done = false;
         s->norm_ready = fold_norm;
+        s->norm_by_project = nip;
         if(part == 0 && !s->whole && !s->fold) {
                 launch_rowsums(s);
                 HIP_TRY(hipGetLastError());
@@ -446,8 +463,8 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
         if(part != 2 && s->proj_boundary_done) { return fail(J2P_ESTATE, "boundary part of phase_project issued twice"); }
         unsigned P = 1;
         while(P < s->ntr_global) { P <<= 1; }
-        if(part == 2 || s->norm_ready) {
-                // the norm is already there
+        if(part == 2 || s->norm_ready || s->norm_by_project) {
+                // the norm is already there, or every wavefront of k_project reduces the row sums itself
         } else if(s->fold) {
                 // level 1 came with the gradient launch (band solvers: the caller has gathered all bands' row sums)
                 hipLaunchKernelGGL(k_norm_finish, dim3(s->nch), dim3(256), P * sizeof(double), s->stream,
@@ -475,7 +492,35 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
         a.part_prob = s->part_prob;
         a.strips_per_chan = s->strips_stride;
         a.reverse = s->proj_reverse ? 1u : 0u;
+        a.norm_rowsums = s->norm_by_project ? s->rowsum_local : nullptr;
+        a.norm_rows = s->ntr_global;
+        a.norm_nch = s->nch;
         if(part != 1) { mark(s); }
+        const bool inwave_nt_off = s->nch > 1 && s->joint_inwave;      // those gradient kernels have no non-temporal form
+        auto block_rows = [&](unsigned hs, unsigned z) -> unsigned {
+                const unsigned brows = (s->rows + 8 * hs - 1) / (8 * hs);
+                if(part == 0) { a.by_offset[z] = 0; a.by_mul[z] = 1; a.nby[z] = brows; }
+                else if(part == 1) { a.by_offset[z] = 0; a.by_mul[z] = brows > 1 ? brows - 1 : 1; a.nby[z] = brows < 2 ? brows : 2; }
+                else { a.by_offset[z] = 1; a.by_mul[z] = 1; a.nby[z] = brows > 2 ? brows - 2 : 0; }
+                return a.nby[z];
+        };
+        bool mixed = false;
+        for(unsigned c = 1; c < s->nch; c++) { mixed = mixed || s->ch[c].ws != s->ch[0].ws || s->ch[c].hs != s->ch[0].hs; }
+        if(mixed && s->mixed_project && (size_t)s->W * s->rows <= kMixedProjectPixels) {
+                // small canvas, several samplings: one launch for all channels (k_project_mixed)
+                unsigned max_strips = 0;
+                for(unsigned c = 0; c < s->nch; c++) {
+                        a.chan_of_z[c] = c;
+                        const unsigned ws = s->ch[c].ws, hs = s->ch[c].hs;
+                        const unsigned strips = ((s->W + 64 * ws - 1) / (64 * ws)) * block_rows(hs, c);
+                        if(strips > max_strips) { max_strips = strips; }
+                }
+                if(max_strips) {
+                        const dim3 grid((max_strips + 3) / 4, 1, s->nch);
+                        if(log) { hipLaunchKernelGGL((k_project_mixed<true>), grid, dim3(256), 0, s->stream, a); }
+                        else { hipLaunchKernelGGL((k_project_mixed<false>), grid, dim3(256), 0, s->stream, a); }
+                }
+        } else {
         // one launch per sampling class present (usually: luma 1x1, both chroma 2x2)
         bool done[kMaxCh] = {false, false, false};
         for(unsigned c0 = 0; c0 < s->nch; c0++) {
@@ -484,28 +529,31 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
                 unsigned nz = 0;
                 for(unsigned c = c0; c < s->nch; c++) {
                         if(!done[c] && s->ch[c].ws == ws && s->ch[c].hs == hs) {
+                                block_rows(hs, nz);
                                 a.chan_of_z[nz++] = c;
                                 done[c] = true;
                         }
                 }
-                const unsigned brows = (s->rows + 8 * hs - 1) / (8 * hs);
-                if(part == 0) { a.by_offset = 0; a.by_mul = 1; a.nby = brows; }
-                else if(part == 1) { a.by_offset = 0; a.by_mul = brows > 1 ? brows - 1 : 1; a.nby = brows < 2 ? brows : 2; }
-                else { a.by_offset = 1; a.by_mul = 1; a.nby = brows > 2 ? brows - 2 : 0; }
-                if(a.nby == 0) { continue; }
-                const unsigned strips = ((s->W + 64 * ws - 1) / (64 * ws)) * a.nby;
+                if(a.nby[0] == 0) { continue; }
+                const unsigned strips = ((s->W + 64 * ws - 1) / (64 * ws)) * a.nby[0];
                 dim3 grid((strips + 3) / 4, 1, nz);
+        // (g is read non-temporally exactly when the gradient launch wrote it that way; only the 1x1 instantiation
+        // has the register-resident path that carries the hint)
 #define J2P_LAUNCH_PROJECT(WS_, HS_)                                                               \
         do {                                                                                       \
                 if(log) { hipLaunchKernelGGL((k_project<true, WS_, HS_>), grid, dim3(256), 0, s->stream, a); }  \
                 else { hipLaunchKernelGGL((k_project<false, WS_, HS_>), grid, dim3(256), 0, s->stream, a); }    \
         } while(0)
-                if(ws == 1 && hs == 1) { J2P_LAUNCH_PROJECT(1, 1); }
+                if(ws == 1 && hs == 1 && s->ntg && !inwave_nt_off && !log) {
+                        hipLaunchKernelGGL((k_project<false, 1, 1, true>), grid, dim3(256), 0, s->stream, a);
+                }
+                else if(ws == 1 && hs == 1) { J2P_LAUNCH_PROJECT(1, 1); }
                 else if(ws == 2 && hs == 2) { J2P_LAUNCH_PROJECT(2, 2); }
                 else if(ws == 2 && hs == 1) { J2P_LAUNCH_PROJECT(2, 1); }
                 else if(ws == 1 && hs == 2) { J2P_LAUNCH_PROJECT(1, 2); }
                 else { J2P_LAUNCH_PROJECT(0, 0); }
 #undef J2P_LAUNCH_PROJECT
+        }
         }
         if(part != 1) { mark(s); }
         HIP_TRY(hipGetLastError());
@@ -548,6 +596,7 @@ int launch_init(j2p_solver *s)
         s->interior_done = false;
         s->rowsums_pending = false;
         s->norm_ready = false;
+        s->norm_by_project = false;
         s->proj_boundary_done = false;
         s->bandlog_pending = false;
         for(unsigned c = 0; c < kMaxCh; c++) { s->carried_prob[c] = 0.; }
@@ -662,6 +711,9 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 // joint image inside one wavefront instead of one wavefront per channel — same bits, slower
                 const char *env = getenv("J2P_JOINT_INWAVE");
                 s->joint_inwave = env && atoi(env) != 0;
+                // ... and: one projection launch per sampling class also on small canvases (J2P_OPT_MIXED_PROJECT)
+                env = getenv("J2P_MIXED_PROJECT");
+                if(env) { s->mixed_project = atoi(env) != 0; }
         }
         int rc = J2P_OK;
 #define CREATE_TRY(expr)                                                                           \
@@ -782,6 +834,20 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 carve.take(s->part_prob, (size_t)max_strips * nchannel);
         }
 
+        // ---- nt_policy: is the gradient plane what keeps the iteration's working set from staying in the
+        // Infinity Cache?  x_k, x_{k-1}, g, prob state, d of every channel; measured on 4096-wide Y planes:
+        // 2048 rows (144 MiB) 78.0 us per iteration with plain accesses vs 79.4 non-temporal, 4096 rows (288 MiB)
+        // 137.1 vs 126.4-130.1, 8192 rows (576 MiB) 275.4 vs 276.0
+        {
+                size_t working_set = 0;
+                for(unsigned c = 0; c < nchannel; c++) {
+                        const ChanHost &h = s->ch[c];
+                        const size_t cells = (size_t)(h.crows ? h.crows : 1) * h.cw;
+                        working_set += (2 * plane_floats + (size_t)s->rows * W + cells) * sizeof(float) + cells * sizeof(int16_t);
+                }
+                s->ntg = working_set > kNtWorkingSet;
+        }
+
         // ---- uploads (host arrays: whole-image unless band_local) ----
         float qf[64 * kMaxCh];
         for(unsigned c = 0; c < nchannel; c++) {
@@ -867,6 +933,9 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
                 break;
         case J2P_OPT_JOINT_INWAVE: s->joint_inwave = value != 0; break;
         case J2P_OPT_PROJECT_REVERSE: s->proj_reverse = value != 0; break;
+        case J2P_OPT_NORM_IN_PROJECT: s->norm_in_project = value != 0; break;
+        case J2P_OPT_NT_GRADIENT: s->ntg = value != 0; break;
+        case J2P_OPT_MIXED_PROJECT: s->mixed_project = value != 0; break;
         default: return fail(J2P_EINVAL, "unknown option %d", option);
         }
         return J2P_OK;

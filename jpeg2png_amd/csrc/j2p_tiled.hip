@@ -273,6 +273,25 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
         int prev = -1;
         (void)hipGetDevice(&prev);
         int rc = J2P_OK;
+        // every band reads every other band's row sums and its neighbours' edge rows in place: peer access first,
+        // so that every allocation the band solvers make below is mapped for the peers from the start
+        for(unsigned a = 0; a < nband && rc == J2P_OK; a++) {
+                for(unsigned b = 0; b < nband && rc == J2P_OK; b++) {
+                        const int da = devices[a], db = devices[b];
+                        if(da == db) { continue; }
+                        int can = 0;
+                        if(hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can) {
+                                rc = j2p_fail(J2P_EDEVICE, "device %d cannot access device %d's memory (no peer access)", da, db);
+                                break;
+                        }
+                        if(hipSetDevice(da) != hipSuccess) { rc = j2p_fail(J2P_EDEVICE, "hipSetDevice(%d) failed", da); break; }
+                        const hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+                        if(e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                                rc = j2p_fail(J2P_EDEVICE, "hipDeviceEnablePeerAccess(%d -> %d): %s", da, db, hipGetErrorString(e));
+                        }
+                        (void)hipGetLastError();
+                }
+        }
         for(unsigned b = 0; b < nband && rc == J2P_OK; b++) {
                 Band *bd = new(std::nothrow) Band();
                 if(!bd) { rc = j2p_fail(J2P_ENOMEM, "host allocation failed"); break; }
@@ -306,24 +325,6 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                            hipEventCreateWithFlags(&bd->ev_edge[k], hipEventDisableTiming) != hipSuccess) {
                                 rc = j2p_fail(J2P_EDEVICE, "hipEventCreate failed");
                         }
-                }
-        }
-        // every band reads every other band's row sums and its neighbours' edge rows in place
-        for(unsigned a = 0; a < t->bands.size() && rc == J2P_OK; a++) {
-                for(unsigned b = 0; b < t->bands.size() && rc == J2P_OK; b++) {
-                        const int da = t->bands[a]->device, db = t->bands[b]->device;
-                        if(da == db) { continue; }
-                        int can = 0;
-                        if(hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can) {
-                                rc = j2p_fail(J2P_EDEVICE, "device %d cannot access device %d's memory (no peer access)", da, db);
-                                break;
-                        }
-                        (void)hipSetDevice(da);
-                        const hipError_t e = hipDeviceEnablePeerAccess(db, 0);
-                        if(e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
-                                rc = j2p_fail(J2P_EDEVICE, "hipDeviceEnablePeerAccess(%d -> %d): %s", da, db, hipGetErrorString(e));
-                        }
-                        (void)hipGetLastError();
                 }
         }
         if(prev >= 0) { (void)hipSetDevice(prev); }

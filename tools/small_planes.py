@@ -19,9 +19,11 @@ else:
     planes = synth.make_planes(1920, 1080, "444", 10, seed=1236)
     solvers = [j.Solver([p], 0.3 if c == 0 else 0.0, [0.001], 100) for c, p in enumerate(planes)]
     its, px = 100, 1920 * 1080 * 3
+nip = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 for fold in ((1, 0) if len(sys.argv) <= 3 else (int(sys.argv[3]),)):
     for s in solvers:
         s.debug_option(j.J2P_OPT_NORM_FOLD, fold)
+        s.debug_option(j.J2P_OPT_NORM_IN_PROJECT, nip if fold else 0)
     t0 = None
     for r in range(reps + 1):
         if r == 1:
@@ -34,4 +36,4 @@ for fold in ((1, 0) if len(sys.argv) <= 3 else (int(sys.argv[3]),)):
         for s in solvers:
             s.sync()
     dt = (time.perf_counter() - t0) / reps
-    print(f"config {which} fold {fold}: {dt * 1e3:.3f} ms per solve, {dt / its * 1e6:.1f} us per iteration, {px * its / dt / 1e9:.1f} Gpx-it/s", flush=True)
+    print(f"config {which} fold {fold} nip {nip if fold else 0}: {dt * 1e3:.3f} ms per solve, {dt / its * 1e6:.1f} us per iteration, {px * its / dt / 1e9:.1f} Gpx-it/s", flush=True)

@@ -77,6 +77,8 @@ for cs in cases(seed, n):
             for info in infos:                     # the bands' tv / tv2 / prob sums of this iteration
                 part = np.zeros(5)
                 hip.hipMemcpy(part.ctypes.data, info.log_local, 40, 2)
+                if not np.all(np.isfinite(part)):
+                    print(f"      non-finite band log sums at iteration {it}, band {infos.index(info)}: {part}")
                 sums[it] += part
             nbytes = infos[0].halo_floats * 4
             for i in range(nb - 1):
