@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--force-tiled", action="store_true", help="run the row-tiled path even with one rank (debug)")
     ap.add_argument("--bands", type=int, default=0, help="--force-tiled on one GPU: number of bands on device 0")
     ap.add_argument("--tiled-impl", choices=["c", "rccl"], default="c")
-    ap.add_argument("--norm-fold", type=int, default=0, help="0: the round-1 stand-alone norm kernels (A/B)")
+    ap.add_argument("--norm-fold", type=int, default=-1, help="A/B: 1 = norm reduction inside k_gradient, 0 = stand-alone kernels; default: the library's choice")
     ap.add_argument("--norm-in-project", type=int, default=-1, help="A/B: final norm tree inside k_project (needs --norm-fold 1)")
     ap.add_argument("--proj-reverse", type=int, default=-1, help="A/B: projection phase bottom-up (1) or top-down (0)")
     return ap.parse_args()
@@ -278,7 +278,8 @@ def main():
         workload = f"{W}x{H} Y-only Q10 -i {its} (BASELINE configs[2])"
         planes = synth.make_planes(W, H, "444", 10, seed=seed, y_only=True)
         solver = j.Solver(planes, WEIGHT, [PWEIGHT], its, device=local_rank)   # fdata=None: decoded on device
-        solver.debug_option(j.J2P_OPT_NORM_FOLD, a.norm_fold)
+        if a.norm_fold >= 0:
+            solver.debug_option(j.J2P_OPT_NORM_FOLD, a.norm_fold)
         if a.proj_reverse >= 0:
             solver.debug_option(j.J2P_OPT_PROJECT_REVERSE, a.proj_reverse)
         if a.norm_in_project >= 0:
@@ -442,7 +443,7 @@ def main():
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "iterations_per_step": its, "weight": WEIGHT, "pweight": PWEIGHT,
-                       "parallelism": parallelism, "norm_fold": bool(a.norm_fold)},
+                       "parallelism": parallelism},
             "roofline": {"bound": "hbm", "scope": "whole iteration (k_gradient + k_project, launch gaps included), wall clock, per GPU",
                          "kernel": kern, "achieved": round(it_gbs, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(it_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,

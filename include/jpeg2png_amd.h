@@ -109,6 +109,15 @@ void j2p_pool_trim(void);
                                      sampling; 0: one launch per sampling class, as large canvases do */
 int j2p_solver_debug_option(j2p_solver *s, int option, int value);
 
+/* The checked build (the analogue of the reference's DEBUG=1, whose pixel indexer p() asserts every access,
+ * utils.h:68-81): compiled with -DJ2P_DEBUG, every global load and store of the two phase kernels is compared
+ * with the byte range it is meant to stay in; violations are counted on the device.  j2p_debug_build() tells
+ * which build this is; j2p_solver_debug_violations() returns the count, the code of the first offending site
+ * (1xx = gradient phase, 2xx = projection phase, see j2p_kernels.hip.h) and its offset; J2P_ESTATE in a release
+ * build, where the checks are compiled out. */
+int j2p_debug_build(void);
+int j2p_solver_debug_violations(j2p_solver *s, unsigned long long *count, unsigned *site, unsigned long long *offset);
+
 /* canvas geometry (compute.c:410-416) and band bookkeeping */
 int j2p_solver_canvas(const j2p_solver *s, unsigned *W, unsigned *H);
 int j2p_solver_band(const j2p_solver *s, unsigned *row_begin, unsigned *row_end);

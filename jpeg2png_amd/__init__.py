@@ -81,6 +81,7 @@ C_ABI_SYMBOLS = [
     "j2p_tiled_download",
     "j2p_batch_create", "j2p_batch_destroy", "j2p_batch_submit", "j2p_batch_wait",
     "compute", "j2p_compute", "j2p_compute_tiled",
+    "j2p_debug_build", "j2p_solver_debug_violations",
 ]
 J2P_OPT_NORM_FOLD, J2P_OPT_JOINT_INWAVE, J2P_OPT_PROJECT_REVERSE, J2P_OPT_NORM_IN_PROJECT, J2P_OPT_NT_GRADIENT, J2P_OPT_MIXED_PROJECT = 1, 2, 3, 4, 5, 6
 
@@ -168,6 +169,8 @@ def load_library():
     lib.j2p_math_selftest.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_uint,
                                       ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
     lib.j2p_solver_debug_option.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    lib.j2p_solver_debug_violations.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_uint),
+                                                ctypes.POINTER(ctypes.c_ulonglong)]
     lib.j2p_pool_trim.restype = None
     lib.j2p_tiled_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint, ctypes.POINTER(ctypes.c_int),
                                      ctypes.POINTER(ctypes.c_uint), ctypes.c_uint, ctypes.POINTER(_CPlane), ctypes.c_float,
@@ -194,6 +197,11 @@ def load_library():
 def _check(rc):
     if rc != 0:
         raise J2PError(f"jpeg2png_amd error {rc}: {load_library().j2p_last_error().decode()}")
+
+
+def debug_build():
+    """True when the loaded library was compiled with -DJ2P_DEBUG (address checks in the phase kernels)"""
+    return bool(load_library().j2p_debug_build())
 
 
 def device_count():
@@ -346,6 +354,12 @@ class Solver:
     def debug_option(self, option, value):
         """schedule switches (J2P_OPT_*): speed only, never results"""
         _check(self._lib.j2p_solver_debug_option(self._h, int(option), int(value)))
+
+    def debug_violations(self):
+        """J2P_DEBUG builds: (count, first site code, first offset) of the phase kernels' address checks"""
+        n, site, off = ctypes.c_ulonglong(), ctypes.c_uint(), ctypes.c_ulonglong()
+        _check(self._lib.j2p_solver_debug_violations(self._h, ctypes.byref(n), ctypes.byref(site), ctypes.byref(off)))
+        return n.value, site.value, off.value
 
     def enable_timing(self, every=1):
         """record HIP events around the two phase kernels of every `every`-th iteration (0 = off)."""

@@ -79,6 +79,28 @@ def build(force=False, verbose=False):
     return LIB
 
 
+DEBUG_LIB = os.path.join(HERE, "libjpeg2png_amd_debug.so")
+
+
+def build_debug(force=False, verbose=False):
+    """The checked build (-DJ2P_DEBUG): every global access of the two phase kernels is compared with the range
+    it is meant to stay in, the counterpart of the reference's DEBUG=1 build with its asserting pixel indexer
+    (utils.h:68-81).  Same sources; only the device translation unit is compiled a second time.  Loaded with
+    J2P_LIBRARY=<this file> (tests/test_debug_build_gpu.py, tools/debug_sweep.py)."""
+    build(force=False, verbose=verbose)             # the host-only objects are shared with the release build
+    src = os.path.join(CSRC, "j2p_solver.hip")
+    obj = os.path.join(CSRC, "j2p_solver_debug.o")
+    deps = [src] + [os.path.join(CSRC, f) for f in HEADERS] + [os.path.join(INCLUDE, "jpeg2png_amd.h"), os.path.abspath(__file__)]
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if force or _newer(obj, deps):
+        _run([hipcc, *HIP_FLAGS, "-DJ2P_DEBUG", "-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj], verbose)
+    objs = [obj] + [os.path.join(CSRC, u.replace(".hip", ".o")) for u in HIP_UNITS if u != "j2p_solver.hip"]
+    objs.append(os.path.join(CSRC, "compute_host.o"))
+    if force or _newer(DEBUG_LIB, objs):
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lpthread", "-Wl,-soname,libjpeg2png_amd_debug.so", "-o", DEBUG_LIB], verbose)
+    return DEBUG_LIB
+
+
 CLI = os.path.join(HERE, "jpeg2png_gpu")
 
 

@@ -34,6 +34,40 @@ constexpr int kMaxCh = 3;
 constexpr int kHalo = 2;
 
 // ---------------------------------------------------------------------------
+// -DJ2P_DEBUG: the analogue of the reference's DEBUG build, whose pixel indexer p() asserts every access
+// (utils.h:68-81).  Every global load and store of the two phase kernels is checked against the byte range the
+// access is MEANT to stay in — x: the band's own rows plus the halo rows that exist in the image (phase A) / the
+// own rows (phase B); g: the own rows; prob state and d: the coefficient rows the band holds.  A violation does
+// not trap (the kernels' loads are unconditional by design, so a trap would hide the count): it is counted, and
+// the first offender's site code and offset are kept; j2p_debug_violations() reads the counters.  The release
+// build compiles the checks out.
+// ---------------------------------------------------------------------------
+#ifdef J2P_DEBUG
+struct DbgRange {
+        const char *lo, *hi;
+};
+struct DbgChan {
+        DbgRange x_read[2];    // [0] = xcur, [1] = xprev: rows phase A may read
+        DbgRange x_own[2];     // ... rows phase B reads and writes
+        DbgRange grad, pg, d;
+        unsigned long long *counters;   // [0] violations, [1] first site code, [2] first offset (bytes from lo)
+};
+__device__ __forceinline__ void dbg_check(const DbgChan &g, const DbgRange &r, const void *p, unsigned bytes, unsigned site)
+{
+        const char *c = static_cast<const char *>(p);
+        if(c < r.lo || c + bytes > r.hi) {
+                if(atomicAdd(g.counters, 1ull) == 0ull) {
+                        g.counters[1] = site;
+                        g.counters[2] = (unsigned long long)(c - r.lo);
+                }
+        }
+}
+#define J2P_CHK(k, range, ptr, bytes, site) dbg_check((k).dbg, (k).dbg.range, (ptr), (bytes), (site))
+#else
+#define J2P_CHK(k, range, ptr, bytes, site) ((void)0)
+#endif
+
+// ---------------------------------------------------------------------------
 // 8-point orthonormal DCT-II / DCT-III, one lane owns the whole 8-vector.
 // ---------------------------------------------------------------------------
 // sqrt(2/8)*cos(k*pi/16), sqrt(2/8)*sin(k*pi/16), and cos(pi/4) — the values of
@@ -151,6 +185,9 @@ struct ChanDev {
         unsigned crows;     // coefficient rows held (pg always has at least one row allocated)
         float p_alpha;      // pweight*2*255*sqrtf(2)  (compute.c:245)
         int prob_on;        // pweight != 0
+#ifdef J2P_DEBUG
+        DbgChan dbg;
+#endif
 };
 
 struct Geo {
@@ -731,6 +768,8 @@ void k_gradient(GradArgs a)
                 const ptrdiff_t roff = (ptrdiff_t)lc * W;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
+                        J2P_CHK(a.ch[cbase + c], x_read[0], reinterpret_cast<const char *>(a.ch[cbase + c].xcur + roff) + xoff, 8, 101);
+                        J2P_CHK(a.ch[cbase + c], x_read[1], reinterpret_cast<const char *>(a.ch[cbase + c].xprev + roff) + xoff, 8, 102);
                         rc[c] = *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(a.ch[cbase + c].xcur + roff) + xoff);
                         rp[c] = *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(a.ch[cbase + c].xprev + roff) + xoff);
                 }
@@ -796,6 +835,7 @@ void k_gradient(GradArgs a)
                         const int gt = row0 + (FREE ? ltc : (ltc < 0 ? 0 : ltc));
                         if constexpr(decltype(free_tag)::unit) {
                                 const float *prow = k.pg + (size_t)((unsigned)gt - k.crow0) * k.cw;
+                                J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + xoff, 8, 103);
                                 pv[c] = *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(prow) + xoff);
                                 continue;
                         }
@@ -807,6 +847,8 @@ void k_gradient(GradArgs a)
                                 cr = cr < k.crow0 ? k.crow0 : (cr > cr_hi ? cr_hi : cr);
                         }
                         const float *prow = k.pg + (size_t)(cr - k.crow0) * k.cw;
+                        J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][0], 4, 104);
+                        J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][1], 4, 105);
                         pv[c] = v2f{*reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][0]),
                                     *reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][1])};   // two dword loads whatever the sampling: no branch
                 }
@@ -911,6 +953,7 @@ void k_gradient(GradArgs a)
                                         }
                                         if(pair_own) {
                                                 v2f *gdst = reinterpret_cast<v2f *>(reinterpret_cast<char *>(k.grad + (size_t)t * W) + (unsigned)xl * 4u);
+                                                J2P_CHK(k, grad, gdst, 8, 106);
                                                 if constexpr(NTG) { __builtin_nontemporal_store(g, gdst); }
                                                 else { *gdst = g; }
                                                 const v2f sq = g * g;
@@ -1232,6 +1275,9 @@ __global__ __launch_bounds__(256) void k_log_sums(const double *part_tv, unsigne
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float stepped(const ChanDev &k, ptrdiff_t off, float factor, float step, float norm)
 {
+        J2P_CHK(k, x_own[0], k.xcur + off, 4, 201);
+        J2P_CHK(k, x_own[1], k.xprev + off, 4, 202);
+        J2P_CHK(k, grad, k.grad + off, 4, 203);
         const float xc = k.xcur[off], xp = k.xprev[off];
         const float y = xc + factor * (xc - xp);                 // compute.c:435
         if(norm != 0.f) { return y - step * (k.grad[off] / norm); }   // compute.c:213
@@ -1276,6 +1322,9 @@ __device__ __forceinline__ void sub_load_step_mean(const ChanDev &k, size_t base
 #pragma unroll
                 for(int i = 0; i < 4 * HS; i++) {
                         const size_t off = base + (size_t)(half * 4 * HS + i) * W;
+                        J2P_CHK(k, grad, k.grad + off, 4 * WS, 204);
+                        J2P_CHK(k, x_own[0], k.xcur + off, 4 * WS, 205);
+                        J2P_CHK(k, x_own[1], k.xprev + off, 4 * WS, 206);
                         gv[i] = *reinterpret_cast<const vws *>(k.grad + off);
                         xc[i] = *reinterpret_cast<const vws *>(k.xcur + off);
                         xp[i] = *reinterpret_cast<const vws *>(k.xprev + off);
@@ -1340,6 +1389,7 @@ __device__ __forceinline__ void sub_store_residual(const ChanDev &k, size_t base
                                 const float res = t.f[r * HS + sy][sx] - mean_old[r];     // compute.c:365
                                 o[sx] = res + mean_new[r];                                // compute.c:398
                         }
+                        J2P_CHK(k, x_own[1], k.xprev + base + (size_t)(r * HS + sy) * W, 4 * WS, 207);
                         *reinterpret_cast<vws *>(k.xprev + base + (size_t)(r * HS + sy) * W) = o;
                 }
         }
@@ -1425,6 +1475,9 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                 const size_t base = (size_t)ly0 * W + cx;
 #pragma unroll
                 for(int r = 0; r < 8; r++) {
+                        J2P_CHK(k, grad, &k.grad[base + (size_t)r * W], 4, 208);
+                        J2P_CHK(k, x_own[0], &k.xcur[base + (size_t)r * W], 4, 209);
+                        J2P_CHK(k, x_own[1], &k.xprev[base + (size_t)r * W], 4, 210);
                         if constexpr(NTG) { gv[r] = __builtin_nontemporal_load(&k.grad[base + (size_t)r * W]); }
                         else { gv[r] = k.grad[base + (size_t)r * W]; }
                         xcv[r] = k.xcur[base + (size_t)r * W];
@@ -1471,7 +1524,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                         if(inside && ly0 + r < a.geo.rows) {
                                 const ptrdiff_t off = (ptrdiff_t)(ly0 + r) * W + cx;
                                 v[r] = stepped(k, off, a.factor, a.step, norm);
-                                if(!covered) { k.xprev[off] = v[r]; }  // stepped but never projected (SURVEY §7 hard part 5)
+                                if(!covered) { k.xprev[off] = v[r]; }  // stepped but never projected (SURVEY §7 hard part 5); address checked by stepped()
                         }
                 }
         } else {
@@ -1513,6 +1566,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                 int4 raw = make_int4(0, 0, 0, 0);
                 if(bcov) {
                         const size_t blk = (size_t)(cy0 / 8 - k.crow0 / 8) * (k.cw / 8) + bx;
+                        J2P_CHK(k, d, k.d + blk * 64 + rr * 8, 16, 211);
                         raw = *reinterpret_cast<const int4 *>(k.d + blk * 64 + rr * 8);
                 }
                 const int rw[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -1575,6 +1629,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
         if(direct) {
                 if(bcov && ly0 + rr < a.geo.rows) {
                         float4 *dst = reinterpret_cast<float4 *>(k.xprev + (size_t)(ly0 + rr) * W + bx * 8);
+                        J2P_CHK(k, x_own[1], dst, 32, 212);
                         dst[0] = make_float4(v[0], v[1], v[2], v[3]);
                         dst[1] = make_float4(v[4], v[5], v[6], v[7]);
                 }
@@ -1587,7 +1642,10 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                         // full && resample1: residual (x - mean) + new mean, lane = column again
                         const size_t base = (size_t)ly0 * W + cx;
 #pragma unroll
-                        for(int r = 0; r < 8; r++) { k.xprev[base + (size_t)r * W] = (st1[r] - mean_old[r]) + v[r]; }
+                        for(int r = 0; r < 8; r++) {
+                                J2P_CHK(k, x_own[1], &k.xprev[base + (size_t)r * W], 4, 213);
+                                k.xprev[base + (size_t)r * W] = (st1[r] - mean_old[r]) + v[r];
+                        }
                 } else if(covered) {
 #pragma unroll 1
                         for(int r = 0; r < 8; r++) {
@@ -1612,6 +1670,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                 idct8(e);
                 if(bcov) {
                         float4 *dst = reinterpret_cast<float4 *>(k.pg + (size_t)(cy0 - k.crow0 + rr) * k.cw + bx * 8);
+                        J2P_CHK(k, pg, dst, 32, 214);
                         dst[0] = make_float4(e[0], e[1], e[2], e[3]);
                         dst[1] = make_float4(e[4], e[5], e[6], e[7]);
                 }

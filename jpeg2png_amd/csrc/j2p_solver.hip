@@ -65,6 +65,8 @@ struct ChanHost {
         int16_t *d = nullptr;
         float *q = nullptr;
         float *decoded = nullptr;            // frows * cw floats
+        float *scratch_f = nullptr;          // decode scratch of bands too short to lend their x buffers (create only)
+        int16_t *scratch_d = nullptr;
         float pweight = 0.f;
 };
 
@@ -98,6 +100,7 @@ struct j2p_solver {
         bool norm_in_project = false;   // J2P_OPT_NORM_IN_PROJECT (with fold): level 2 of the norm inside k_project
         bool ntg = false;               // g through non-temporal stores / loads (nt_policy; J2P_OPT_NT_GRADIENT)
         bool mixed_project = true;      // small canvases: all samplings in one projection launch (J2P_OPT_MIXED_PROJECT)
+        unsigned long long *dbg_counters = nullptr;   // J2P_DEBUG builds: [0] address violations, [1] first site, [2] first offset
         bool norm_ready = false; // the gradient launch of this iteration also produced norm[]
         bool norm_by_project = false;   // ... or left level-1 row sums that k_project reduces itself
         unsigned *tickets = nullptr;     // device: [ntr_local] per-tile-row arrival counters + [1] finished-rows counter
@@ -231,6 +234,7 @@ struct Carver {
 };
 
 constexpr size_t kNtWorkingSet = (size_t)240 << 20;      // see nt_policy in j2p_solver_create
+constexpr size_t kNormInProjectPixels = (size_t)4 << 20; // whole canvases up to this size reduce ||g|| without a launch of its own
 constexpr size_t kMixedProjectPixels = (size_t)1 << 20;  // canvases up to this size project all channels in one launch
 
 unsigned gcd_u(unsigned a, unsigned b) { return b ? gcd_u(b, a % b) : a; }
@@ -255,6 +259,25 @@ ChanDev chan_dev(const j2p_solver *s, unsigned c)
         k.crows = h.crows;
         k.p_alpha = h.pweight * 2 * 255 * sqrtf(2);       // compute.c:245
         k.prob_on = h.pweight != 0.f;
+#ifdef J2P_DEBUG
+        {
+                // what each access of the phase kernels is meant to stay inside (see DbgChan)
+                const long above = s->row0 < (unsigned)kHalo ? (long)s->row0 : (long)kHalo;
+                const unsigned below_rows = s->H - s->row0 - s->rows;
+                const long below = below_rows < (unsigned)kHalo ? (long)below_rows : (long)kHalo;
+                const float *own[2] = {k.xcur, k.xprev};
+                for(int i = 0; i < 2; i++) {
+                        k.dbg.x_read[i] = {reinterpret_cast<const char *>(own[i] - above * (long)s->W),
+                                           reinterpret_cast<const char *>(own[i] + ((long)s->rows + below) * (long)s->W)};
+                        k.dbg.x_own[i] = {reinterpret_cast<const char *>(own[i]), reinterpret_cast<const char *>(own[i] + (size_t)s->rows * s->W)};
+                }
+                const size_t cells = (size_t)(h.crows ? h.crows : 1) * h.cw;
+                k.dbg.grad = {reinterpret_cast<const char *>(h.grad), reinterpret_cast<const char *>(h.grad + (size_t)s->rows * s->W)};
+                k.dbg.pg = {reinterpret_cast<const char *>(h.pg), reinterpret_cast<const char *>(h.pg + cells)};
+                k.dbg.d = {reinterpret_cast<const char *>(h.d), reinterpret_cast<const char *>(h.d + cells)};
+                k.dbg.counters = s->dbg_counters;
+        }
+#endif
         return k;
 }
 
@@ -703,6 +726,13 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         // the row sums alternate between two buffers (measured on whole canvases: 4096^2 140.0 us per iteration either
         // way, 512^2 4:2:0 42.0 vs 40.3 us — the tail costs what the k_norm_whole launch did)
         s->fold = !whole;
+        // ... except on whole canvases small enough to be bound by the number of dependent launches: there the
+        // gradient kernel leaves the per-tile-row sums and every wavefront of k_project runs the final tree itself
+        // (512x512 4:2:0: 27.7 -> 27.2 us per iteration, 1080p Y: 55.2 -> 52.4; 4096^2: 130 -> 134, hence the limit)
+        if(whole && (size_t)W * H <= kNormInProjectPixels) {
+                s->fold = true;
+                s->norm_in_project = true;
+        }
         s->band_local = !whole && band_local_arrays != 0;
         s->weight = weight;
         s->iterations = iterations;
@@ -817,6 +847,16 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                         carve.take(h.pg, (size_t)(h.crows ? h.crows : 1) * h.cw);
                         carve.take(h.decoded, (size_t)h.frows * h.cw);
                         carve.take(h.d, (size_t)(h.crows ? h.crows : 1) * h.cw);
+                        // device-side decode of a band's input window (own rows + halo rows, rounded out to whole
+                        // block rows) normally borrows the two x buffers as scratch; a band of only a few rows is
+                        // smaller than that window, and gets scratch of its own
+                        if(!planes[c].fdata) {
+                                const size_t cells = (size_t)((h.frow0 + h.frows + 7) / 8 - h.frow0 / 8) * 8 * h.cw;
+                                if(cells > plane_floats) {
+                                        carve.take(h.scratch_f, cells);
+                                        carve.take(h.scratch_d, cells);
+                                }
+                        }
                 }
                 carve.take(q_all, 64 * kMaxCh);
                 carve.take(s->seg_row, seg.size());
@@ -830,6 +870,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 }
                 carve.take(s->norm, kMaxCh);
                 carve.take(s->tickets, (size_t)s->ntr_local + 1);
+                carve.take(s->dbg_counters, 3);
                 carve.take(s->part_tv, ntiles * 2);
                 carve.take(s->part_prob, (size_t)max_strips * nchannel);
         }
@@ -859,6 +900,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         CREATE_TRY(hipMemcpyAsync(s->seg_map, map.data(), map.size() * sizeof(unsigned), hipMemcpyHostToDevice, s->stream));
         CREATE_TRY(hipMemsetAsync(s->tickets, 0, ((size_t)s->ntr_local + 1) * sizeof(unsigned), s->stream));
         CREATE_TRY(hipMemsetAsync(s->part_prob, 0, (size_t)max_strips * nchannel * sizeof(double), s->stream));
+        CREATE_TRY(hipMemsetAsync(s->dbg_counters, 0, 3 * sizeof(unsigned long long), s->stream));
         for(unsigned c = 0; c < nchannel; c++) {
                 const j2p_plane &p = planes[c];
                 ChanHost &h = s->ch[c];
@@ -884,12 +926,12 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                                 dsrc = h.d + (size_t)(b0 * 8 - h.crow0) * h.cw;
                         } else {
                                 // scratch: the first x buffer holds (rows + 4) * W floats >= the window's int16 data
-                                if((size_t)nb_rows * 8 * h.cw * sizeof(int16_t) > plane_floats * sizeof(float)) {
+                                if(!h.scratch_d && (size_t)nb_rows * 8 * h.cw * sizeof(int16_t) > plane_floats * sizeof(float)) {
                                         rc = fail(J2P_EINVAL, "channel %u: decode window does not fit the scratch plane", c);
                                         j2p_solver_destroy(s);
                                         return rc;
                                 }
-                                int16_t *dtmp = reinterpret_cast<int16_t *>(h.xbuf[0]);
+                                int16_t *dtmp = h.scratch_d ? h.scratch_d : reinterpret_cast<int16_t *>(h.xbuf[0]);
                                 const int16_t *src = p.data + (size_t)(b0 * 8 - host_row0) * h.cw;
                                 CREATE_TRY(hipMemcpyAsync(dtmp, src, (size_t)nb_rows * 8 * h.cw * sizeof(int16_t), hipMemcpyHostToDevice, s->stream));
                                 dsrc = dtmp;
@@ -899,12 +941,12 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                                                    (const float *)h.q, h.decoded, h.cw, nb_rows);
                         } else {
                                 // window not block aligned (halo rows of a band): decode into the second x buffer, copy the rows
-                                if((size_t)nb_rows * 8 * h.cw > plane_floats) {
+                                if(!h.scratch_f && (size_t)nb_rows * 8 * h.cw > plane_floats) {
                                         rc = fail(J2P_EINVAL, "channel %u: decode window does not fit the scratch plane", c);
                                         j2p_solver_destroy(s);
                                         return rc;
                                 }
-                                float *ftmp = h.xbuf[1];
+                                float *ftmp = h.scratch_f ? h.scratch_f : h.xbuf[1];
                                 hipLaunchKernelGGL(k_decode, dim3((groups + 3) / 4), dim3(256), 0, s->stream, dsrc,
                                                    (const float *)h.q, ftmp, h.cw, nb_rows);
                                 CREATE_TRY(hipMemcpyAsync(h.decoded, ftmp + (size_t)(h.frow0 - b0 * 8) * h.cw,
@@ -939,6 +981,34 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
         default: return fail(J2P_EINVAL, "unknown option %d", option);
         }
         return J2P_OK;
+}
+
+int j2p_debug_build(void)
+{
+#ifdef J2P_DEBUG
+        return 1;
+#else
+        return 0;
+#endif
+}
+
+int j2p_solver_debug_violations(j2p_solver *s, unsigned long long *count, unsigned *site, unsigned long long *offset)
+{
+        if(!s || !count) { return fail(J2P_EINVAL, "NULL argument"); }
+#ifdef J2P_DEBUG
+        unsigned long long h[3] = {0, 0, 0};
+        DeviceGuard guard(s->device);
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(hipMemcpy(h, s->dbg_counters, sizeof(h), hipMemcpyDeviceToHost));
+        *count = h[0];
+        if(site) { *site = (unsigned)h[1]; }
+        if(offset) { *offset = h[2]; }
+        return J2P_OK;
+#else
+        (void)site;
+        (void)offset;
+        return fail(J2P_ESTATE, "not a J2P_DEBUG build: the address checks are compiled out");
+#endif
 }
 
 int j2p_solver_canvas(const j2p_solver *s, unsigned *W, unsigned *H)

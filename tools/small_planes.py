@@ -22,8 +22,10 @@ else:
 nip = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 for fold in ((1, 0) if len(sys.argv) <= 3 else (int(sys.argv[3]),)):
     for s in solvers:
-        s.debug_option(j.J2P_OPT_NORM_FOLD, fold)
+        if fold == 9:               # the library's own defaults
+            continue
         s.debug_option(j.J2P_OPT_NORM_IN_PROJECT, nip if fold else 0)
+        s.debug_option(j.J2P_OPT_NORM_FOLD, fold)
     t0 = None
     for r in range(reps + 1):
         if r == 1:
