@@ -408,7 +408,7 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         a.part_tv = s->part_tv;
         // the norm reduction rides on this launch: level 1 (row sums) always, level 2 (tree -> norm) when the
         // launch covers the whole canvas
-        const bool nip = s->norm_in_project && s->fold && s->whole && part == 0 && s->ntr_global <= kWaveTreeMax;
+        const bool nip = s->norm_in_project && s->fold && s->whole && part == 0 && s->ntr_global <= kWaveTreeMax && !log;
         const bool fold_norm = !nip && s->fold && s->whole && part == 0 && s->ntr_global <= kFoldMaxRows;
         a.row_ticket = s->fold ? s->tickets : nullptr;
         a.done_ticket = s->tickets + s->ntr_local;
@@ -540,8 +540,9 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
                 }
                 if(max_strips) {
                         const dim3 grid((max_strips + 3) / 4, 1, s->nch);
-                        if(log) { hipLaunchKernelGGL((k_project_mixed<true>), grid, dim3(256), 0, s->stream, a); }
-                        else { hipLaunchKernelGGL((k_project_mixed<false>), grid, dim3(256), 0, s->stream, a); }
+                        if(log) { hipLaunchKernelGGL((k_project_mixed<true, false>), grid, dim3(256), 0, s->stream, a); }
+                        else if(s->norm_by_project) { hipLaunchKernelGGL((k_project_mixed<false, true>), grid, dim3(256), 0, s->stream, a); }
+                        else { hipLaunchKernelGGL((k_project_mixed<false, false>), grid, dim3(256), 0, s->stream, a); }
                 }
         } else {
         // one launch per sampling class present (usually: luma 1x1, both chroma 2x2)
@@ -565,9 +566,10 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
 #define J2P_LAUNCH_PROJECT(WS_, HS_)                                                               \
         do {                                                                                       \
                 if(log) { hipLaunchKernelGGL((k_project<true, WS_, HS_>), grid, dim3(256), 0, s->stream, a); }  \
+                else if(s->norm_by_project) { hipLaunchKernelGGL((k_project<false, WS_, HS_, false, true>), grid, dim3(256), 0, s->stream, a); } \
                 else { hipLaunchKernelGGL((k_project<false, WS_, HS_>), grid, dim3(256), 0, s->stream, a); }    \
         } while(0)
-                if(ws == 1 && hs == 1 && s->ntg && !inwave_nt_off && !log) {
+                if(ws == 1 && hs == 1 && s->ntg && !inwave_nt_off && !log && !s->norm_by_project) {
                         hipLaunchKernelGGL((k_project<false, 1, 1, true>), grid, dim3(256), 0, s->stream, a);
                 }
                 else if(ws == 1 && hs == 1) { J2P_LAUNCH_PROJECT(1, 1); }
