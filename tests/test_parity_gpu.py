@@ -182,6 +182,7 @@ def test_band_split_matches_whole(lib, oracle):
                 for src in infos:
                     n = src.local_tile_rows
                     hip.hipMemcpy(dst.partials_all + 8 * src.first_tile_row, src.partials_local, 8 * n, D2D)  # nch == 1
+            hip.hipDeviceSynchronize()      # device-to-device hipMemcpy may return early; the solver streams are non-blocking
             for s in bands:
                 s.phase_project()
             for s in bands:
@@ -190,6 +191,7 @@ def test_band_split_matches_whole(lib, oracle):
             nbytes = infos[0].halo_floats * 4
             hip.hipMemcpy(infos[1].recv_top[0], infos[0].send_bottom[0], nbytes, D2D)
             hip.hipMemcpy(infos[0].recv_bottom[0], infos[1].send_top[0], nbytes, D2D)
+            hip.hipDeviceSynchronize()
         got = np.concatenate([s.download(0) for s in bands], axis=0)
     finally:
         for s in bands:
