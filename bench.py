@@ -240,7 +240,8 @@ def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("J2P_BENCH_ONE_DEVICE"):      # debugging on a 1-GPU box: every rank on the same device
+    one_device = bool(os.environ.get("J2P_BENCH_ONE_DEVICE"))
+    if one_device:                                  # debugging on a 1-GPU box: every rank on the same device
         local_rank = int(os.environ["J2P_BENCH_ONE_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     n_gpus = a.gpus
@@ -269,7 +270,11 @@ def main():
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29541")
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            if one_device:
+                # debugging the multi-rank control flow on a 1-GPU box: RCCL refuses two ranks on one device, gloo does not
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not tiled_mode:
         W = a.size or 4096
         H = a.height or W
@@ -313,7 +318,7 @@ def main():
             try:
                 data = np.concatenate([np.load(f"{tag}_{b}.npy") for b in range(nband)])
                 plane = synth.Plane(W, H, 1, 1, data, qt)
-                devices = list(range(n_gpus)) if n_gpus > 1 else [local_rank] * nband
+                devices = list(range(n_gpus)) if n_gpus > 1 and not one_device else [local_rank] * nband
                 tsolver = j.TiledSolver([plane], WEIGHT, [PWEIGHT], its, devices=devices)
                 del data, plane
                 eng = tsolver.band_solver(0)
@@ -396,7 +401,7 @@ def main():
     g_ms, p_ms, samples = eng.kernel_times() if eng is not None else (0.0, 0.0, 0)
 
     if dist is not None and dist.is_initialized():
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -20,7 +20,8 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAV
         --output-format csv -d "$OUT/${TAG}_pmc_sq" -- $B2 > /dev/null 2>&1
 # keep what is small: the stats csv and the per-kernel counter averages
 find "$OUT/${TAG}_stats" -name '*kernel_stats.csv' -exec cp {} "$OUT/${TAG}_bench_kernel_stats.csv" \;
-python $R/tools/pmc_summary.py "$OUT/${TAG}_pmc_fetch" "$OUT/${TAG}_pmc_write" "$OUT/${TAG}_pmc_sq" > "$OUT/${TAG}_pmc_raw.json"
+python $R/tools/pmc_summary.py --about "rocprofv3 on MI355X, $TAG: separate --kernel-trace --pmc passes (FETCH_SIZE | WRITE_SIZE | the SQ/GRBM set) of \`python bench.py --steps 1 --warmup 0 --iterations 50 --no-cpu-baseline --no-other-configs\` (4096x4096 Y-only Q10, BASELINE configs[2]), averaged over the launches of each kernel; hbm_* = FETCH_SIZE x2 (gfx950 correction of MI355X_MICROARCH.md) and WRITE_SIZE as reported. Collected by tools/collect_profiles.sh." \
+        "$OUT/${TAG}_pmc_fetch" "$OUT/${TAG}_pmc_write" "$OUT/${TAG}_pmc_sq" > "$OUT/${TAG}_pmc_summary.json"
 find "$OUT" -name '*.csv' -size +2M -delete
 find "$OUT" -name '*_agent_info.csv' -delete
 python $R/bench.py --steps 3 --warmup 1 > "$OUT/${TAG}_bench_n1.log" 2>&1

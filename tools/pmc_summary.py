@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Average rocprofv3 --pmc counter_collection.csv values per kernel: tools/pmc_summary.py DIR..."""
+"""Average rocprofv3 --pmc counter_collection.csv values per kernel: tools/pmc_summary.py [--about TEXT] DIR...
+Adds, where FETCH_SIZE and WRITE_SIZE are both present, the HBM-side bytes per launch with the gfx950 correction
+of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE, in KiB, reports half of a wide coalesced stream: x2;
+WRITE_SIZE as reported)."""
 import collections
 import csv
 import glob
@@ -7,7 +10,11 @@ import json
 import sys
 
 out = {}
-for d in sys.argv[1:]:
+args = sys.argv[1:]
+if args and args[0] == "--about":
+    out["_about"] = args[1]
+    args = args[2:]
+for d in args:
     for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
@@ -15,4 +22,9 @@ for d in sys.argv[1:]:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             out.setdefault(k, {}).update({c: round(sum(x) / len(x), 1) for c, x in v.items()})
+for k, v in out.items():
+    if isinstance(v, dict) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        v["hbm_read_bytes_per_launch"] = int(v["FETCH_SIZE"] * 1024 * 2)
+        v["hbm_write_bytes_per_launch"] = int(v["WRITE_SIZE"] * 1024)
+        v["hbm_bytes_per_launch"] = v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"]
 print(json.dumps(out, indent=1))
