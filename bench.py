@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--height", type=int, default=0, help="override plane height (debug, single GPU)")
     ap.add_argument("--iterations", type=int, default=0, help="override iterations per solve (debug)")
     ap.add_argument("--batch", type=int, default=32, help="--config batch: images per step")
+    ap.add_argument("--slots", type=int, default=4, help="--config batch: images in flight per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--timing-every", type=int, default=16, help="HIP-event sample stride (iterations)")
@@ -214,7 +215,7 @@ def bench_batch(a, j, synth):
     its = a.iterations or 100
     planes = synth.make_planes(1920, 1080, "420", 50, seed=1238)
     ndev = max(1, a.gpus)
-    with j.Batch(devices=list(range(ndev)), slots_per_device=4) as b:
+    with j.Batch(devices=list(range(ndev)), slots_per_device=a.slots) as b:
         def step():
             tickets = [b.submit(planes, WEIGHT, [PWEIGHT] * 3, its, width=1920, height=1080, bits=8) for _ in range(a.batch)]
             for t in tickets:
@@ -233,7 +234,7 @@ def bench_batch(a, j, synth):
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "images_per_s": round(a.batch / dt, 2),
         "config": {"workload": f"{a.batch} x 1080p 4:2:0 Q50 -i {its} joint per step (BASELINE configs[4] slice), "
-                               f"j2p_batch: {ndev} device(s) x 4 slots, PCIe inclusive"}}), flush=True)
+                               f"j2p_batch: {ndev} device(s) x {a.slots} slots, PCIe inclusive"}}), flush=True)
 
 
 def main():
