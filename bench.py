@@ -73,7 +73,6 @@ def parse():
     ap.add_argument("--tiled-impl", choices=["c", "rccl"], default="c")
     ap.add_argument("--norm-fold", type=int, default=-1, help="A/B: 1 = norm reduction inside k_gradient, 0 = stand-alone kernels; default: the library's choice")
     ap.add_argument("--norm-in-project", type=int, default=-1, help="A/B: final norm tree inside k_project (needs --norm-fold 1)")
-    ap.add_argument("--proj-reverse", type=int, default=-1, help="A/B: projection phase bottom-up (1) or top-down (0)")
     return ap.parse_args()
 
 
@@ -286,8 +285,6 @@ def main():
         solver = j.Solver(planes, WEIGHT, [PWEIGHT], its, device=local_rank)   # fdata=None: decoded on device
         if a.norm_fold >= 0:
             solver.debug_option(j.J2P_OPT_NORM_FOLD, a.norm_fold)
-        if a.proj_reverse >= 0:
-            solver.debug_option(j.J2P_OPT_PROJECT_REVERSE, a.proj_reverse)
         if a.norm_in_project >= 0:
             solver.debug_option(j.J2P_OPT_NORM_IN_PROJECT, a.norm_in_project)
         del planes

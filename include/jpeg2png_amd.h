@@ -99,8 +99,6 @@ void j2p_pool_trim(void);
                                      reduction kernels — same bits, and on a whole canvas the same speed */
 #define J2P_OPT_JOINT_INWAVE  2   /* 1: all channels of a joint image in one wavefront; 0 (default): one wavefront
                                      per channel.  Environment J2P_JOINT_INWAVE sets the default at create time */
-#define J2P_OPT_PROJECT_REVERSE 3 /* 1: the projection phase walks the canvas bottom-up (the gradient phase top-down), so
-                                     each phase starts on what the previous one left in the Infinity Cache */
 #define J2P_OPT_NORM_IN_PROJECT 4 /* 1 (needs NORM_FOLD): the gradient kernel leaves per-tile-row sums and every wavefront of
                                      the projection kernel runs the final tree itself: no reduction launch in between */
 #define J2P_OPT_NT_GRADIENT 5     /* 1: the gradient plane is written and read with non-temporal accesses; default: on when

@@ -83,7 +83,7 @@ C_ABI_SYMBOLS = [
     "compute", "j2p_compute", "j2p_compute_tiled",
     "j2p_debug_build", "j2p_solver_debug_violations",
 ]
-J2P_OPT_NORM_FOLD, J2P_OPT_JOINT_INWAVE, J2P_OPT_PROJECT_REVERSE, J2P_OPT_NORM_IN_PROJECT, J2P_OPT_NT_GRADIENT, J2P_OPT_MIXED_PROJECT = 1, 2, 3, 4, 5, 6
+J2P_OPT_NORM_FOLD, J2P_OPT_JOINT_INWAVE, J2P_OPT_NORM_IN_PROJECT, J2P_OPT_NT_GRADIENT, J2P_OPT_MIXED_PROJECT = 1, 2, 4, 5, 6
 
 _lib = None
 

@@ -232,10 +232,6 @@ struct ProjArgs {
         // sampling): by = by_offset + i * by_mul for i < nby
         // (all: 0,1,brows; first and last only: 0,brows-1,2; all but those: 1,1,brows-2)
         unsigned by_offset[kMaxCh], by_mul[kMaxCh], nby[kMaxCh];
-        // 1: strips are handed to workgroups in descending order, so that this phase starts on the rows the
-        // gradient phase finished last (and the next gradient phase starts on the rows this one finished last):
-        // what the previous launch touched last is what the 256 MiB Infinity Cache still holds
-        unsigned reverse;
         // non-NULL: the norm is not read from `norm` but reduced by every wavefront itself from the level-1 row sums
         // [tile row][channel] the gradient launch left behind (norm_tree_wave) — no reduction kernel between the phases
         const double *norm_rowsums;
@@ -1443,7 +1439,6 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                 lstrip = l * 4 + wave;                                // index within this launch
         }
         if(lstrip >= strips_x * a.nby[zi]) { return; }
-        if(a.reverse) { lstrip = strips_x * a.nby[zi] - 1 - lstrip; }
         const unsigned by = a.by_offset[zi] + (lstrip / strips_x) * a.by_mul[zi], sx = lstrip % strips_x;
         const unsigned strip = by * strips_x + sx;                    // index within the band
         (void)brows;

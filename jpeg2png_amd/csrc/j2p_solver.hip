@@ -96,7 +96,6 @@ struct j2p_solver {
         // reductions
         bool fold = false;       // norm reduction folded into k_gradient (J2P_OPT_NORM_FOLD); default: band solvers only
         bool joint_inwave = false;   // J2P_OPT_JOINT_INWAVE
-        bool proj_reverse = false;   // J2P_OPT_PROJECT_REVERSE
         bool norm_in_project = false;   // J2P_OPT_NORM_IN_PROJECT (with fold): level 2 of the norm inside k_project
         bool ntg = false;               // g through non-temporal stores / loads (nt_policy; J2P_OPT_NT_GRADIENT)
         bool mixed_project = true;      // small canvases: all samplings in one projection launch (J2P_OPT_MIXED_PROJECT)
@@ -514,7 +513,6 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
         a.norm = s->norm;
         a.part_prob = s->part_prob;
         a.strips_per_chan = s->strips_stride;
-        a.reverse = s->proj_reverse ? 1u : 0u;
         a.norm_rowsums = s->norm_by_project ? s->rowsum_local : nullptr;
         a.norm_rows = s->ntr_global;
         a.norm_nch = s->nch;
@@ -976,7 +974,6 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
                 s->fold = value != 0;
                 break;
         case J2P_OPT_JOINT_INWAVE: s->joint_inwave = value != 0; break;
-        case J2P_OPT_PROJECT_REVERSE: s->proj_reverse = value != 0; break;
         case J2P_OPT_NORM_IN_PROJECT: s->norm_in_project = value != 0; break;
         case J2P_OPT_NT_GRADIENT: s->ntg = value != 0; break;
         case J2P_OPT_MIXED_PROJECT: s->mixed_project = value != 0; break;

@@ -522,6 +522,36 @@ def test_both_joint_modes_agree(lib, oracle, monkeypatch):
             assert bit_equal(got[c].fdata, want[c]), f"mode {mode} channel {c}"
 
 
+@pytest.mark.parametrize("shape", [(520, 136, "420", False), (1000, 96, "444", True), (264, 200, "422", False)])
+def test_every_schedule_switch_leaves_the_bits_alone(lib, oracle, shape):
+    """the J2P_OPT_* switches select schedules of the same arithmetic (where the norm is reduced, whether g is
+    streamed non-temporally, one projection launch or one per sampling class): every combination the solver can
+    pick by itself — the choice depends on the canvas size — must give the bits of the reference on ONE canvas"""
+    import jpeg2png_amd as j
+    w, h, sub, yonly = shape
+    planes = make_case(w, h, sub, 10, seed=91, y_only=yonly)
+    n = len(planes)
+    its = 9
+    want, _ = oracle.oracle_compute(planes, 0.3, [0.001] * n, its)
+    settings = [
+        {},                                                                         # the solver's own choice
+        {j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 0},                     # stand-alone norm kernel
+        {j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 1},                     # both levels inside k_gradient
+        {j.J2P_OPT_NORM_FOLD: 1, j.J2P_OPT_NORM_IN_PROJECT: 1},                     # level 2 inside k_project
+        {j.J2P_OPT_NT_GRADIENT: 1},                                                 # what a > 240 MiB working set gets
+        {j.J2P_OPT_NT_GRADIENT: 1, j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 0},
+        {j.J2P_OPT_MIXED_PROJECT: 0},                                               # what a > 1 Mpixel canvas gets
+        {j.J2P_OPT_MIXED_PROJECT: 0, j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 0, j.J2P_OPT_JOINT_INWAVE: 1},
+    ]
+    for opts in settings:
+        with j.Solver(planes, 0.3, [0.001] * n, its) as s:
+            for k, v in opts.items():
+                s.debug_option(k, v)
+            s.run(its)
+            for c in range(n):
+                assert bit_equal(s.download(c), want[c]), f"options {opts} channel {c}"
+
+
 def test_concurrent_calls_are_independent(lib, oracle):
     """compute() is entered concurrently by the reference's `-s` and multi-file OpenMP regions
     (jpeg2png.c:147,330): six simultaneous calls from six host threads must each return the

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Result of one solve as a file, for bitwise comparison between library builds / schedule options:
-    [J2P_LIBRARY=...] python tools/ab_parity.py OUT.npy [opt=value ...]     (opt: fold, nip, rev)
+    [J2P_LIBRARY=...] python tools/ab_parity.py OUT.npy [opt=value ...]     (opt: fold, nip, ntg, mixed)
     python tools/ab_parity.py --cmp A.npy B.npy ..."""
 import os
 import sys
@@ -28,7 +28,7 @@ res = []
 for (w, h, samp, yonly, its) in ((1000, 744, "444", True, 40), (4096, 1024, "444", True, 12), (640, 480, "420", False, 25)):
     planes = synth.make_planes(w, h, samp, 10, seed=77, y_only=yonly)
     s = j.Solver(planes, 0.3, [0.001] * len(planes), its)
-    for name, oid in (("fold", j.J2P_OPT_NORM_FOLD), ("rev", j.J2P_OPT_PROJECT_REVERSE), ("nip", j.J2P_OPT_NORM_IN_PROJECT)):
+    for name, oid in (("fold", j.J2P_OPT_NORM_FOLD), ("nip", j.J2P_OPT_NORM_IN_PROJECT), ("ntg", j.J2P_OPT_NT_GRADIENT), ("mixed", j.J2P_OPT_MIXED_PROJECT)):
         if name in opts:
             s.debug_option(oid, int(opts[name]))
     s.run(its)

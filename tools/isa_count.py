@@ -47,14 +47,14 @@ def count(body, trips):
             f"+ s_waitcnt {c['s_waitcnt'] / trips:.1f} + vmem {vmem / trips:.1f} + lds {lds / trips:.1f}")
 
 
-for kern, trips in (("_ZN3j2p10k_gradientILi1ELb1ELb0ELi1EEEvNS_8GradArgsE", 4), ("_ZN3j2p10k_gradientILi1ELb1ELb0ELi3EEEvNS_8GradArgsE", 3)):
+for kern, trips in (("_ZN3j2p10k_gradientILi1ELb1ELb0ELi1ELb1EEEvNS_8GradArgsE", 4), ("_ZN3j2p10k_gradientILi1ELb1ELb0ELi3ELb0EEEvNS_8GradArgsE", 3)):
     i = text.index(kern + ":")
     j = text.index("s_endpgm", i)
     L = text[i:j].split("\n")
     hdr = [n for n, line in enumerate(L) if "Inner Loop Header" in line]
     m = re.search(r"; NumVgprs: *(\d+)", text[j:j + 6000])
     code = re.search(r"codeLenInByte = (\d+)", text[j:j + 6000])
-    print(f"{kern[-28:-16]}: VGPRs {m.group(1) if m else '?'}, code {code.group(1) if code else '?'} bytes")
+    print(f"{kern[-34:-16]}: VGPRs {m.group(1) if m else '?'}, code {code.group(1) if code else '?'} bytes")
     for which, h in enumerate(hdr):
         body = L[h:hdr[which + 1]] if which + 1 < len(hdr) else L[h:]
         print(f"   march {which}: per trip {count(body, trips)}")
