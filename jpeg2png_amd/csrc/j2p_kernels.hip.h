@@ -196,8 +196,11 @@ struct Geo {
         unsigned rows;      // band rows
         unsigned ntx;       // gradient strips (wavefronts) per row of strips
         unsigned rpw;       // rows per gradient strip = rows per norm partial: 16, or 8 / 4 on small canvases
-        const unsigned *seg_row;   // [nseg + 1] first band-local row of every row segment (multiples of rpw)
-        const unsigned *seg_map;   // [gridDim.y] segments this launch processes (all, interior only, or the two edge ones)
+        // row segments of a gradient launch: segment i covers band-local rows [i * rpw, min((i + 1) * rpw, rows));
+        // launch row j of the grid handles segment seg_off + j * seg_mul (all: 0,1; interior only: 1,1; the two
+        // edge ones: 0, nseg - 1).  Plain arithmetic on kernel arguments: a table in memory would put two dependent
+        // loads in front of every wavefront's first row fetch
+        unsigned seg_off, seg_mul;
 };
 
 struct GradArgs {
@@ -720,15 +723,15 @@ void k_gradient(GradArgs a)
                 const unsigned xcd = b & 7, q = nwg >> 3, rem = nwg & 7;
                 const unsigned l = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
                 bx = l % gridDim.x;
-                bseg = a.geo.seg_map[l / gridDim.x];
+                bseg = a.geo.seg_off + (l / gridDim.x) * a.geo.seg_mul;
         }
         const int wcol = J == 1 ? (int)bx * (int)(blockDim.x >> 6) + wave : (int)bx;   // J == 1: blockDim.x / 64 strips per workgroup
         const int cbase = J == 1 ? 0 : wave;                    // first channel of this wavefront
         if(wcol >= (int)a.geo.ntx) { return; }
         const int W = (int)a.geo.W, H = (int)a.geo.H;
         const int rows = (int)a.geo.rows, row0 = (int)a.geo.row0;
-        const int t0 = (int)a.geo.seg_row[bseg];               // band-local target rows [t0, t1)
-        const int t1 = (int)a.geo.seg_row[bseg + 1];
+        const int t0 = (int)(bseg * a.geo.rpw);                // band-local target rows [t0, t1)
+        const int t1 = t0 + (int)a.geo.rpw < rows ? t0 + (int)a.geo.rpw : rows;
         // Strip i loads columns [124 i, 124 i + 128); lanes 0 and 63 are halo — except at the image's
         // left and right edges, where the neighbour beyond the edge contributes nothing anyway, so the
         // first strip also owns its lane 0 and the last strip its lane 63: n strips cover 124 n + 4
@@ -1414,18 +1417,6 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
         const int c = (int)a.chan_of_z[zi];
         const ChanDev &k = a.ch[c];
         const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-        if(threadIdx.x < 64) {
-                const float q = k.q[threadIdx.x];
-                qs[threadIdx.x] = q;
-                qq[threadIdx.x] = q * q;
-                rqq[threadIdx.x] = div_prepare1(q * q);
-                rq[threadIdx.x] = div_prepare1(q);
-                const bool ok = den_ok(q * q) && den_ok(q);
-                const unsigned long long all_ok = __builtin_amdgcn_ballot_w64(ok);
-                if(threadIdx.x == 0) { q_fast = all_ok == ~0ull; }
-        }
-        __syncthreads();
-
         const unsigned W = a.geo.W;
         const unsigned ws = k.ws, hs = k.hs;
         const unsigned strips_x = (W + 64 * ws - 1) / (64 * ws);      // strips across the canvas
@@ -1438,7 +1429,9 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                 const unsigned l = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
                 lstrip = l * 4 + wave;                                // index within this launch
         }
-        if(lstrip >= strips_x * a.nby[zi]) { return; }
+        // (wavefronts past the launch's last strip stay until the workgroup barrier below)
+        const bool active = lstrip < strips_x * a.nby[zi];
+        if(!active) { lstrip = 0; }
         const unsigned by = a.by_offset[zi] + (lstrip / strips_x) * a.by_mul[zi], sx = lstrip % strips_x;
         const unsigned strip = by * strips_x + sx;                    // index within the band
         (void)brows;
@@ -1461,23 +1454,14 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
         const bool resample1 = unit && (k.cw != W || k.ch != a.geo.H);
         const bool direct = unit && !resample1;
         // wave-uniform: the whole 64 x 8 strip is inside the canvas and projected
-        const bool full = WS == 1 && HS == 1 && unit && sx * 64 + 64 <= k.cw && sx * 64 + 64 <= W && cy0 < k.ch &&
+        const bool full = active && WS == 1 && HS == 1 && unit && sx * 64 + 64 <= k.cw && sx * 64 + 64 <= W && cy0 < k.ch &&
                           ly0 + 8 <= a.geo.rows;
 
-        // subsampled channel, strip wholly inside canvas and coverage: register-resident fast path
-        constexpr bool kSub = WS * HS > 1;
-        const bool fullsub = kSub && ws == (unsigned)WS && hs == (unsigned)HS && sx * 64 + 64 <= k.cw &&
-                             (sx * 64 + 64) * ws <= W && cy0 + 8 <= k.ch && ly0 + 8 * hs <= a.geo.rows;
-        const size_t sub_base = (size_t)ly0 * W + (size_t)cx * ws;
-        SubTile<(kSub ? WS : 1), (kSub ? HS : 1)> tile;
-
-        float v[8];
-        float st1[8];                                                   // stepped pixels of a `full && resample1` strip
-        if(fullsub) {
-                sub_load_step_mean<(kSub ? WS : 1), (kSub ? HS : 1)>(k, sub_base, W, a.factor, a.step, norm, tile, v);
-        } else if(full) {
-                // all 24 loads in flight before the first use
-                float gv[8], xcv[8], xpv[8];
+        // The common path puts its 24 loads in flight FIRST; the quantisation tables (one more dependent global load,
+        // then LDS and a workgroup barrier) are set up while they fly: one memory round trip in front of the
+        // arithmetic instead of two.
+        float gv[8], xcv[8], xpv[8];
+        if(full) {
                 const size_t base = (size_t)ly0 * W + cx;
                 // (array by array: 0.5 % faster than row by row)
 #pragma unroll
@@ -1496,6 +1480,33 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                         if constexpr(NTG) { gv[r] = __builtin_nontemporal_load(&k.grad[base + (size_t)r * W]); }
                         else { gv[r] = k.grad[base + (size_t)r * W]; }
                 }
+        }
+        if(threadIdx.x < 64) {
+                const float q = k.q[threadIdx.x];
+                qs[threadIdx.x] = q;
+                qq[threadIdx.x] = q * q;
+                rqq[threadIdx.x] = div_prepare1(q * q);
+                rq[threadIdx.x] = div_prepare1(q);
+                const bool ok = den_ok(q * q) && den_ok(q);
+                const unsigned long long all_ok = __builtin_amdgcn_ballot_w64(ok);
+                if(threadIdx.x == 0) { q_fast = all_ok == ~0ull; }
+        }
+        __syncthreads();
+
+        if(!active) { return; }
+
+        // subsampled channel, strip wholly inside canvas and coverage: register-resident fast path
+        constexpr bool kSub = WS * HS > 1;
+        const bool fullsub = kSub && ws == (unsigned)WS && hs == (unsigned)HS && sx * 64 + 64 <= k.cw &&
+                             (sx * 64 + 64) * ws <= W && cy0 + 8 <= k.ch && ly0 + 8 * hs <= a.geo.rows;
+        const size_t sub_base = (size_t)ly0 * W + (size_t)cx * ws;
+        SubTile<(kSub ? WS : 1), (kSub ? HS : 1)> tile;
+
+        float v[8];
+        float st1[8];                                                   // stepped pixels of a `full && resample1` strip
+        if(fullsub) {
+                sub_load_step_mean<(kSub ? WS : 1), (kSub ? HS : 1)>(k, sub_base, W, a.factor, a.step, norm, tile, v);
+        } else if(full) {
                 v2f y2[4], g2[4];
                 bool sus = false;
 #pragma unroll

@@ -104,8 +104,6 @@ struct j2p_solver {
         bool norm_by_project = false;   // ... or left level-1 row sums that k_project reduces itself
         unsigned *tickets = nullptr;     // device: [ntr_local] per-tile-row arrival counters + [1] finished-rows counter
         unsigned rpw = 16;
-        unsigned *seg_row = nullptr;     // device: [nseg + 1] segment start rows
-        unsigned *seg_map = nullptr;     // device: [nseg] identity, then [nseg - 2] interior, then [2] first/last
         bool interior_done = false;
         bool rowsums_pending = false;
         unsigned ntx = 0, nseg = 0, ntr_local = 0, ntr_global = 0, first_tr = 0;   // strips per row, row segments
@@ -289,8 +287,8 @@ Geo geo_of(const j2p_solver *s)
         g.rows = s->rows;
         g.ntx = s->ntx;
         g.rpw = s->rpw;
-        g.seg_row = s->seg_row;
-        g.seg_map = s->seg_map;
+        g.seg_off = 0;
+        g.seg_mul = 1;
         return g;
 }
 
@@ -391,14 +389,15 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
                 s->t = tnext;
         }
         unsigned nseg_launch = s->nseg;
-        const unsigned *map = s->seg_map;
-        if(part == 1) { nseg_launch = s->nseg - 2; map = s->seg_map + s->nseg; }
-        if(part == 2) { nseg_launch = 2; map = s->seg_map + s->nseg + (s->nseg - 2); }
+        unsigned seg_off = 0, seg_mul = 1;
+        if(part == 1) { nseg_launch = s->nseg - 2; seg_off = 1; }
+        if(part == 2) { nseg_launch = 2; seg_mul = s->nseg - 1; }
 
         GradArgs a;
         for(unsigned c = 0; c < s->nch; c++) { a.ch[c] = chan_dev(s, c); }
         a.geo = geo_of(s);
-        a.geo.seg_map = map;
+        a.geo.seg_off = seg_off;
+        a.geo.seg_mul = seg_mul;
         a.factor = s->factor;
         a.a_tv = (float)(1. / (double)sqrtf((float)s->nch));                    // compute.c:90
         const float alpha = s->weight / sqrtf((float)(4 / 2));                  // compute.c:258
@@ -820,14 +819,6 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 if(strips > max_strips) { max_strips = strips; }
         }
         s->strips_stride = max_strips;
-        // launch lists: all segments | interior segments | the two edge segments
-        std::vector<unsigned> seg, map;
-        for(unsigned i = 0; i <= s->nseg; i++) { seg.push_back(i * s->rpw < s->rows ? i * s->rpw : s->rows); }
-        for(unsigned i = 0; i < s->nseg; i++) { map.push_back(i); }
-        for(unsigned i = 1; i + 1 < s->nseg; i++) { map.push_back(i); }
-        map.push_back(0);
-        map.push_back(s->nseg - 1);
-
         // ---- one arena for everything (sizes first, then the pointers) ----
         const size_t plane_floats = (size_t)(s->rows + 2 * kHalo) * W;
         float *q_all = nullptr;
@@ -859,8 +850,6 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                         }
                 }
                 carve.take(q_all, 64 * kMaxCh);
-                carve.take(s->seg_row, seg.size());
-                carve.take(s->seg_map, map.size());
                 carve.take(s->part_g2, ntiles * nchannel);
                 carve.take(s->rowsum_local, (size_t)s->ntr_local * nchannel);
                 if(whole) { s->rowsum_all = s->rowsum_local; }
@@ -896,8 +885,6 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 for(int j = 0; j < 64; j++) { qf[64 * c + j] = (float)planes[c].quant_table[j]; }
         }
         CREATE_TRY(hipMemcpyAsync(q_all, qf, sizeof(float) * 64 * nchannel, hipMemcpyHostToDevice, s->stream));
-        CREATE_TRY(hipMemcpyAsync(s->seg_row, seg.data(), seg.size() * sizeof(unsigned), hipMemcpyHostToDevice, s->stream));
-        CREATE_TRY(hipMemcpyAsync(s->seg_map, map.data(), map.size() * sizeof(unsigned), hipMemcpyHostToDevice, s->stream));
         CREATE_TRY(hipMemsetAsync(s->tickets, 0, ((size_t)s->ntr_local + 1) * sizeof(unsigned), s->stream));
         CREATE_TRY(hipMemsetAsync(s->part_prob, 0, (size_t)max_strips * nchannel * sizeof(double), s->stream));
         CREATE_TRY(hipMemsetAsync(s->dbg_counters, 0, 3 * sizeof(unsigned long long), s->stream));
