@@ -27,6 +27,9 @@ static pthread_mutex_t progress_lock = PTHREAD_MUTEX_INITIALIZER;
  * log->f == NULL and pb == NULL the reference never observably calls them either. */
 extern void logger_log(struct logger *log, double objective, double prob_dist, double tv, double tv2) __attribute__((weak));
 extern void progressbar_inc(struct progressbar *pb) __attribute__((weak));
+/* likewise the first half of the host's die() (utils.c:11-17): it wipes the progress bar off the line before the
+ * `jpeg2png: ` prefix goes out.  Used when the host has it, so that a failure in here reads like one of its own. */
+extern void die_message_start(void) __attribute__((weak));
 
 /* The loop of compute.c:427-453 over either engine: one j2p_solver (whole canvas on one GPU) or one j2p_tiled
  * (row bands over several GPUs).  Same chunking, callbacks and hand-back either way. */
@@ -153,7 +156,8 @@ void compute(unsigned nchannel, struct coef coefs[], struct logger *log, struct 
         if(rc != J2P_OK) {
                 const char *msg = j2p_last_error();
                 /* die(), utils.c:20-28 */
-                fprintf(stderr, "jpeg2png: %s\n", (msg && *msg) ? msg : "GPU solver failed");
+                if(die_message_start) { die_message_start(); } else { fprintf(stderr, "jpeg2png: "); }
+                fprintf(stderr, "%s\n", (msg && *msg) ? msg : "GPU solver failed");
                 exit(EXIT_FAILURE);
         }
 }

@@ -199,6 +199,26 @@ def test_the_reference_program_itself_runs_on_the_library(tmp_path, flags, threa
 
 
 @pytest.mark.gpu
+def test_a_failure_inside_the_library_reads_like_the_reference_dying(tmp_path):
+    """compute() has no return value: any failure ends like die() (utils.c:11-28) — the host's own
+    die_message_start() wipes the progress bar off the line, then `jpeg2png: <message>` and EXIT_FAILURE.  Provoked
+    here by asking the reference program, linked against the library, for a GPU that does not exist."""
+    if not os.path.exists(REF_DROPIN):
+        pytest.skip("oracle/_ref/jpeg2png_ref_dropin not built (needs /root/reference)")
+    jpg = tmp_path / "a.jpg"
+    make_jpeg(jpg, 64, 48, 30, 2, seed=9)
+    env = dict(os.environ, J2P_DEVICE="99")
+    env.pop("J2P_DEVICES", None)
+    r = subprocess.run([REF_DROPIN, str(jpg), "-o", str(tmp_path / "a.png"), "-i", "3"], capture_output=True, text=True, env=env)
+    assert r.returncode == 1
+    assert r.stderr.startswith("jpeg2png: ") and "device" in r.stderr
+    assert not (tmp_path / "a.png").exists()
+    # the bar was drawn and then wiped by the host's own die_message_start (progressbar_clear, progressbar.c:57-66:
+    # carriage return, 77 blanks, carriage return — which text mode hands over as newlines)
+    assert "0%" in r.stdout and r.stdout.rstrip("\n").endswith(" " * 77)
+
+
+@pytest.mark.gpu
 def test_truncated_jpeg_warns_and_carries_on_like_the_reference(cli, tmp_path):
     """libjpeg reports a premature end of file through output_message; the reference prints it
     (`jpeg2png: libjpeg error: ...`, jpeg.c:14-19) and decodes what is there.  So must the CLI — and the drop-in."""
