@@ -1112,6 +1112,9 @@ int j2p_solver_set_logging(j2p_solver *s, int on)
 {
         if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
         DeviceGuard guard(s->device);
+        // like the schedule switches: the two phases of an iteration have to agree on it (where the norm is reduced
+        // depends on it)
+        if(s->grad_done || s->interior_done) { return fail(J2P_ESTATE, "logging changes between iterations only"); }
         if(on && !s->log_band) {
                 HIP_TRY(hipMalloc(&s->log_band, (2 + kMaxCh) * sizeof(double)));
                 HIP_TRY(hipMemsetAsync(s->log_band, 0, (2 + kMaxCh) * sizeof(double), s->stream));
