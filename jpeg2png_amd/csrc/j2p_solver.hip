@@ -799,12 +799,15 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         // measured no faster).  A small canvas is latency-bound INSIDE k_gradient — 512x512 4:2:0: 480
         // wavefronts of 18 dependent row trips each on a chip with 4096 wavefront slots, 21 us; launch gaps are ~0
         // (profiles/r02_small_planes.md) — so it gets more and shorter strips: 8 or 4 rows while the canvas has fewer
-        // than 1024 strips.  A function of the CANVAS only (never of the band), so that every band of a tiled run —
+        // than 2048 strips.  A function of the CANVAS only (never of the band), so that every band of a tiled run —
         // and the whole-canvas solver — reduce ||g|| over the same partials in the same order.
         {
                 const unsigned per_strip_row = s->ntx * nchannel;       // one wavefront per channel and strip
                 unsigned g = kTY;
-                while(g > 4 && (unsigned long long)per_strip_row * ((H + g - 1) / g) < 1024ull) { g >>= 1; }
+                // (2048: half the chip's 4096 wavefront slots.  Measured: 1080p Y 34.2 -> 31.2 us per iteration with 8-row
+                // strips, three such planes on three streams 124.5 -> 131.3 Gpx-it/s, 1024^2 22.5 -> 21.4 us; 2048^2 and
+                // larger keep 16 rows and their times.  A limit of 4096 costs the 512^2 image 5 %.)
+                while(g > 4 && (unsigned long long)per_strip_row * ((H + g - 1) / g) < 2048ull) { g >>= 1; }
                 s->rpw = g;
         }
         s->nseg = (s->rows + s->rpw - 1) / s->rpw;
