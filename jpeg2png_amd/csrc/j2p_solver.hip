@@ -231,7 +231,7 @@ struct Carver {
 };
 
 constexpr size_t kNtWorkingSet = (size_t)240 << 20;      // see nt_policy in j2p_solver_create
-constexpr size_t kNormInProjectPixels = (size_t)4 << 20; // whole canvases up to this size reduce ||g|| without a launch of its own
+constexpr size_t kNormInProjectPixels = (size_t)5 << 19; // whole canvases up to this size (2.5 Mpixel) reduce ||g|| without a launch of its own
 constexpr size_t kMixedProjectPixels = (size_t)1 << 20;  // canvases up to this size project all channels in one launch
 
 unsigned gcd_u(unsigned a, unsigned b) { return b ? gcd_u(b, a % b) : a; }
@@ -727,7 +727,8 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         s->fold = !whole;
         // ... except on whole canvases small enough to be bound by the number of dependent launches: there the
         // gradient kernel leaves the per-tile-row sums and every wavefront of k_project runs the final tree itself
-        // (512x512 4:2:0: 27.7 -> 27.2 us per iteration, 1080p Y: 55.2 -> 52.4; 4096^2: 130 -> 134, hence the limit)
+        // (512x512 4:2:0: 27.7 -> 27.2 us per iteration, 1024^2 Y: 22.1 -> 21.7, 1080p and 1536^2 Y: equal;
+        // 2048^2: 48.9 -> 50.8, 4096^2: 130 -> 134, hence the limit)
         if(whole && (size_t)W * H <= kNormInProjectPixels) {
                 s->fold = true;
                 s->norm_in_project = true;
