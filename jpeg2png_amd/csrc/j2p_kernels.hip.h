@@ -704,7 +704,7 @@ constexpr int kGradWaves3 = 2;    // ... the three-channels-in-one-wavefront sch
 // NTG: g is written with non-temporal stores (and read that way by k_project<.., NTG>): written once, read once,
 // it then stays out of the way of the data that IS re-used between the phases (x_k, x_{k-1}, prob state, d).  Pays
 // when the solver's working set exceeds the 256 MiB Infinity Cache only because of g (4096^2 Y: 288 MiB with g,
-// 224 MiB without: 137 -> 127 us per iteration); costs 1-5 % when everything fits anyway (see nt_policy).
+// 224 MiB without: 137 -> 127 us per iteration); costs 1-2 % when everything fits anyway (see nt_policy).
 template <int NCH, bool TGV, bool LOG, int J = 1, bool NTG = false>
 __global__ __launch_bounds__((J == 1 ? 256 : 64 * J), (NCH == 1 ? kGradWaves1 : NCH == 2 ? 3 : kGradWaves3))
 void k_gradient(GradArgs a)

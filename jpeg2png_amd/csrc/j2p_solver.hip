@@ -230,7 +230,7 @@ struct Carver {
         }
 };
 
-constexpr size_t kNtWorkingSet = (size_t)240 << 20;      // see nt_policy in j2p_solver_create
+constexpr size_t kNtWorkingSet = (size_t)260 << 20;      // see nt_policy in j2p_solver_create
 constexpr size_t kNormInProjectPixels = (size_t)5 << 19; // whole canvases up to this size (2.5 Mpixel) reduce ||g|| without a launch of its own
 constexpr size_t kMixedProjectPixels = (size_t)1 << 20;  // canvases up to this size project all channels in one launch
 
@@ -869,9 +869,10 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         }
 
         // ---- nt_policy: is the gradient plane what keeps the iteration's working set from staying in the
-        // Infinity Cache?  x_k, x_{k-1}, g, prob state, d of every channel; measured on 4096-wide Y planes:
-        // 2048 rows (144 MiB) 78.0 us per iteration with plain accesses vs 79.4 non-temporal, 4096 rows (288 MiB)
-        // 137.1 vs 126.4-130.1, 8192 rows (576 MiB) 275.4 vs 276.0
+        // Infinity Cache (256 MiB)?  x_k, x_{k-1}, g, prob state, d of every channel; measured on 4096-wide Y planes,
+        // us per iteration with plain / non-temporal accesses to g: 2560 rows (180 MiB) 87.0 / 88.2, 3072 (216) 99.3 /
+        // 101.2, 3328 (234) 106.9 / 108.5, 3584 (252) 112.3 / 114.1, 4096 (288) 135.8 / 127.0, 5120 (360) 175.0 /
+        // 161.3, 8192 (576) 275.4 / 276.0
         {
                 size_t working_set = 0;
                 for(unsigned c = 0; c < nchannel; c++) {
