@@ -101,8 +101,9 @@ void j2p_pool_trim(void);
                                      per channel.  Environment J2P_JOINT_INWAVE sets the default at create time */
 #define J2P_OPT_NORM_IN_PROJECT 4 /* 1 (needs NORM_FOLD): the gradient kernel leaves per-tile-row sums and every wavefront of
                                      the projection kernel runs the final tree itself: no reduction launch in between */
-#define J2P_OPT_NT_GRADIENT 5     /* 1: the gradient plane is written and read with non-temporal accesses; default: on when
-                                     the solver's working set exceeds the Infinity Cache (256 MiB), off otherwise */
+#define J2P_OPT_NT_GRADIENT 5     /* 0..3: which streams are accessed non-temporally (1: the gradient plane, 2: + the prob
+                                     state, 3: + the coefficients); default: by the size of the solver's working set
+                                     against the Infinity Cache (256 MiB) */
 #define J2P_OPT_MIXED_PROJECT 6   /* 1 (default): canvases up to 1 Mpixel project all channels in ONE launch whatever their
                                      sampling; 0: one launch per sampling class, as large canvases do */
 int j2p_solver_debug_option(j2p_solver *s, int option, int value);

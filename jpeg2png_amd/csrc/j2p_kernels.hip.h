@@ -701,11 +701,14 @@ constexpr int kGradWaves3 = 2;    // ... the three-channels-in-one-wavefront sch
 // NCH channels are handled inside one wavefront (J == 1, workgroup = 4 strips), or — for a
 // jointly optimised image — J wavefronts of a workgroup take one channel each of the same strip
 // and only exchange their norm contributions through LDS (J > 1, NCH == 1).
-// NTG: g is written with non-temporal stores (and read that way by k_project<.., NTG>): written once, read once,
-// it then stays out of the way of the data that IS re-used between the phases (x_k, x_{k-1}, prob state, d).  Pays
-// when the solver's working set exceeds the 256 MiB Infinity Cache only because of g (4096^2 Y: 288 MiB with g,
-// 224 MiB without: 137 -> 127 us per iteration); costs 1-2 % when everything fits anyway (see nt_policy).
-template <int NCH, bool TGV, bool LOG, int J = 1, bool NTG = false>
+// NT (0..3): which streams bypass the caches' retention (non-temporal loads / stores), chosen by the solver from the
+// size of its working set against the 256 MiB Infinity Cache (nt_policy in j2p_solver_create).  x_k and x_{k-1} are
+// each touched two or three times per iteration and never get the hint; g (written by this kernel, read once by
+// k_project) gets it at level >= 1, the prob state (written by k_project, read once here) at >= 2, the coefficients
+// d (read once per iteration by k_project) at 3.  What is left without the hint is what should stay cache-resident:
+// 4096^2 Y (288 MiB): level 1, 137 -> 127 us per iteration; 16384x2048 (576 MiB, the planes x_k, x_{k-1} are exactly
+// 256 MiB): level 3, 292 -> 240 us; when everything fits the hint costs 1-2 %.
+template <int NCH, bool TGV, bool LOG, int J = 1, int NT = 0>
 __global__ __launch_bounds__((J == 1 ? 256 : 64 * J), (NCH == 1 ? kGradWaves1 : NCH == 2 ? 3 : kGradWaves3))
 void k_gradient(GradArgs a)
 {
@@ -835,7 +838,8 @@ void k_gradient(GradArgs a)
                         if constexpr(decltype(free_tag)::unit) {
                                 const float *prow = k.pg + (size_t)((unsigned)gt - k.crow0) * k.cw;
                                 J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + xoff, 8, 103);
-                                pv[c] = *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(prow) + xoff);
+                                if constexpr(NT >= 2) { pv[c] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(prow) + xoff)); }
+                                else { pv[c] = *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(prow) + xoff); }
                                 continue;
                         }
                         unsigned cr;
@@ -953,7 +957,7 @@ void k_gradient(GradArgs a)
                                         if(pair_own) {
                                                 v2f *gdst = reinterpret_cast<v2f *>(reinterpret_cast<char *>(k.grad + (size_t)t * W) + (unsigned)xl * 4u);
                                                 J2P_CHK(k, grad, gdst, 8, 106);
-                                                if constexpr(NTG) { __builtin_nontemporal_store(g, gdst); }
+                                                if constexpr(NT >= 1) { __builtin_nontemporal_store(g, gdst); }
                                                 else { *gdst = g; }
                                                 const v2f sq = g * g;
                                                 g2[c] += (double)sq.x;   // compute.c:203
@@ -1406,7 +1410,7 @@ struct __attribute__((aligned(16))) ProjShared {
         int q_fast;
 };
 
-template <bool LOG, int WS, int HS, bool NTG, bool NIP>
+template <bool LOG, int WS, int HS, int NT, bool NIP>
 __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
 {
         float *const tp = sh.tp;
@@ -1477,7 +1481,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
 #pragma unroll
                 for(int r = 0; r < 8; r++) {
                         J2P_CHK(k, grad, &k.grad[base + (size_t)r * W], 4, 208);
-                        if constexpr(NTG) { gv[r] = __builtin_nontemporal_load(&k.grad[base + (size_t)r * W]); }
+                        if constexpr(NT >= 1) { gv[r] = __builtin_nontemporal_load(&k.grad[base + (size_t)r * W]); }
                         else { gv[r] = k.grad[base + (size_t)r * W]; }
                 }
         }
@@ -1591,7 +1595,13 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                 if(bcov) {
                         const size_t blk = (size_t)(cy0 / 8 - k.crow0 / 8) * (k.cw / 8) + bx;
                         J2P_CHK(k, d, k.d + blk * 64 + rr * 8, 16, 211);
-                        raw = *reinterpret_cast<const int4 *>(k.d + blk * 64 + rr * 8);
+                        if constexpr(NT >= 3) {
+                                typedef int v4i __attribute__((ext_vector_type(4)));
+                                const v4i rv = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(k.d + blk * 64 + rr * 8));
+                                raw = make_int4(rv.x, rv.y, rv.z, rv.w);
+                        } else {
+                                raw = *reinterpret_cast<const int4 *>(k.d + blk * 64 + rr * 8);
+                        }
                 }
                 const int rw[4] = {raw.x, raw.y, raw.z, raw.w};
                 v2f t2[4], q2[4];
@@ -1695,8 +1705,14 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                 if(bcov) {
                         float4 *dst = reinterpret_cast<float4 *>(k.pg + (size_t)(cy0 - k.crow0 + rr) * k.cw + bx * 8);
                         J2P_CHK(k, pg, dst, 32, 214);
-                        dst[0] = make_float4(e[0], e[1], e[2], e[3]);
-                        dst[1] = make_float4(e[4], e[5], e[6], e[7]);
+                        if constexpr(NT >= 2) {
+                                typedef float v4f __attribute__((ext_vector_type(4)));
+                                __builtin_nontemporal_store(v4f{e[0], e[1], e[2], e[3]}, reinterpret_cast<v4f *>(dst));
+                                __builtin_nontemporal_store(v4f{e[4], e[5], e[6], e[7]}, reinterpret_cast<v4f *>(dst) + 1);
+                        } else {
+                                dst[0] = make_float4(e[0], e[1], e[2], e[3]);
+                                dst[1] = make_float4(e[4], e[5], e[6], e[7]);
+                        }
                 }
                 if(LOG) {
                         if(!bcov) { dist = 0.; }
@@ -1709,11 +1725,11 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
 
 // NIP: the norm comes from norm_tree_wave (ProjArgs::norm_rowsums) instead of ProjArgs::norm
 // (80 registers for the 1x1 form = six wavefronts per SIMD; forcing seven or eight spills: 66 -> 76 / 97 us)
-template <bool LOG, int WS, int HS, bool NTG = false, bool NIP = false>
+template <bool LOG, int WS, int HS, int NT = 0, bool NIP = false>
 __global__ __launch_bounds__(256) void k_project(ProjArgs a)
 {
         __shared__ ProjShared sh;
-        project_strip<LOG, WS, HS, NTG, NIP>(a, sh);
+        project_strip<LOG, WS, HS, NT, NIP>(a, sh);
 }
 
 // Small canvases are bound by the number of dependent launches per iteration, not by bytes: there ALL channels
@@ -1725,9 +1741,9 @@ __global__ __launch_bounds__(256) void k_project_mixed(ProjArgs a)
 {
         __shared__ ProjShared sh;
         const ChanDev &k = a.ch[a.chan_of_z[blockIdx.z]];
-        if(k.ws == 1 && k.hs == 1) { project_strip<LOG, 1, 1, false, NIP>(a, sh); }
-        else if(k.ws == 2 && k.hs == 2) { project_strip<LOG, 2, 2, false, NIP>(a, sh); }
-        else { project_strip<LOG, 0, 0, false, NIP>(a, sh); }
+        if(k.ws == 1 && k.hs == 1) { project_strip<LOG, 1, 1, 0, NIP>(a, sh); }
+        else if(k.ws == 2 && k.hs == 2) { project_strip<LOG, 2, 2, 0, NIP>(a, sh); }
+        else { project_strip<LOG, 0, 0, 0, NIP>(a, sh); }
 }
 
 // ---------------------------------------------------------------------------

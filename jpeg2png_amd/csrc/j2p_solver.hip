@@ -97,7 +97,7 @@ struct j2p_solver {
         bool fold = false;       // norm reduction folded into k_gradient (J2P_OPT_NORM_FOLD); default: band solvers only
         bool joint_inwave = false;   // J2P_OPT_JOINT_INWAVE
         bool norm_in_project = false;   // J2P_OPT_NORM_IN_PROJECT (with fold): level 2 of the norm inside k_project
-        bool ntg = false;               // g through non-temporal stores / loads (nt_policy; J2P_OPT_NT_GRADIENT)
+        int nt = 0;                     // 0..3: streams with the non-temporal hint (nt_policy; J2P_OPT_NT_GRADIENT)
         bool mixed_project = true;      // small canvases: all samplings in one projection launch (J2P_OPT_MIXED_PROJECT)
         unsigned long long *dbg_counters = nullptr;   // J2P_DEBUG builds: [0] address violations, [1] first site, [2] first offset
         bool norm_ready = false; // the gradient launch of this iteration also produced norm[]
@@ -293,17 +293,22 @@ Geo geo_of(const j2p_solver *s)
 }
 
 template <int NCH, int J>
-void launch_gradient_n(const GradArgs &a, unsigned ntx, unsigned nseg, hipStream_t st, bool tgv, bool log, bool ntg)
+void launch_gradient_n(const GradArgs &a, unsigned ntx, unsigned nseg, hipStream_t st, bool tgv, bool log, int nt)
 {
         // J == 1: 4 strips per 256-thread workgroup; J > 1: one strip per workgroup of J wavefronts
         constexpr unsigned wpb = 4;     // strips per workgroup
         const dim3 grid = J == 1 ? dim3((ntx + wpb - 1) / wpb, nseg) : dim3(ntx, nseg);
         const dim3 block = J == 1 ? dim3(64 * wpb) : dim3(64 * J);
         if constexpr(NCH == 1) {
-                // non-temporal g (see nt_policy): the one-channel-per-wavefront kernels without logging
-                if(ntg && !log) {
-                        if(tgv) { hipLaunchKernelGGL((k_gradient<NCH, true, false, J, true>), grid, block, 0, st, a); }
-                        else { hipLaunchKernelGGL((k_gradient<NCH, false, false, J, true>), grid, block, 0, st, a); }
+                // non-temporal g / prob state (see nt_policy): the one-channel-per-wavefront kernels without logging
+                if(nt >= 1 && !log) {
+                        if(nt >= 2) {
+                                if(tgv) { hipLaunchKernelGGL((k_gradient<NCH, true, false, J, 2>), grid, block, 0, st, a); }
+                                else { hipLaunchKernelGGL((k_gradient<NCH, false, false, J, 2>), grid, block, 0, st, a); }
+                        } else {
+                                if(tgv) { hipLaunchKernelGGL((k_gradient<NCH, true, false, J, 1>), grid, block, 0, st, a); }
+                                else { hipLaunchKernelGGL((k_gradient<NCH, false, false, J, 1>), grid, block, 0, st, a); }
+                        }
                         return;
                 }
         }
@@ -423,14 +428,14 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         // selects the in-wavefront kernel (kept: it is the same arithmetic in another schedule, and tested).
         const bool inwave = s->joint_inwave;
         switch(s->nch) {
-        case 1: launch_gradient_n<1, 1>(a, s->ntx, nseg_launch, st, tgv, log, s->ntg); break;
+        case 1: launch_gradient_n<1, 1>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); break;
         case 2:
-                if(inwave) { launch_gradient_n<2, 1>(a, s->ntx, nseg_launch, st, tgv, log, false); }
-                else { launch_gradient_n<1, 2>(a, s->ntx, nseg_launch, st, tgv, log, s->ntg); }
+                if(inwave) { launch_gradient_n<2, 1>(a, s->ntx, nseg_launch, st, tgv, log, 0); }
+                else { launch_gradient_n<1, 2>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); }
                 break;
         default:
-                if(inwave) { launch_gradient_n<3, 1>(a, s->ntx, nseg_launch, st, tgv, log, false); }
-                else { launch_gradient_n<1, 3>(a, s->ntx, nseg_launch, st, tgv, log, s->ntg); }
+                if(inwave) { launch_gradient_n<3, 1>(a, s->ntx, nseg_launch, st, tgv, log, 0); }
+                else { launch_gradient_n<1, 3>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); }
                 break;
         }
         if(part != 2) { mark(s); }
@@ -563,11 +568,13 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
 #define J2P_LAUNCH_PROJECT(WS_, HS_)                                                               \
         do {                                                                                       \
                 if(log) { hipLaunchKernelGGL((k_project<true, WS_, HS_>), grid, dim3(256), 0, s->stream, a); }  \
-                else if(s->norm_by_project) { hipLaunchKernelGGL((k_project<false, WS_, HS_, false, true>), grid, dim3(256), 0, s->stream, a); } \
+                else if(s->norm_by_project) { hipLaunchKernelGGL((k_project<false, WS_, HS_, 0, true>), grid, dim3(256), 0, s->stream, a); } \
                 else { hipLaunchKernelGGL((k_project<false, WS_, HS_>), grid, dim3(256), 0, s->stream, a); }    \
         } while(0)
-                if(ws == 1 && hs == 1 && s->ntg && !inwave_nt_off && !log && !s->norm_by_project) {
-                        hipLaunchKernelGGL((k_project<false, 1, 1, true>), grid, dim3(256), 0, s->stream, a);
+                if(ws == 1 && hs == 1 && s->nt >= 1 && !inwave_nt_off && !log && !s->norm_by_project) {
+                        if(s->nt >= 3) { hipLaunchKernelGGL((k_project<false, 1, 1, 3>), grid, dim3(256), 0, s->stream, a); }
+                        else if(s->nt == 2) { hipLaunchKernelGGL((k_project<false, 1, 1, 2>), grid, dim3(256), 0, s->stream, a); }
+                        else { hipLaunchKernelGGL((k_project<false, 1, 1, 1>), grid, dim3(256), 0, s->stream, a); }
                 }
                 else if(ws == 1 && hs == 1) { J2P_LAUNCH_PROJECT(1, 1); }
                 else if(ws == 2 && hs == 2) { J2P_LAUNCH_PROJECT(2, 2); }
@@ -868,19 +875,27 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 carve.take(s->part_prob, (size_t)max_strips * nchannel);
         }
 
-        // ---- nt_policy: is the gradient plane what keeps the iteration's working set from staying in the
-        // Infinity Cache (256 MiB)?  x_k, x_{k-1}, g, prob state, d of every channel; measured on 4096-wide Y planes,
-        // us per iteration with plain / non-temporal accesses to g: 2560 rows (180 MiB) 87.0 / 88.2, 3072 (216) 99.3 /
-        // 101.2, 3328 (234) 106.9 / 108.5, 3584 (252) 112.3 / 114.1, 4096 (288) 135.8 / 127.0, 5120 (360) 175.0 /
-        // 161.3, 8192 (576) 275.4 / 276.0
+        // ---- nt_policy: which streams of the iteration get the non-temporal hint, so that what stays without it can
+        // live in the 256 MiB Infinity Cache.  Per byte and iteration x_k and x_{k-1} are touched 2-3 times, g and the
+        // prob state twice, d once: keep the planes, then d and the prob state if they fit beside them, g last.
+        // Measured on Y planes (us per iteration; none / level 1 / level 2 / level 3):
+        //   4096x3584 (252 MiB) 112.3 / 114.1            4096x4096 (288 MiB) 135.8 / 127.0
+        //   4096x5120 (360 MiB) 175.0 / 163.7 / 159.6 / 163.4
+        //   16384x2048 (576 MiB) 295 / 292.7 / 250.8 / 240.2     8192x8192 (1152 MiB) - / 541.5 / 528.3 / 527.0
         {
-                size_t working_set = 0;
+                size_t working_set = 0, planes_bytes = 0, d_bytes = 0;
                 for(unsigned c = 0; c < nchannel; c++) {
                         const ChanHost &h = s->ch[c];
                         const size_t cells = (size_t)(h.crows ? h.crows : 1) * h.cw;
                         working_set += (2 * plane_floats + (size_t)s->rows * W + cells) * sizeof(float) + cells * sizeof(int16_t);
+                        planes_bytes += 2 * plane_floats * sizeof(float);
+                        d_bytes += cells * sizeof(int16_t);
                 }
-                s->ntg = working_set > kNtWorkingSet;
+                const size_t g_bytes = (size_t)nchannel * s->rows * W * sizeof(float);
+                if(working_set <= kNtWorkingSet) { s->nt = 0; }                                   // everything fits
+                else if(working_set - g_bytes <= kNtWorkingSet) { s->nt = 1; }                    // everything but g fits
+                else if(planes_bytes + d_bytes <= kNtWorkingSet) { s->nt = 2; }                   // planes and d fit
+                else { s->nt = 3; }
         }
 
         // ---- uploads (host arrays: whole-image unless band_local) ----
@@ -967,7 +982,7 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
                 break;
         case J2P_OPT_JOINT_INWAVE: s->joint_inwave = value != 0; break;
         case J2P_OPT_NORM_IN_PROJECT: s->norm_in_project = value != 0; break;
-        case J2P_OPT_NT_GRADIENT: s->ntg = value != 0; break;
+        case J2P_OPT_NT_GRADIENT: s->nt = value < 0 ? 0 : (value > 3 ? 3 : value); break;
         case J2P_OPT_MIXED_PROJECT: s->mixed_project = value != 0; break;
         default: return fail(J2P_EINVAL, "unknown option %d", option);
         }

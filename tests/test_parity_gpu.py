@@ -538,8 +538,10 @@ def test_every_schedule_switch_leaves_the_bits_alone(lib, oracle, shape):
         {j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 0},                     # stand-alone norm kernel
         {j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 1},                     # both levels inside k_gradient
         {j.J2P_OPT_NORM_FOLD: 1, j.J2P_OPT_NORM_IN_PROJECT: 1},                     # level 2 inside k_project
-        {j.J2P_OPT_NT_GRADIENT: 1},                                                 # what a > 240 MiB working set gets
-        {j.J2P_OPT_NT_GRADIENT: 1, j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 0},
+        {j.J2P_OPT_NT_GRADIENT: 1},                                                 # what working sets beyond the Infinity Cache get:
+        {j.J2P_OPT_NT_GRADIENT: 2},                                                 # g / + prob state / + coefficients non-temporal
+        {j.J2P_OPT_NT_GRADIENT: 3},
+        {j.J2P_OPT_NT_GRADIENT: 3, j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 0},
         {j.J2P_OPT_MIXED_PROJECT: 0},                                               # what a > 1 Mpixel canvas gets
         {j.J2P_OPT_MIXED_PROJECT: 0, j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 0, j.J2P_OPT_JOINT_INWAVE: 1},
     ]
