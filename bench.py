@@ -9,14 +9,21 @@ compute.c:443) — with no host copies inside the timed region.
 
 Workloads (BASELINE.json configs):
   N = 1 : configs[2]  4096x4096 Y-only, Q=10, -i 500, weight 0.3, pweight 0.001
-          (the configuration the metric "Mpixel-iterations/sec on 4K Y-plane" is quoted on)
+          (the configuration the metric "Mpixel-iterations/sec on 4K Y-plane" is quoted on).
+          `other_configs` carries configs[0], configs[1], a configs[4] slice and the 16384x2048 band that is
+          the N = 1 point of the N > 1 workload below.
   N > 1 : configs[3]  16384-wide Y-only plane, Q=10, -i 100, row-tiled: 2048 rows per GPU
-          (N = 8 is exactly the 16384x16384 config); weak scaling (fixed rows per GPU).
-          Default engine: the C row tiling (j2p_tiled: one process drives all N GPUs with one host
-          thread per band; bands exchange edge rows and norm row sums by peer access over xGMI,
-          ordered by HIP events) — rank 0 drives it, the other ranks of the launch only take part
-          in the barriers.  `--tiled-impl rccl`: the round-1 harness, one process per GPU with
-          RCCL send/recv + all-gather (jpeg2png_amd/tiled.py).
+          (N = 8 is exactly the 16384x16384 config); weak scaling (fixed rows per GPU).  BOTH engines are
+          timed, each with W warm-up and K timed steps between barriers:
+            c    : the C row tiling (j2p_tiled: one process drives all N GPUs with one host thread per band;
+                   bands exchange edge rows and norm row sums by peer access over xGMI, ordered by HIP events)
+                   — rank 0 drives it; the other ranks of the launch wait in a gloo (CPU) barrier, so that no
+                   RCCL barrier kernel spins on their GPUs while rank 0's band kernels run there;
+            rccl : one process per GPU, RCCL send/recv of the halo rows + all-gather of the norm row sums
+                   (jpeg2png_amd/tiled.py), the exchange north_star names.
+          `value` is the faster of the two (`config.parallelism` says which), the other one is in
+          `other_configs`, next to the SAME canvas solved whole on ONE GPU (the strong-scaling denominator)
+          and configs[4] — 256 x 1080p 4:2:0 Q50 -i 100 through the C batch engine over all N GPUs.
   --config batch : configs[4] slice — B x 1080p 4:2:0 Q=50 -i 100 through the C batch API
           (host buffers in, RGB out: PCIe inclusive), images/s and Mpx-it/s.
 
@@ -32,8 +39,7 @@ The JSON also carries
                  box's host cores on a bounded sample of the same workload, 1 thread;
   cpu_baseline_all_cores : the same library called from one host thread per core on independent
                  planes — the reference's file-level OpenMP parallelism (jpeg2png.c:330; its
-                 in-solver OpenMP gains nothing for a single plane, SURVEY.md §6.2);
-  other_configs: configs[0], configs[1] and a configs[4] slice timed in this same run.
+                 in-solver OpenMP gains nothing for a single plane).
 """
 import argparse
 import json
@@ -52,6 +58,7 @@ BYTES_GRADIENT = 16              # per canvas pixel per launch (SURVEY.md §8d, 
 BYTES_PROJECT = 22               # phase B
 BYTES_ITERATION = BYTES_GRADIENT + BYTES_PROJECT
 WEIGHT, PWEIGHT = 0.3, 0.001     # jpeg2png.c:22-23 defaults
+RCCL_LEG_TIMEOUT_S = 240         # watchdog of the second (RCCL) leg of an N > 1 run
 
 
 def parse():
@@ -70,7 +77,8 @@ def parse():
     ap.add_argument("--timing-every", type=int, default=16, help="HIP-event sample stride (iterations)")
     ap.add_argument("--force-tiled", action="store_true", help="run the row-tiled path even with one rank (debug)")
     ap.add_argument("--bands", type=int, default=0, help="--force-tiled on one GPU: number of bands on device 0")
-    ap.add_argument("--tiled-impl", choices=["c", "rccl"], default="c")
+    ap.add_argument("--tiled-impl", choices=["both", "c", "rccl"], default="both",
+                    help="N > 1: which row-tiling engine(s) to time (default both; the faster one is `value`)")
     ap.add_argument("--norm-fold", type=int, default=-1, help="A/B: 1 = norm reduction inside k_gradient, 0 = stand-alone kernels; default: the library's choice")
     ap.add_argument("--norm-in-project", type=int, default=-1, help="A/B: final norm tree inside k_project (needs --norm-fold 1)")
     return ap.parse_args()
@@ -104,6 +112,8 @@ def cpu_baseline(width, seed):
     from jpeg2png_amd import synth
     from oracle import bindings as ob
     rows, its = 4096, 40
+    if width > 4096:                       # the 16384-wide workload of an N > 1 run: the same number of pixels
+        rows = 1024
     planes = synth.make_planes(width, rows, "444", 10, seed=seed, y_only=True)
     for p in planes:
         p.fdata = ob.decode_plane(p)
@@ -116,17 +126,19 @@ def cpu_baseline(width, seed):
         secs = time.perf_counter() - t0
         kind = "port"
     one = {"value": round(width * rows * its / secs / 1e6, 2), "unit": "Mpixel-iterations/s", "cores": 1,
-           "kind": kind, "cpu": cpu_model(),
+           "kind": kind, "cpu": cpu_model(), "width": width, "rows": rows, "iterations": its, "seconds": round(secs, 3),
+           "planes": 1,
            "sample": f"{width}x{rows} Y-only Q10, {its} iterations, weight {WEIGHT}, pweight {PWEIGHT}, "
                      f"{secs:.2f} s inside compute(), host has {os.cpu_count()} cores"}
     # all cores: one compute() per host thread on independent planes (the reference's omp-parallel-for over files,
-    # jpeg2png.c:330): the 4096-row plane cut into 512-row pieces, each thread solves one piece, 20 iterations
+    # jpeg2png.c:330): the plane cut into 512-row pieces, each thread solves one piece, 10 iterations
     ncores = os.cpu_count() or 1
     nthreads = min(ncores, 256)
-    piece_rows, its_all = 512, 10
+    piece_rows, its_all = 512 * 4096 // width if width > 4096 else 512, 10
     pieces = []
     for k in range(8):
-        pl = synth.make_planes(width, 4096, "444", 10, seed=seed, y_only=True, rows=(k * piece_rows, (k + 1) * piece_rows))
+        pl = synth.make_planes(width, rows, "444", 10, seed=seed, y_only=True,
+                               rows=((k * piece_rows) % rows, (k * piece_rows) % rows + piece_rows))
         for p in pl:
             p.fdata = ob.decode_plane(p)
         pieces.append(pl)
@@ -140,23 +152,60 @@ def cpu_baseline(width, seed):
         t.join()
     secs_all = time.perf_counter() - t0
     allc = {"value": round(nthreads * width * piece_rows * its_all / secs_all / 1e6, 2), "unit": "Mpixel-iterations/s",
-            "cores": nthreads, "kind": kind, "cpu": cpu_model(),
+            "cores": nthreads, "kind": kind, "cpu": cpu_model(), "width": width, "rows": piece_rows, "iterations": its_all,
+            "seconds": round(secs_all, 3), "planes": nthreads,
             "sample": f"{nthreads} concurrent compute() calls (one host thread each, the reference's file-level "
                       f"parallelism), each {width}x{piece_rows} Y-only Q10, {its_all} iterations; {secs_all:.2f} s wall"}
     return one, allc
 
 
-def other_configs(j, synth):
-    """configs[0], configs[1] and a configs[4] slice on this GPU, solver-resident like the headline (reset + run)."""
-    out = []
-
-    def timed(fn, reps):
+def _timed(fn, reps):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
         fn()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        return (time.perf_counter() - t0) / reps
+    return (time.perf_counter() - t0) / reps
 
+
+def whole_canvas_on_one_gpu(j, plane, its, device=0, reps=2):
+    """a Y plane solved whole on ONE GPU, resident (reset + run): Mpx-it/s and the iteration fraction"""
+    s = j.Solver([plane], WEIGHT, [PWEIGHT], its, device=device)
+
+    def run():
+        s.reset()
+        s.run(its)
+        s.sync()
+    dt = _timed(run, reps)
+    s.close()
+    j.load_library().j2p_pool_trim()
+    px = plane.w * plane.h
+    return {"ms_per_solve": round(dt * 1e3, 3), "us_per_iteration": round(dt / its * 1e6, 2),
+            "Mpx_it_per_s": round(px * its / dt / 1e6, 1),
+            "iteration_frac": round(BYTES_ITERATION * px * its / dt / 1e9 / HBM_PEAK_GBS, 4)}
+
+
+def batch_images_per_s(j, synth, devices, n_images, slots, its=100):
+    """configs[4]: n_images x 1080p 4:2:0 Q50 -i `its` joint through the C batch engine over `devices` (host
+    coefficient buffers in, RGB out: PCIe inclusive; the file loop jpeg2png.c:330-337)"""
+    planes = synth.make_planes(1920, 1080, "420", 50, seed=1238)
+    with j.Batch(devices=devices, slots_per_device=slots) as b:
+        def step(n):
+            tickets = [b.submit(planes, WEIGHT, [PWEIGHT] * 3, its, width=1920, height=1080, bits=8) for _ in range(n)]
+            for t in tickets:
+                b.wait(t)
+        step(min(n_images, 4 * len(devices) * slots))          # warm the pool on every device
+        t0 = time.perf_counter()
+        step(n_images)
+        dt = time.perf_counter() - t0
+    W, H = 1920, 1088
+    return {"images": n_images, "seconds": round(dt, 4), "images_per_s": round(n_images / dt, 2),
+            "Mpx_it_per_s": round(n_images * W * H * 3 * its / dt / 1e6, 1), "devices": len(devices), "slots_per_device": slots}
+
+
+def other_configs(j, synth):
+    """configs[0], configs[1], a configs[4] slice and the N = 1 point of the row-tiled workload on this GPU,
+    solver-resident like the headline (reset + run)."""
+    out = []
     planes = synth.make_planes(512, 512, "420", 10, seed=1235)
     s = j.Solver(planes, WEIGHT, [PWEIGHT] * 3, 50)
 
@@ -164,7 +213,7 @@ def other_configs(j, synth):
         s.reset()
         s.run(50)
         s.sync()
-    dt = timed(run0, 20)
+    dt = _timed(run0, 20)
     s.close()
     out.append({"config": "configs[0] 512x512 4:2:0 Q10 -i 50 joint", "ms_per_solve": round(dt * 1e3, 4),
                 "Mpx_it_per_s": round(512 * 512 * 3 * 50 / dt / 1e6, 1)})
@@ -181,7 +230,7 @@ def other_configs(j, synth):
                 sv.run(10)
         for sv in solvers:
             sv.sync()
-    dt = timed(run1, 5)
+    dt = _timed(run1, 5)
     for sv in solvers:
         sv.close()
     out.append({"config": "configs[1] 1920x1080 4:4:4 Q10 -i 100, -s: three compute(1,...) on three streams, weights 0.3/0/0",
@@ -200,12 +249,20 @@ def other_configs(j, synth):
                 sv.run(10)
         for sv in solvers:
             sv.sync()
-    dt = timed(run4, 2)
+    dt = _timed(run4, 2)
     for sv in solvers:
         sv.close()
     out.append({"config": f"configs[4] slice: {n} x 1080p 4:2:0 Q50 -i 100 joint (canvas {W}x{H}), one stream each, resident",
                 "ms_per_batch": round(dt * 1e3, 3), "images_per_s": round(n / dt, 2),
                 "Mpx_it_per_s": round(n * W * H * 3 * 100 / dt / 1e6, 1)})
+    j.load_library().j2p_pool_trim()
+
+    # the N = 1 point of `--gpus N` (2048 rows of the 16384-wide plane per GPU): one such band, whole, on this GPU
+    band = synth.make_planes(16384, 2048, "444", 10, seed=1234 + 4, y_only=True)[0]
+    r = whole_canvas_on_one_gpu(j, band, 100)
+    r["config"] = ("configs[3] N = 1 point: 16384x2048 Y-only Q10 -i 100 on one GPU (what `--gpus N` gives every GPU: "
+                   "2048 rows of the 16384-wide plane)")
+    out.append(r)
     return out
 
 
@@ -236,19 +293,379 @@ def bench_batch(a, j, synth):
                                f"j2p_batch: {ndev} device(s) x {a.slots} slots, PCIe inclusive"}}), flush=True)
 
 
+class Ranks:
+    """the launch's ranks: RCCL (backend nccl) process group as the contract asks, plus a gloo side group for
+    everything that must not touch the GPUs — the timing barriers (an RCCL barrier is a kernel that spins on the
+    waiting rank's GPU: rank 0's band kernels of the C engine run on those very GPUs) and the max-over-ranks"""
+
+    def __init__(self, rank, world, local_rank, one_device):
+        self.rank, self.world = rank, world
+        self.dist = None
+        self.cpu = None
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            if one_device:
+                # rehearsing the multi-rank control flow on a 1-GPU box: RCCL refuses two ranks on one device
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            self.dist = dist
+            self.cpu = dist.new_group(backend="gloo")
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier(group=self.cpu)
+
+    def max(self, v):
+        if self.dist is None:
+            return v
+        import torch
+        t = torch.tensor([v], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.cpu)
+        return float(t.item())
+
+    def share(self, obj, src=0):
+        if self.dist is None:
+            return obj
+        box = [obj]
+        self.dist.broadcast_object_list(box, src=src, group=self.cpu)
+        return box[0]
+
+    def close(self):
+        if self.dist is not None and self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+
+def time_steps(ranks, reset, solve, sync, warmup, steps, eng, timing_every):
+    """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; max over ranks"""
+    import torch
+    for _ in range(warmup):
+        reset()
+        solve()
+    sync()
+    if eng is not None:
+        eng.enable_timing(timing_every)
+    ranks.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        reset()
+        solve()
+    sync()
+    torch.cuda.synchronize()
+    ranks.barrier()
+    elapsed = ranks.max(time.perf_counter() - t0)
+    g_ms, p_ms, samples = eng.kernel_times() if eng is not None else (0.0, 0.0, 0)
+    if eng is not None:
+        eng.enable_timing(0)
+    return elapsed, g_ms, p_ms, samples
+
+
+def per_kernel_roofline(px_gradient, px_project, g_ms, p_ms):
+    per_kernel = {}
+    for kname, kms, kb, px in (("k_gradient", g_ms, BYTES_GRADIENT, px_gradient), ("k_project", p_ms, BYTES_PROJECT, px_project)):
+        gbs = px * kb / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        per_kernel[kname] = {"avg_launch_ms": round(kms, 4), "algorithmic_bytes_per_launch": px * kb,
+                             "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    return per_kernel
+
+
+def pmc_traffic():
+    """HBM bytes per iteration from the rocprofv3 PMC passes of the N = 1 workload (profiles/, corrected as
+    MI355X_MICROARCH.md prescribes)"""
+    for tag in ("r03", "r02", "r01"):
+        pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json")
+        if not os.path.exists(pmc):
+            continue
+        with open(pmc) as f:
+            summ = json.load(f)
+        tot = {}
+        for name, v in summ.items():
+            if isinstance(v, dict) and "hbm_bytes_per_launch" in v:
+                for kk in ("k_gradient", "k_project"):
+                    if name.startswith("j2p::" + kk) or name.startswith(kk):
+                        tot[kk] = v["hbm_bytes_per_launch"]
+        if len(tot) == 2:
+            return tot["k_gradient"] + tot["k_project"], f"profiles/{tag}_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE; k_gradient + k_project)"
+    return None, None
+
+
+def roofline_object(value_mpx, gpus_used, its, elapsed, steps, band_px, per_kernel, samples, timing_every, traffic=None, traffic_src=None):
+    kern = min(per_kernel, key=lambda k: per_kernel[k]["frac"])
+    it_gbs = BYTES_ITERATION * value_mpx * 1e6 / gpus_used / 1e9
+    return {"bound": "hbm", "scope": "whole iteration (k_gradient + k_project, launch gaps included), wall clock, per GPU",
+            "kernel": kern, "achieved": round(it_gbs, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(it_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_unit": "bytes per iteration", "traffic_source": traffic_src,
+            "algorithmic_bytes_per_iteration": band_px * BYTES_ITERATION,
+            "iteration_ms": round(elapsed / steps / its * 1e3, 5),
+            "kernel_frac": per_kernel[kern]["frac"],
+            "per_kernel": per_kernel,
+            "event_samples": samples,
+            "note": "per-kernel durations come from HIP events around every "
+                    f"{timing_every}th iteration; the event records themselves cost time on those "
+                    "iterations, so the two durations can add up to more than iteration_ms"}
+
+
+def single_gpu(a, j, synth, local_rank):
+    W = a.size or 4096
+    H = a.height or W
+    its = a.iterations or 500
+    seed = 1234 + 3
+    workload = f"{W}x{H} Y-only Q10 -i {its} (BASELINE configs[2])"
+    planes = synth.make_planes(W, H, "444", 10, seed=seed, y_only=True)
+    solver = j.Solver(planes, WEIGHT, [PWEIGHT], its, device=local_rank)   # fdata=None: decoded on device
+    if a.norm_fold >= 0:
+        solver.debug_option(j.J2P_OPT_NORM_FOLD, a.norm_fold)
+    if a.norm_in_project >= 0:
+        solver.debug_option(j.J2P_OPT_NORM_IN_PROJECT, a.norm_in_project)
+    del planes
+    ranks = Ranks(0, 1, local_rank, False)
+    elapsed, g_ms, p_ms, samples = time_steps(ranks, solver.reset, lambda: solver.run(its), solver.sync, a.warmup, a.steps,
+                                              solver, a.timing_every)
+    px = W * H
+    value = px * its * a.steps / elapsed / 1e6
+    per_kernel = per_kernel_roofline(px, px, g_ms, p_ms)
+    traffic, traffic_src = pmc_traffic() if not a.size else (None, None)
+    out = {
+        "metric": "Mpixel-iterations/sec on 4K Y-plane", "value": round(value, 1),
+        "unit": "Mpixel-iterations/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "iterations_per_step": its, "weight": WEIGHT, "pweight": PWEIGHT,
+                   "parallelism": "single GPU"},
+        "roofline": roofline_object(value, 1, its, elapsed, a.steps, px, per_kernel, samples, a.timing_every, traffic, traffic_src),
+    }
+    solver.close()
+    if not a.no_other_configs and not a.size:
+        out["other_configs"] = other_configs(j, synth)
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(W, seed)
+    _flush_c_stdio()
+    print(json.dumps(out), flush=True)
+
+
+def tiled(a, j, synth, rank, world, local_rank, one_device):
+    """N > 1 (or --force-tiled): the 16384-wide plane, 2048 rows per GPU, both engines"""
+    import torch
+    n_gpus = world
+    ranks = Ranks(rank, world, local_rank, one_device)
+    W = a.size or 16384
+    rows_per_gpu = 2048 if not a.size else max(64, a.size // 8 // 16 * 16)
+    nband = n_gpus if n_gpus > 1 else max(2, a.bands or 2)
+    H = rows_per_gpu * nband
+    its = a.iterations or 100
+    seed = 1234 + 4
+    workload = (f"{W}x{H} Y-only Q10 -i {its}, row-tiled {rows_per_gpu} rows/GPU over {n_gpus} GPUs "
+                f"(BASELINE configs[3] at 8 GPUs)")
+    px, band_px = W * H, W * rows_per_gpu
+    # every rank synthesises its own band(s); rank 0 collects them through /dev/shm for the engines it drives alone
+    tag = f"/dev/shm/j2p_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+    my_bands = {}
+    whole_plane = None
+    if n_gpus == 1:
+        # --force-tiled on one GPU: the whole canvas, synthesised band by band on the host's cores
+        whole_plane = synth.make_y_plane_banded(W, H, 10, seed, band_rows=rows_per_gpu, workers=min(nband, os.cpu_count() or 1))
+        my_bands[0] = synth.Plane(W, rows_per_gpu, 1, 1, whole_plane.data[: W * rows_per_gpu], whole_plane.quant_table)
+    else:
+        band = synth.make_planes(W, H, "444", 10, seed=seed, y_only=True, rows=(rank * rows_per_gpu, (rank + 1) * rows_per_gpu))[0]
+        my_bands[rank] = band
+        np.save(f"{tag}_{rank}.npy", band.data)
+        ranks.barrier()
+        if rank == 0:
+            whole_plane = synth.Plane(W, H, 1, 1, np.concatenate([np.load(f"{tag}_{b}.npy") for b in range(nband)]), band.quant_table)
+        ranks.barrier()
+        try:
+            os.unlink(f"{tag}_{rank}.npy")
+        except OSError:
+            pass
+
+    legs = {}
+    want_c = a.tiled_impl in ("both", "c")
+    # (the RCCL harness needs one rank per GPU: not in the one-device rehearsal, and with a single rank only on request)
+    want_rccl = (a.tiled_impl == "rccl" or (a.tiled_impl == "both" and world > 1)) and not (one_device and world > 1)
+
+    # ---- leg 1: the C engine, driven by rank 0 ----
+    if want_c:
+        ok = [True, ""]
+        tsolver = eng = None
+        if rank == 0:
+            try:
+                devices = list(range(n_gpus)) if n_gpus > 1 and not one_device else [local_rank] * nband
+                tsolver = j.TiledSolver([whole_plane], WEIGHT, [PWEIGHT], its, devices=devices)
+                eng = tsolver.band_solver(0)
+            except Exception as e:      # noqa: BLE001  (no peer access between the GPUs, a device this process cannot open ...)
+                ok = [False, f"{type(e).__name__}: {e}"]
+        ok = ranks.share(ok)
+        if ok[0]:
+            if rank == 0:
+                reset, solve, sync = tsolver.reset, (lambda: tsolver.run(its)), tsolver.sync
+            else:
+                reset = solve = sync = (lambda: None)
+            elapsed, g_ms, p_ms, samples = time_steps(ranks, reset, solve, sync, a.warmup, a.steps, eng, a.timing_every)
+            cpu_s = tsolver.host_cpu_seconds() if rank == 0 else 0.0
+            if rank == 0:
+                tsolver.close()
+            legs["c"] = {"elapsed": elapsed, "g_ms": g_ms, "p_ms": p_ms, "samples": samples, "split": True,
+                         "host_cpu_s": round(cpu_s, 3),
+                         "parallelism": (f"row-tiled x{nband}: C engine (j2p_tiled), one process drives all GPUs, one host thread per "
+                                         "band; edge rows and norm row sums read over peer access, ordered by HIP events; one band "
+                                         "reduces ||g|| for all")}
+        elif rank == 0:
+            print(f"bench: C row tiling unavailable: {ok[1]}", file=sys.stderr, flush=True)
+            legs["c_error"] = ok[1]
+    ranks.barrier()
+
+    # ---- leg 2: one process per GPU over RCCL ----
+    watchdog = None
+    state = {"printed": False, "out": None}
+    lock = threading.Lock()
+
+    def emit():
+        with lock:
+            if state["printed"] or state["out"] is None:
+                return
+            state["printed"] = True
+            _flush_c_stdio()
+            print(json.dumps(state["out"]), flush=True)
+
+    def finish(extra_other=None, strict=True):
+        """rank 0: assemble the JSON line from the legs measured so far"""
+        if rank != 0:
+            return
+        timed = {k: v for k, v in legs.items() if isinstance(v, dict) and "elapsed" in v}
+        if not timed and not strict:
+            return
+        if not timed:
+            raise SystemExit("bench: no row-tiling engine could run: " + json.dumps({k: v for k, v in legs.items() if not isinstance(v, dict)}))
+        best = min(timed, key=lambda k: timed[k]["elapsed"])
+        L = timed[best]
+        value = px * its * a.steps / L["elapsed"] / 1e6
+        # pixels per TIMED launch: in the split schedules the events bracket the interior launches only
+        # (all 16-row segments but the band's first and last; all block rows but the first and last)
+        pxg, pxp = (W * (rows_per_gpu - 32), W * (rows_per_gpu - 16)) if L["split"] else (band_px, band_px)
+        per_kernel = per_kernel_roofline(pxg, pxp, L["g_ms"], L["p_ms"])
+        others = []
+        for k, v in timed.items():
+            if k == best:
+                continue
+            others.append({"config": f"the same workload through the other engine ({k})", "parallelism": v["parallelism"],
+                           "Mpx_it_per_s": round(px * its * a.steps / v["elapsed"] / 1e6, 1),
+                           "ms_per_step": round(v["elapsed"] / a.steps * 1e3, 3)})
+        for k, v in legs.items():
+            if not isinstance(v, dict):
+                others.append({"config": f"engine {k}", "error": v})
+        others += extra_other or []
+        gpus_used = n_gpus if n_gpus > 1 else 1
+        out = {
+            "metric": (f"Mpixel-iterations/sec on a 16384-wide Y plane row-tiled over {n_gpus} GPUs, 2048 rows per GPU "
+                       "(BASELINE configs[3] at 8 GPUs)") if not a.size else "Mpixel-iterations/sec, row-tiled Y plane (debug size)",
+            "value": round(value, 1),
+            "unit": "Mpixel-iterations/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(L["elapsed"] / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "iterations_per_step": its, "weight": WEIGHT, "pweight": PWEIGHT,
+                       "parallelism": L["parallelism"], "engine": best, "band_threads_host_cpu_s": L.get("host_cpu_s")},
+            "roofline": roofline_object(value, gpus_used, its, L["elapsed"], a.steps, band_px, per_kernel, L["samples"], a.timing_every),
+            "other_configs": others,
+        }
+        state["out"] = out
+
+    finish(strict=False)
+    if want_rccl:
+        def bark():
+            # the RCCL leg hung or a rank failed inside it: rank 0 reports what the first leg measured
+            if rank == 0:
+                if state["out"] is not None:
+                    state["out"]["other_configs"].append({"config": "engine rccl", "error": f"no result within {RCCL_LEG_TIMEOUT_S} s"})
+                emit()
+            os._exit(0 if (rank != 0 or state["printed"]) else 1)
+        watchdog = threading.Timer(RCCL_LEG_TIMEOUT_S, bark)
+        watchdog.daemon = True
+        watchdog.start()
+        err = ""
+        try:
+            from jpeg2png_amd import tiled as tiledmod
+            dist = ranks.dist
+            if dist is None:
+                import torch.distributed as dist
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29541")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+                ranks.dist = dist
+            r0, r1 = rank * rows_per_gpu, (rank + 1) * rows_per_gpu
+            bp = my_bands[rank]
+            bp = synth.Plane(bp.w, H, 1, 1, bp.data, bp.quant_table)   # planes describe the whole image; arrays are band-local
+            if n_gpus == 1:                                             # --force-tiled on one GPU: one band, its own neighbour
+                bp = synth.Plane(bp.w, rows_per_gpu, 1, 1, bp.data, bp.quant_table)
+                r0, r1 = 0, rows_per_gpu
+            engine = tiledmod.HipBandEngine([bp], WEIGHT, [PWEIGHT], its, (r0, r1), local_rank)
+            driver = tiledmod.RowTiledSolver(engine)
+            _flush_c_stdio()
+
+            def reset():
+                engine.reset()
+                driver.start()
+            reset()
+            elapsed, g_ms, p_ms, samples = time_steps(ranks, reset, lambda: driver.iterate(its), engine.solver.sync, a.warmup,
+                                                      a.steps, engine.solver, a.timing_every)
+            # (a single rank solves ONE band of the nband-band canvas the figures below are quoted on)
+            legs["rccl"] = {"elapsed": elapsed * (nband if n_gpus == 1 else 1), "g_ms": g_ms, "p_ms": p_ms, "samples": samples,
+                            "split": bool(driver.overlap),
+                            "parallelism": (f"row-tiled x{n_gpus}, one process per GPU, RCCL halo send/recv + norm all-gather "
+                                            f"({'librccl called on the solver streams' if driver.direct is not None else 'through torch.distributed'})")}
+            driver.close()
+            engine.close()
+        except Exception as e:          # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+            legs["rccl_error"] = err
+            print(f"bench: rank {rank}: RCCL harness failed: {err}", file=sys.stderr, flush=True)
+        ranks.barrier()                 # a rank that failed alone leaves the others in a collective: the watchdog ends that
+        watchdog.cancel()
+    finish()
+
+    # ---- the same canvas on ONE GPU, configs[4] over all GPUs, the CPU baseline (rank 0) ----
+    if rank == 0 and state["out"] is not None and not a.no_other_configs:
+        extra = []
+        try:
+            j.load_library().j2p_pool_trim()
+            r = whole_canvas_on_one_gpu(j, whole_plane, its, device=local_rank)
+            r["config"] = (f"strong-scaling denominator: the SAME {W}x{H} canvas solved whole on ONE GPU, -i {its} "
+                           "(value / this = speed-up of the tiling)")
+            r["speedup_of_the_tiled_run"] = round(state["out"]["value"] / r["Mpx_it_per_s"], 3)
+            extra.append(r)
+        except Exception as e:          # noqa: BLE001
+            extra.append({"config": "strong-scaling denominator", "error": f"{type(e).__name__}: {e}"})
+        try:
+            devs = list(range(n_gpus)) if n_gpus > 1 and not one_device else [local_rank]
+            r = batch_images_per_s(j, synth, devs, 256 if not a.size else 16, a.slots)
+            r["config"] = (f"configs[4]: {r['images']} x 1080p 4:2:0 Q50 -i 100 joint through j2p_batch over {len(devs)} GPU(s) "
+                           "(host coefficient buffers in, RGB out: PCIe inclusive)")
+            extra.append(r)
+        except Exception as e:          # noqa: BLE001
+            extra.append({"config": "configs[4] batch", "error": f"{type(e).__name__}: {e}"})
+        state["out"]["other_configs"] += extra
+    if rank == 0 and state["out"] is not None and not a.no_cpu_baseline:
+        state["out"]["cpu_baseline"], state["out"]["cpu_baseline_all_cores"] = cpu_baseline(W, seed)
+    ranks.barrier()
+    if rank == 0:
+        emit()
+    ranks.close()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     one_device = bool(os.environ.get("J2P_BENCH_ONE_DEVICE"))
-    if one_device:                                  # debugging on a 1-GPU box: every rank on the same device
+    if one_device:                                  # rehearsal on a 1-GPU box: every rank on the same device
         local_rank = int(os.environ["J2P_BENCH_ONE_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = a.gpus
-    if world != n_gpus:
-        if world == 1 and n_gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        n_gpus = world
+    if world != a.gpus and world == 1 and a.gpus > 1:
+        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
 
     import torch
     import jpeg2png_amd as j
@@ -260,215 +677,10 @@ def main():
         if rank == 0:
             bench_batch(a, j, synth)
         return
-
-    tiled_mode = n_gpus > 1 or a.force_tiled
-    c_tiled = tiled_mode and a.tiled_impl == "c"
-    driver = None
-    dist = None
-    if n_gpus > 1:
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29541")
-            if one_device:
-                # debugging the multi-rank control flow on a 1-GPU box: RCCL refuses two ranks on one device, gloo does not
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-            else:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if not tiled_mode:
-        W = a.size or 4096
-        H = a.height or W
-        its = a.iterations or 500
-        seed = 1234 + 3
-        workload = f"{W}x{H} Y-only Q10 -i {its} (BASELINE configs[2])"
-        planes = synth.make_planes(W, H, "444", 10, seed=seed, y_only=True)
-        solver = j.Solver(planes, WEIGHT, [PWEIGHT], its, device=local_rank)   # fdata=None: decoded on device
-        if a.norm_fold >= 0:
-            solver.debug_option(j.J2P_OPT_NORM_FOLD, a.norm_fold)
-        if a.norm_in_project >= 0:
-            solver.debug_option(j.J2P_OPT_NORM_IN_PROJECT, a.norm_in_project)
-        del planes
-        reset, solve, sync = solver.reset, (lambda: solver.run(its)), solver.sync
-        eng = solver
-        parallelism = "single GPU"
-        rows_per_gpu = H
-    elif c_tiled:
-        W = a.size or 16384
-        rows_per_gpu = 2048 if not a.size else max(64, a.size // 8 // 16 * 16)
-        nband = n_gpus if n_gpus > 1 else max(2, a.bands or 2)
-        H = rows_per_gpu * nband
-        its = a.iterations or 100
-        seed = 1234 + 4
-        workload = (f"{W}x{H} Y-only Q10 -i {its}, row-tiled {rows_per_gpu} rows/GPU over {n_gpus} GPUs "
-                    f"(BASELINE configs[3] at 8 GPUs)")
-        # every rank synthesises its own band(s); rank 0 collects them through /dev/shm and drives all GPUs
-        tag = f"/dev/shm/j2p_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
-        mine = range(nband) if n_gpus == 1 else [rank]
-        for b in mine:
-            band = synth.make_planes(W, H, "444", 10, seed=seed, y_only=True, rows=(b * rows_per_gpu, (b + 1) * rows_per_gpu))[0]
-            np.save(f"{tag}_{b}.npy", band.data)
-            qt = band.quant_table
-        if dist is not None:
-            dist.barrier()
-        eng = None
-        c_ok = [True, ""]
-        if rank == 0:
-            try:
-                data = np.concatenate([np.load(f"{tag}_{b}.npy") for b in range(nband)])
-                plane = synth.Plane(W, H, 1, 1, data, qt)
-                devices = list(range(n_gpus)) if n_gpus > 1 and not one_device else [local_rank] * nband
-                tsolver = j.TiledSolver([plane], WEIGHT, [PWEIGHT], its, devices=devices)
-                del data, plane
-                eng = tsolver.band_solver(0)
-                reset, solve, sync = tsolver.reset, (lambda: tsolver.run(its)), tsolver.sync
-            except Exception as e:      # noqa: BLE001  (no peer access between the GPUs, a device this process cannot open ...)
-                if dist is None:
-                    raise
-                c_ok = [False, f"{type(e).__name__}: {e}"]
-        else:
-            reset = solve = sync = (lambda: None)
-        if dist is not None:
-            # every rank has to agree on the engine: without peer access fall back to one process per GPU over RCCL
-            dist.broadcast_object_list(c_ok, src=0)
-        for b in mine:
-            try:
-                os.unlink(f"{tag}_{b}.npy")
-            except OSError:
-                pass
-        parallelism = (f"row-tiled x{nband}: C engine (j2p_tiled), one process drives all GPUs, one host thread per band; "
-                       "edge rows and norm row sums read over peer access, ordered by HIP events")
-    fallback_note = ""
-    if c_tiled and not c_ok[0]:
-        c_tiled = False
-        fallback_note = f"; C engine unavailable ({c_ok[1]})"
-        if rank == 0:
-            print(f"bench: C row tiling unavailable, using the RCCL harness: {c_ok[1]}", file=sys.stderr, flush=True)
-    if tiled_mode and not c_tiled:
-        from jpeg2png_amd import tiled
-        if dist is None:
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29541")
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        W = a.size or 16384
-        rows_per_gpu = 2048 if not a.size else max(64, a.size // 8 // 16 * 16)
-        H = rows_per_gpu * n_gpus
-        its = a.iterations or 100
-        seed = 1234 + 4
-        workload = (f"{W}x{H} Y-only Q10 -i {its}, row-tiled {rows_per_gpu} rows/GPU over {n_gpus} GPUs "
-                    f"(BASELINE configs[3] at 8 GPUs)")
-        r0, r1 = rank * rows_per_gpu, (rank + 1) * rows_per_gpu
-        band_planes = synth.make_planes(W, H, "444", 10, seed=seed, y_only=True, rows=(r0, r1))
-        for p in band_planes:
-            p.h = H                       # planes describe the whole image; arrays are band-local
-        engine = tiled.HipBandEngine(band_planes, WEIGHT, [PWEIGHT], its, (r0, r1), local_rank)
-        del band_planes
-        driver = tiled.RowTiledSolver(engine)
-        _flush_c_stdio()
-
-        def reset():
-            engine.reset()
-            driver.start()
-        solve, sync = (lambda: driver.iterate(its)), engine.solver.sync
-        eng = engine.solver
-        reset()
-        parallelism = (f"row-tiled x{n_gpus}, one process per GPU, RCCL halo send/recv + norm all-gather "
-                       f"({'librccl called on the solver streams' if driver.direct is not None else 'through torch.distributed'})"
-                       + fallback_note)
-
-    def barrier():
-        if dist is not None and dist.is_initialized():
-            dist.barrier()
-
-    for _ in range(a.warmup):
-        reset()
-        solve()
-    sync()
-    if eng is not None:
-        eng.enable_timing(a.timing_every)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        reset()
-        solve()
-    sync()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    g_ms, p_ms, samples = eng.kernel_times() if eng is not None else (0.0, 0.0, 0)
-
-    if dist is not None and dist.is_initialized():
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    if rank == 0:
-        px = W * H
-        value = px * its * a.steps / elapsed / 1e6
-        ngp = n_gpus if n_gpus > 1 else 1
-        band_px = W * rows_per_gpu
-        # pixels per TIMED launch: in the row-tiled schedules the events bracket the interior launches only
-        # (all 16-row segments but the band's first and last; all block rows but the first and last)
-        px_of = {"k_gradient": band_px, "k_project": band_px}
-        if tiled_mode and (c_tiled or driver.overlap):
-            px_of = {"k_gradient": W * (rows_per_gpu - 32), "k_project": W * (rows_per_gpu - 16)}
-        per_kernel = {}
-        for kname, kms, kb in (("k_gradient", g_ms, BYTES_GRADIENT), ("k_project", p_ms, BYTES_PROJECT)):
-            gbs = px_of[kname] * kb / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-            per_kernel[kname] = {"avg_launch_ms": round(kms, 4), "algorithmic_bytes_per_launch": px_of[kname] * kb,
-                                 "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
-        kern = min(per_kernel, key=lambda k: per_kernel[k]["frac"])
-        # whole iteration, wall clock, per GPU (bands on one GPU share it)
-        gpus_used = ngp
-        it_gbs = BYTES_ITERATION * value * 1e6 / gpus_used / 1e9
-        it_ms = elapsed / a.steps / its * 1e3
-        # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/, corrected as
-        # MI355X_MICROARCH.md prescribes); only meaningful for the N=1 workload they were taken on
-        traffic, traffic_src = None, None
-        for tag in ("r02", "r01"):
-            pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json")
-            if traffic is None and not tiled_mode and not a.size and os.path.exists(pmc):
-                with open(pmc) as f:
-                    summ = json.load(f)
-                tot = {}
-                for name, v in summ.items():
-                    if isinstance(v, dict) and "hbm_bytes_per_launch" in v:
-                        for kk in ("k_gradient", "k_project"):
-                            if name.startswith("j2p::" + kk) or name.startswith(kk):
-                                tot[kk] = v["hbm_bytes_per_launch"]
-                if len(tot) == 2:
-                    traffic = tot["k_gradient"] + tot["k_project"]
-                    traffic_src = f"profiles/{tag}_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE; k_gradient + k_project)"
-        out = {
-            "metric": "Mpixel-iterations/sec on 4K Y-plane", "value": round(value, 1),
-            "unit": "Mpixel-iterations/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "iterations_per_step": its, "weight": WEIGHT, "pweight": PWEIGHT,
-                       "parallelism": parallelism},
-            "roofline": {"bound": "hbm", "scope": "whole iteration (k_gradient + k_project, launch gaps included), wall clock, per GPU",
-                         "kernel": kern, "achieved": round(it_gbs, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(it_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_unit": "bytes per iteration", "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_iteration": band_px * BYTES_ITERATION,
-                         "iteration_ms": round(it_ms, 5),
-                         "kernel_frac": per_kernel[kern]["frac"],
-                         "per_kernel": per_kernel,
-                         "event_samples": samples,
-                         "note": "per-kernel durations come from HIP events around every "
-                                 f"{a.timing_every}th iteration; the event records themselves cost time on those "
-                                 "iterations, so the two durations can add up to more than iteration_ms"},
-        }
-        if not tiled_mode and not a.no_other_configs and not a.size:
-            eng.close()
-            out["other_configs"] = other_configs(j, synth)
-        if not tiled_mode and not a.no_cpu_baseline:
-            out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(W, seed)
-        _flush_c_stdio()
-        print(json.dumps(out), flush=True)
-    if dist is not None and dist.is_initialized():
-        dist.destroy_process_group()
+    if world > 1 or a.force_tiled:
+        tiled(a, j, synth, rank, world, local_rank, one_device)
+    else:
+        single_gpu(a, j, synth, local_rank)
 
 
 if __name__ == "__main__":

@@ -11,8 +11,10 @@
  * Differences from the reference, on purpose:
  *   -t threads   = number of input files in flight (host threads reading / writing files; each file's GPU work
  *                  is a job of the library's batch engine, j2p_batch_*), instead of an OpenMP thread count;
- *                  default 4
- *   J2P_DEVICE / J2P_DEVICES environment: GPU index, or a comma list to spread files over
+ *                  default: the number of online cores, as OpenMP's default is (jpeg2png.c:246-257, :330)
+ *   J2P_DEVICE / J2P_DEVICES environment: GPU index, or a comma list.  Files are spread over the listed GPUs; with
+ *                  fewer files than GPUs every image is row-tiled over ALL of them instead (one band per GPU when
+ *                  its canvas has at least 48 rows per GPU) — same pixels either way
  * Messages and exit codes follow the reference ("jpeg2png: <message>", EXIT_FAILURE).
  */
 #define _POSIX_C_SOURCE 200809L
@@ -24,6 +26,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <jpeglib.h>
 #include <png.h>
@@ -196,6 +199,7 @@ struct options {
         float weights[3], pweights[3];
         unsigned png_bits;
         bool joint, quiet;
+        bool tile;              /* fewer files than GPUs: every image over all of them */
         FILE *csv;
         int ndev, devs[16];
 };
@@ -274,6 +278,7 @@ static void decode_file(const char *infile, const char *outfile, const struct op
                 job.iterations[c] = o->iterations[c];
         }
         job.separate = !o->joint;
+        job.tile = o->tile;
         job.out_bits = o->png_bits;
         job.out_w = jp.w;
         job.out_h = jp.h;
@@ -332,12 +337,13 @@ static void usage(void)
                "                               DCT-coefficient distance weight (default 0.001)\n"
                "  -i, --iterations N[,Ncb,Ncr] optimisation steps (default 50); three values need -s\n"
                "  -s, --separate-components    optimise Y, Cb, Cr independently (three GPU streams)\n"
-               "  -t, --threads N              input files processed concurrently (default 4)\n"
+               "  -t, --threads N              input files processed concurrently (default: online cores)\n"
                "  -1, --16-bits-png            16-bit PNG\n"
                "  -c, --csv-log FILE           per-iteration objective log\n"
                "  -q, --quiet                  no progress bar\n"
                "  -h, --help    -V, --version\n"
-               "environment: J2P_DEVICE=n or J2P_DEVICES=a,b,... selects the GPU(s)\n");
+               "environment: J2P_DEVICE=n or J2P_DEVICES=a,b,... selects the GPU(s); fewer files than GPUs:\n"
+               "             every image is row-tiled over all of them\n");
         exit(EXIT_FAILURE);
 }
 
@@ -351,7 +357,7 @@ int main(int argc, char **argv)
                 {"iterations", required_argument, NULL, 'i'}, {"probability-weight", required_argument, NULL, 'p'},
                 {"second-order-weight", required_argument, NULL, 'w'}, {NULL, 0, NULL, 0}};
         struct options o = {.iterations = {50, 50, 50}, .weights = {0.3f, 0.f, 0.f}, .pweights = {0.001f, 0.001f, 0.001f},
-                            .png_bits = 8, .joint = true, .quiet = false, .csv = NULL, .ndev = 1, .devs = {0}};
+                            .png_bits = 8, .joint = true, .quiet = false, .tile = false, .csv = NULL, .ndev = 1, .devs = {0}};
         const char *w_arg = NULL, *p_arg = NULL, *i_arg = NULL, *t_arg = NULL, *c_arg = NULL;
         char **outs = calloc((size_t)argc, sizeof(*outs));
         unsigned nout = 0;
@@ -397,7 +403,9 @@ int main(int argc, char **argv)
                 else if(n == 1) { o.iterations[1] = o.iterations[2] = o.iterations[0]; }
                 else { die("invalid number of iterations"); }
         }
-        unsigned threads = 4;
+        /* the reference leaves the thread count to OpenMP, i.e. one per online core (jpeg2png.c:246-257) */
+        long cores = sysconf(_SC_NPROCESSORS_ONLN);
+        unsigned threads = cores > 0 ? (unsigned)cores : 1u;
         if(t_arg) {
                 if(sscanf(t_arg, "%u", &threads) != 1 || threads == 0) { die("invalid number of threads"); }
         }
@@ -460,7 +468,10 @@ int main(int argc, char **argv)
         struct work w = {.nin = nin, .next = 0, .in = ins, .out = outfiles, .o = &o};
         pthread_mutex_init(&w.lock, NULL);
         if(threads > nin) { threads = nin; }
-        /* as many GPU slots as files in flight, spread over the devices of J2P_DEVICES */
+        /* as many GPU slots as files in flight, spread over the devices of J2P_DEVICES; with fewer files than GPUs
+         * the library tiles every image over all of them (decode_file -> compute of one large image,
+         * jpeg2png.c:141-152) */
+        o.tile = o.ndev > 1 && nin < (unsigned)o.ndev;
         batch_ndev = (unsigned)o.ndev;
         memcpy(batch_devs, o.devs, sizeof(batch_devs));
         batch_slots = (threads + batch_ndev - 1) / batch_ndev;

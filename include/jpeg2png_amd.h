@@ -89,21 +89,25 @@ void j2p_solver_destroy(j2p_solver *s);
 
 /* Device memory of destroyed solvers is cached per process and handed to the next solver on the same device
  * (hipMalloc / hipFree cost milliseconds and hipFree stalls every stream of the device, which matters when the
- * host calls compute() from several threads, jpeg2png.c:147,330).  j2p_pool_trim() releases the cache. */
+ * host calls compute() from several threads, jpeg2png.c:147,330).  Bounded PER DEVICE: 16 blocks and 8 GiB
+ * (environment J2P_POOL_MIB = another limit in MiB, 0 = cache nothing); any device allocation of the library
+ * that runs out of memory drops the cache and retries.  j2p_pool_trim() releases the cache; j2p_batch_destroy()
+ * and j2p_tiled_destroy() call it. */
 void j2p_pool_trim(void);
 
 /* diagnostics: schedule switches that change speed, never results (A/B timing and the parity tests of both
  * schedules).  Only between iterations. */
-#define J2P_OPT_NORM_FOLD     1   /* 1 (default for band solvers): ||g|| is reduced inside the gradient kernel by its
-                                     last-arriving wavefronts; 0 (default for whole-canvas solvers): separate
-                                     reduction kernels — same bits, and on a whole canvas the same speed */
+#define J2P_OPT_NORM_FOLD     1   /* 1 (default for band solvers and for whole canvases up to 2.5 Mpixel): level 1 of the
+                                     ||g|| reduction runs inside the gradient kernel (its last-arriving wavefronts);
+                                     0 (default for larger whole canvases): separate reduction kernel — same bits */
 #define J2P_OPT_JOINT_INWAVE  2   /* 1: all channels of a joint image in one wavefront; 0 (default): one wavefront
                                      per channel.  Environment J2P_JOINT_INWAVE sets the default at create time */
 #define J2P_OPT_NORM_IN_PROJECT 4 /* 1 (needs NORM_FOLD): the gradient kernel leaves per-tile-row sums and every wavefront of
                                      the projection kernel runs the final tree itself: no reduction launch in between */
 #define J2P_OPT_NT_GRADIENT 5     /* 0..3: which streams are accessed non-temporally (1: the gradient plane, 2: + the prob
-                                     state, 3: + the coefficients); default: by the size of the solver's working set
-                                     against the Infinity Cache (256 MiB) */
+                                     state, 3: + the coefficients); negative = default: by the working sets of ALL
+                                     solvers live on the device against its Infinity Cache (256 MiB), re-evaluated at
+                                     create and reset (environment J2P_NT_SCOPE=solver: this solver's own only) */
 #define J2P_OPT_MIXED_PROJECT 6   /* 1 (default): canvases up to 1 Mpixel project all channels in ONE launch whatever their
                                      sampling; 0: one launch per sampling class, as large canvases do */
 int j2p_solver_debug_option(j2p_solver *s, int option, int value);
@@ -187,7 +191,11 @@ int j2p_solver_exchange_info(j2p_solver *s, j2p_exchange *info);
  *   halo_rows         : the send/recv row addresses of j2p_exchange for x buffer 0 or 1 — the iterate produced by
  *                       iteration k (0-based) lives in buffer (k + 1) & 1 — independent of the solver's state
  *   norm_from_bands   : between the two phases: ||g|| from every band's level-1 sums (partials_local), read in
- *                       place; replaces the all-gather into partials_all
+ *                       place; replaces the all-gather into partials_all.  nout == 0: the result is this solver's
+ *                       norm; nout > 0: it is stored into every norm_out[i] (j2p_solver_norm_ptr() of the bands,
+ *                       this solver's included) — ONE band reduces for all, the others call norm_external
+ *   norm_external     : between the two phases: another band's norm_from_bands has stored (or will have stored, by
+ *                       the time the solver's stream gets there — the caller orders the streams) this solver's norm
  *   alternate_rowsums : band solvers: from now on iteration k leaves its level-1 sums in buffers[k & 1] (returned;
  *                       buffers[0] is partials_local), so that a band may start its next gradient phase while
  *                       slower bands are still reading this iteration's sums
@@ -196,13 +204,19 @@ int j2p_solver_stream(j2p_solver *s, void **stream);
 int j2p_solver_halo_rows(j2p_solver *s, int buffer, j2p_exchange *info);
 int j2p_solver_alternate_rowsums(j2p_solver *s, const double *buffers[2]);
 int j2p_solver_norm_from_bands(j2p_solver *s, unsigned nband, const double *const rowsums[],
-                               const unsigned first_tile_row[], const unsigned tile_rows[]);
+                               const unsigned first_tile_row[], const unsigned tile_rows[],
+                               unsigned nout, float *const norm_out[]);
+int j2p_solver_norm_ptr(j2p_solver *s, float **norm);              /* device address of the solver's [channel] norms */
+int j2p_solver_norm_external(j2p_solver *s);
 int j2p_solver_copy_rows(j2p_solver *s, unsigned n, float *const dst[], const float *const src[], size_t floats);
 
 /* One plane set row-tiled over several GPUs from one process: nband solvers, band i on devices[i] (ids may
  * repeat), one host thread per band.  cuts = nband + 1 row boundaries from 0 to the canvas height, aligned to
  * lcm(16, 8 * h_samp), or NULL for near-equal bands.  run / sync / download mirror the j2p_solver calls; the
- * planes are bit-identical to a whole-canvas solver's whatever the cut.  (Reference loop: compute.c:427-453.) */
+ * planes are bit-identical to a whole-canvas solver's whatever the cut.  (Reference loop: compute.c:427-453.)
+ * nband == 1 is a plain whole-canvas solver behind the same calls.  Per iteration one band reduces ||g|| for all
+ * (environment J2P_TILED_NORM=all: every band for itself).  host_cpu_seconds: user + system time the band
+ * threads have spent issuing work so far. */
 typedef struct j2p_tiled j2p_tiled;
 int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const unsigned cuts[], unsigned nchannel,
                      const j2p_plane planes[], float weight, const float pweight[], unsigned iterations);
@@ -213,6 +227,7 @@ int j2p_tiled_reset(j2p_tiled *t);                                 /* back to it
 int j2p_tiled_run(j2p_tiled *t, unsigned n, j2p_log_row *rows);   /* asynchronous unless rows != NULL */
 int j2p_tiled_sync(j2p_tiled *t);
 int j2p_tiled_download(j2p_tiled *t, unsigned c, float *out);      /* W * H floats */
+int j2p_tiled_host_cpu_seconds(const j2p_tiled *t, double *seconds);
 
 /* CSV logging for band solvers (the "+3 doubles when logging" of the norm exchange): with logging on, the
  * phase calls also leave the band's tv / tv2 / prob sums in j2p_exchange.log_local; the caller adds the bands'
@@ -264,6 +279,11 @@ typedef struct j2p_plane_ref {
         unsigned channel;
 } j2p_plane_ref;
 int j2p_planes_to_rgb(const j2p_plane_ref planes[3], unsigned w, unsigned h, unsigned bits, uint8_t *out_host);
+/* the same for image rows [row_begin, row_end) that three solvers on one device all hold — whole-canvas or band
+ * solvers (the bands of a row-tiled image convert their own rows on their own GPU); out_host receives
+ * (row_end - row_begin) * w * 3 (or 6) bytes */
+int j2p_planes_rows_to_rgb(const j2p_plane_ref planes[3], unsigned w, unsigned row_begin, unsigned row_end, unsigned bits,
+                           uint8_t *out_host);
 
 /* Image batches (BASELINE configs[4]; the file loop jpeg2png.c:330-337): a batch owns slots_per_device worker
  * threads per GPU, each driving one image at a time on streams of its own, so that the uploads, solves and
@@ -290,6 +310,11 @@ typedef struct j2p_job {
         void (*on_rows)(void *user, unsigned channel, unsigned first, unsigned n, const j2p_log_row *rows);
         void (*on_progress)(void *user, unsigned n);
         void *user;
+        /* nonzero: ONE image over ALL the batch's devices — every solve of the job is row-tiled (j2p_tiled) with one
+         * band per device when the canvas has at least 48 rows per device, each band converting its own rows to
+         * RGB; for the case of fewer images than GPUs (decode_file -> compute of one large image,
+         * jpeg2png.c:141-152).  Same bits either way */
+        int tile;
 } j2p_job;
 int j2p_batch_create(j2p_batch **out, unsigned ndev, const int devices[], unsigned slots_per_device);
 void j2p_batch_destroy(j2p_batch *b);                       /* finishes queued jobs first */

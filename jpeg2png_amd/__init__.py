@@ -53,7 +53,7 @@ class _CJob(ctypes.Structure):
                 ("weight", ctypes.c_float * 3), ("pweight", ctypes.c_float * 3), ("iterations", ctypes.c_uint * 3),
                 ("out_bits", ctypes.c_uint), ("out_w", ctypes.c_uint), ("out_h", ctypes.c_uint),
                 ("out_rgb", ctypes.c_void_p), ("out_planes", ctypes.c_void_p * 3),
-                ("on_rows", _ROWS_CB), ("on_progress", _PROGRESS_CB), ("user", ctypes.c_void_p)]
+                ("on_rows", _ROWS_CB), ("on_progress", _PROGRESS_CB), ("user", ctypes.c_void_p), ("tile", ctypes.c_int)]
 
 
 class _CExchange(ctypes.Structure):
@@ -74,11 +74,11 @@ C_ABI_SYMBOLS = [
     "j2p_solver_exchange_info", "j2p_solver_commit_initial_halo", "j2p_solver_download",
     "j2p_solver_download_gradient", "j2p_solver_set_logging", "j2p_log_rows_from_sums",
     "j2p_solver_plane_ptr", "j2p_solver_sync", "j2p_solver_kernel_times", "j2p_solver_enable_timing",
-    "j2p_decode_plane", "j2p_dct8x8_blocks", "j2p_math_selftest", "j2p_planes_to_rgb", "j2p_sqrt_exhaustive",
+    "j2p_decode_plane", "j2p_dct8x8_blocks", "j2p_math_selftest", "j2p_planes_to_rgb", "j2p_planes_rows_to_rgb", "j2p_sqrt_exhaustive",
     "j2p_pool_trim", "j2p_solver_debug_option", "j2p_solver_stream", "j2p_solver_halo_rows",
     "j2p_solver_norm_from_bands", "j2p_solver_copy_rows", "j2p_solver_alternate_rowsums",
     "j2p_tiled_create", "j2p_tiled_destroy", "j2p_tiled_canvas", "j2p_tiled_band", "j2p_tiled_run", "j2p_tiled_reset", "j2p_tiled_sync",
-    "j2p_tiled_download",
+    "j2p_tiled_download", "j2p_tiled_host_cpu_seconds", "j2p_solver_norm_ptr", "j2p_solver_norm_external",
     "j2p_batch_create", "j2p_batch_destroy", "j2p_batch_submit", "j2p_batch_wait",
     "compute", "j2p_compute", "j2p_compute_tiled",
     "j2p_debug_build", "j2p_solver_debug_violations",
@@ -185,6 +185,7 @@ def load_library():
     lib.j2p_tiled_sync.argtypes = [ctypes.c_void_p]
     lib.j2p_tiled_reset.argtypes = [ctypes.c_void_p]
     lib.j2p_tiled_download.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p]
+    lib.j2p_tiled_host_cpu_seconds.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
     lib.j2p_batch_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint, ctypes.POINTER(ctypes.c_int), ctypes.c_uint]
     lib.j2p_batch_destroy.argtypes = [ctypes.c_void_p]
     lib.j2p_batch_destroy.restype = None
@@ -427,6 +428,12 @@ class TiledSolver:
     def reset(self):
         _check(self._lib.j2p_tiled_reset(self._h))
 
+    def host_cpu_seconds(self):
+        """user + system time the band threads have spent issuing work (they sleep while waiting for each other)"""
+        v = ctypes.c_double()
+        _check(self._lib.j2p_tiled_host_cpu_seconds(self._h, ctypes.byref(v)))
+        return v.value
+
     def band_solver(self, b):
         """borrowed handle of band b's j2p_solver (kernel timing in bench.py); owned by the TiledSolver"""
         h = ctypes.c_void_p()
@@ -470,10 +477,12 @@ class Batch:
         self._h = h
         self._pending = {}
 
-    def submit(self, planes, weight, pweight, iterations, separate=False, width=None, height=None, bits=0):
+    def submit(self, planes, weight, pweight, iterations, separate=False, width=None, height=None, bits=0, tile=False):
+        """tile=True: the image is row-tiled over ALL the batch's devices instead of solved on one of them"""
         n = len(planes)
         job = _CJob()
         job.nchannel = n
+        job.tile = 1 if tile else 0
         cpl, keep = _c_planes(planes)
         for c in range(n):
             job.planes[c] = cpl[c]

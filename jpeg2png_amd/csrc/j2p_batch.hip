@@ -35,6 +35,7 @@ struct Job {
 }  // namespace
 
 struct j2p_batch {
+        std::vector<int> devices;           // as given to j2p_batch_create
         std::vector<int> worker_device;
         std::vector<std::thread> workers;
         std::mutex lock;
@@ -54,6 +55,105 @@ constexpr unsigned kChunk = 32;         // iterations per round trip when a job 
                 rc = (expr);                                                                       \
                 if(rc != J2P_OK) { goto out; }                                                     \
         } while(0)
+
+unsigned gcd_u(unsigned a, unsigned b) { return b ? gcd_u(b, a % b) : a; }
+
+// One image over all the batch's devices (j2p_job::tile): every solve of the job becomes a j2p_tiled with band b on
+// devices[b]; the solves of `-s` share their cuts so that band b of the three components meets on one GPU for the
+// colour conversion.  Returns J2P_OK with *handled = false when the canvas is too short to tile (the caller then
+// takes the single-solver path).
+int run_job_tiled(const j2p_job &d, const std::vector<int> &devices, bool *handled)
+{
+        *handled = false;
+        const unsigned nsolve = d.separate ? d.nchannel : 1;
+        unsigned H[J2P_MAX_CHANNELS] = {0, 0, 0}, align = J2P_TILE_ROWS, hmin = ~0u;
+        for(unsigned c = 0; c < d.nchannel; c++) {
+                const j2p_plane &p = d.planes[c];
+                if(p.h_samp == 0 || p.h == 0) { return j2p_fail(J2P_EINVAL, "job: channel %u: empty plane", c); }
+                align = align / gcd_u(align, 8 * p.h_samp) * (8 * p.h_samp);
+                const unsigned k = d.separate ? c : 0;
+                if(p.h * p.h_samp > H[k]) { H[k] = p.h * p.h_samp; }
+        }
+        for(unsigned k = 0; k < nsolve; k++) { if(H[k] < hmin) { hmin = H[k]; } }
+        // at least three 16-row gradient segments per band (an interior to hide the halo exchange behind)
+        unsigned per = 3 * J2P_TILE_ROWS;
+        per = (per + align - 1) / align * align;
+        unsigned nband = hmin / per;
+        if(nband > devices.size()) { nband = (unsigned)devices.size(); }
+        if(nband > 32) { nband = 32; }
+        if(nband < 2) { return J2P_OK; }
+        *handled = true;
+        // near-equal bands of the shortest canvas in units of the alignment; the last band ends where each canvas ends
+        unsigned cuts[33];
+        {
+                const unsigned units = hmin / align;          // whole units; the remainder goes to the last band
+                unsigned start = 0;
+                for(unsigned b = 0; b < nband; b++) {
+                        cuts[b] = start * align;
+                        start += units / nband + (b < units % nband ? 1 : 0);
+                }
+        }
+        j2p_tiled *t[J2P_MAX_CHANNELS] = {nullptr, nullptr, nullptr};
+        unsigned its[J2P_MAX_CHANNELS] = {0, 0, 0}, done[J2P_MAX_CHANNELS] = {0, 0, 0};
+        int rc = J2P_OK;
+        const bool chunked = d.on_rows || d.on_progress;
+        for(unsigned k = 0; k < nsolve; k++) {
+                cuts[nband] = H[k];
+                its[k] = d.iterations[k];
+                if(d.separate) {
+                        JOB_TRY(j2p_tiled_create(&t[k], nband, devices.data(), cuts, 1, &d.planes[k], d.weight[k], &d.pweight[k], its[k]));
+                } else {
+                        JOB_TRY(j2p_tiled_create(&t[k], nband, devices.data(), cuts, d.nchannel, d.planes, d.weight[0], d.pweight, its[k]));
+                }
+        }
+        if(!chunked) {
+                for(unsigned k = 0; k < nsolve; k++) { JOB_TRY(j2p_tiled_run(t[k], its[k], nullptr)); }
+        } else {
+                j2p_log_row rows[kChunk];
+                for(;;) {
+                        bool any = false;
+                        for(unsigned k = 0; k < nsolve; k++) {
+                                const unsigned left = its[k] - done[k];
+                                const unsigned step = left < kChunk ? left : kChunk;
+                                if(!step) { continue; }
+                                any = true;
+                                JOB_TRY(j2p_tiled_run(t[k], step, d.on_rows ? rows : nullptr));
+                                if(d.on_rows) { d.on_rows(d.user, d.separate ? k : 3u, done[k], step, rows); }
+                                else { JOB_TRY(j2p_tiled_sync(t[k])); }
+                                if(d.on_progress) { d.on_progress(d.user, step); }
+                                done[k] += step;
+                        }
+                        if(!any) { break; }
+                }
+        }
+        if(d.out_bits) {
+                const size_t row_bytes = (size_t)d.out_w * (d.out_bits == 8 ? 3 : 6);
+                for(unsigned b = 0; b < nband; b++) {
+                        const unsigned y0 = cuts[b];
+                        unsigned y1 = b + 1 < nband ? cuts[b + 1] : d.out_h;
+                        if(y1 > d.out_h) { y1 = d.out_h; }
+                        if(y0 >= y1) { continue; }                       // band below the image (canvas padding only)
+                        j2p_plane_ref ref[3];
+                        for(unsigned c = 0; c < 3; c++) {
+                                j2p_solver *bs = nullptr;
+                                JOB_TRY(j2p_tiled_band(d.separate ? t[c] : t[0], b, nullptr, nullptr, nullptr, &bs));
+                                ref[c].solver = bs;
+                                ref[c].channel = d.separate ? 0 : c;
+                        }
+                        JOB_TRY(j2p_planes_rows_to_rgb(ref, d.out_w, y0, y1, d.out_bits, d.out_rgb + (size_t)y0 * row_bytes));
+                }
+        } else {
+                for(unsigned c = 0; c < d.nchannel; c++) {
+                        if(!d.out_planes[c]) { continue; }
+                        JOB_TRY(j2p_tiled_download(d.separate ? t[c] : t[0], d.separate ? 0 : c, d.out_planes[c]));
+                }
+        }
+out:
+        for(unsigned k = 0; k < J2P_MAX_CHANNELS; k++) {
+                if(t[k]) { j2p_tiled_destroy(t[k]); }
+        }
+        return rc;
+}
 
 int run_job(const j2p_job &d, int device)
 {
@@ -127,6 +227,9 @@ out:
 
 void worker_main(j2p_batch *b, int device)
 {
+        // the distinct devices of the batch, in the order given (a tiled job puts one band on each)
+        std::vector<int> distinct_or_all = b->devices;
+
         (void)hipSetDevice(device);
         for(;;) {
                 Job *job = nullptr;
@@ -137,7 +240,10 @@ void worker_main(j2p_batch *b, int device)
                         job = b->queue.front();
                         b->queue.pop_front();
                 }
-                const int rc = run_job(job->desc, device);
+                int rc = J2P_OK;
+                bool tiled = false;
+                if(job->desc.tile && distinct_or_all.size() > 1) { rc = run_job_tiled(job->desc, distinct_or_all, &tiled); }
+                if(rc == J2P_OK && !tiled) { rc = run_job(job->desc, device); }
                 {
                         std::lock_guard<std::mutex> g(b->lock);
                         job->rc = rc;
@@ -168,6 +274,7 @@ int j2p_batch_create(j2p_batch **out, unsigned ndev, const int devices[], unsign
         }
         j2p_batch *b = new(std::nothrow) j2p_batch();
         if(!b) { return j2p_fail(J2P_ENOMEM, "host allocation failed"); }
+        b->devices.assign(devices, devices + ndev);
         // slot-major order: the first ndev workers sit on different GPUs, so few images spread out first
         for(unsigned k = 0; k < slots_per_device; k++) {
                 for(unsigned i = 0; i < ndev; i++) { b->worker_device.push_back(devices[i]); }
@@ -188,6 +295,7 @@ void j2p_batch_destroy(j2p_batch *b)
         for(std::thread &t : b->workers) { t.join(); }          // queued jobs are finished first
         for(auto &kv : b->jobs) { delete kv.second; }
         delete b;
+        j2p_pool_trim();        // the arenas the images recycled go back to the device with the batch
 }
 
 int j2p_batch_submit(j2p_batch *b, const j2p_job *job, int *ticket)

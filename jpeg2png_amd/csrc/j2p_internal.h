@@ -6,6 +6,8 @@
 int j2p_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
 // log rows from per-iteration sums like j2p_log_rows_from_sums(), but continuing a run: carried[] holds the prob
-// distance per channel of the state entering the first of the n iterations and is updated (all 0 at iteration 0)
+// distance per channel of the state entering the first of the n iterations and is updated (all 0 at iteration 0);
+// !carried_valid: that distance is unknown (the previous iterations ran without logging) and the first row
+// reports NaN for prob_dist and objective, as j2p_solver_run does
 void j2p_rows_from_sums_carry(unsigned nch, float weight, const float *pweight, unsigned n, const double *sums,
-                              double *carried, j2p_log_row *rows);
+                              double *carried, bool carried_valid, j2p_log_row *rows);

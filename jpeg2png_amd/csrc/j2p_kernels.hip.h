@@ -23,6 +23,14 @@
 // ooura/dct.c:39-66,103-130; gather sums run in the reference's raster order.
 //
 // No MFMA anywhere: there is no dense contraction on this path.
+//
+// Timing-only experiment builds (tools/build_variant.py NAME -DJ2P_EXP_...; results are WRONG, never shipped):
+//   J2P_EXP_NOARITH   k_gradient's square roots and quotients replaced by one multiply each: what the loads, the
+//                     FISTA point, the differences, the gather sums and the stores cost on their own
+//   J2P_EXP_NOTRAFFIC every row address of both phase kernels folded into 64 rows of each plane: operands
+//                     cache-resident, the instruction stream unchanged — the compute side on its own
+//   J2P_EXP_NOHALO    k_gradient re-reads its own first / last rows instead of the 2 + 2 halo rows of a strip:
+//                     what the 1.15x over-fetch costs
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -421,6 +429,9 @@ __device__ __forceinline__ v2f sqrt_rsq(v2f x)
 template <bool FAST, bool EXACT_ZERO>
 __device__ __forceinline__ v2f sqrt_pair(v2f x)
 {
+#ifdef J2P_EXP_NOARITH
+        return x * 0.75f + v2f{1.f, 1.f};
+#endif
         if(!FAST) { return v2f{sqrtf(x.x), sqrtf(x.y)}; }
         if(EXACT_ZERO) { return sqrt_fast(x); }
         return sqrt_rsq(x + v2f{0x1p-120f, 0x1p-120f});
@@ -436,6 +447,11 @@ __device__ __forceinline__ v2f divisor_of(v2f n)
 template <bool FAST, int N>
 __device__ __forceinline__ void div_n(const v2f (&x)[N], v2f d, v2f r, v2f (&q)[N])
 {
+#ifdef J2P_EXP_NOARITH
+#pragma unroll
+        for(int i = 0; i < N; i++) { q[i] = x[i] * d; }
+        return;
+#endif
         if(FAST) {
                 div_shared_n<N>(x, d, r, q);
         } else {
@@ -503,7 +519,11 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
                 const v2f d2 = divisor_of<FAST, LOG>(n2);
                 const v2f a2 = FAST ? v2f{a_tgv, a_tgv}
                                     : v2f{n2.x == 0.f ? 0.f : a_tgv, n2.y == 0.f ? 0.f : a_tgv};   // compute.c:158
+#ifdef J2P_EXP_NOARITH
+                const v2f r2 = d2;
+#else
                 const v2f r2 = FAST ? div_prepare(d2) : d2;
+#endif
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
                         if(NCH > 1) { __builtin_amdgcn_sched_barrier(0); }
@@ -672,7 +692,12 @@ __device__ __forceinline__ void publish_double(double *p, double v)
 }
 __device__ __forceinline__ void stores_acknowledged()
 {
-        __builtin_amdgcn_s_waitcnt(0);         // vmcnt(0) expcnt(0) lgkmcnt(0): every store of this wavefront has been acknowledged
+        // vmcnt(0) lgkmcnt(0): every store of this wavefront has been acknowledged.  Inline asm with a memory clobber,
+        // not __builtin_amdgcn_s_waitcnt: the builtin is no barrier for the COMPILER (it may sink a publishing store
+        // below it or hoist the ticket above it), and the pass that drops "redundant" waitcnts does not see inside asm
+        // (MI355X_MICROARCH.md, compiler hazard).  ISA assumption: an sc1 store that has been acknowledged is visible
+        // to every later sc1 load of the device.
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
 // called by a wavefront whose lane 0 has just published `mine` partials of tile row tr (wave-uniform arguments)
@@ -763,8 +788,14 @@ void k_gradient(GradArgs a)
         auto fetch_row = [&](auto free_tag, int lr, v2f (&rc)[NCH], v2f (&rp)[NCH]) {
                 constexpr bool FREE = decltype(free_tag)::value;
                 // rows past the strip's last needed row (t1+1) re-read that row: a cache hit, not HBM traffic
-                const int lm = lr > t1 + 1 ? t1 + 1 : lr;
-                const int lc = FREE ? lm : (lm < lr_lo ? lr_lo : (lm > lr_hi ? lr_hi : lm));
+                int lm = lr > t1 + 1 ? t1 + 1 : lr;
+#ifdef J2P_EXP_NOHALO
+                lm = lm < t0 ? t0 : (lm > t1 - 1 ? t1 - 1 : lm);
+#endif
+                int lc = FREE ? lm : (lm < lr_lo ? lr_lo : (lm > lr_hi ? lr_hi : lm));
+#ifdef J2P_EXP_NOTRAFFIC
+                lc = (lc < 0 ? 0 : lc) & 63;
+#endif
                 // uniform row pointer + loop-invariant 32-bit lane offset: scalar-base addressing, no
                 // 64-bit vector address arithmetic per row
                 const ptrdiff_t roff = (ptrdiff_t)lc * W;
@@ -834,7 +865,11 @@ void k_gradient(GradArgs a)
                         const ChanDev &k = a.ch[cbase + c];
                         // coefficient row of canvas row lt, clamped into the rows this band holds
                         const int ltc = lt > t1 - 1 ? t1 - 1 : lt;                     // past the strip: re-read its last row
+#ifdef J2P_EXP_NOTRAFFIC
+                        const int gt = row0 + ((ltc < 0 ? 0 : ltc) & 63);
+#else
                         const int gt = row0 + (FREE ? ltc : (ltc < 0 ? 0 : ltc));
+#endif
                         if constexpr(decltype(free_tag)::unit) {
                                 const float *prow = k.pg + (size_t)((unsigned)gt - k.crow0) * k.cw;
                                 J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + xoff, 8, 103);
@@ -955,7 +990,11 @@ void k_gradient(GradArgs a)
                                                 g += s.B[c];             // (x,   t+1)
                                         }
                                         if(pair_own) {
+#ifdef J2P_EXP_NOTRAFFIC
+                                                v2f *gdst = reinterpret_cast<v2f *>(reinterpret_cast<char *>(k.grad + (size_t)(t & 63) * W) + (unsigned)xl * 4u);
+#else
                                                 v2f *gdst = reinterpret_cast<v2f *>(reinterpret_cast<char *>(k.grad + (size_t)t * W) + (unsigned)xl * 4u);
+#endif
                                                 J2P_CHK(k, grad, gdst, 8, 106);
                                                 if constexpr(NT >= 1) { __builtin_nontemporal_store(g, gdst); }
                                                 else { *gdst = g; }
@@ -1199,11 +1238,13 @@ struct BandRowsums {
         unsigned first[kMaxBands];         // its first global tile row
         unsigned count[kMaxBands];         // its tile rows
         unsigned nband;
+        float *out[kMaxBands];             // where the norm goes: [channel] words of nout solvers (peers' memory included)
+        unsigned nout;
 };
 
 // level 2 of the norm reduction over the bands' row sums: the same padded pairwise tree as k_norm_finish over the
 // same global array, so the norm — and the result — does not depend on how the canvas was cut.  One block per channel.
-__global__ __launch_bounds__(256) void k_norm_bands(BandRowsums t, unsigned nrows_global, unsigned nch, float *norm)
+__global__ __launch_bounds__(256) void k_norm_bands(BandRowsums t, unsigned nrows_global, unsigned nch)
 {
         extern __shared__ __attribute__((aligned(16))) float smem[];
         double *buf = reinterpret_cast<double *>(smem);
@@ -1217,7 +1258,10 @@ __global__ __launch_bounds__(256) void k_norm_bands(BandRowsums t, unsigned nrow
                 for(unsigned i = threadIdx.x; i < t.count[b]; i += 256) { buf[t.first[b] + i] = src[(size_t)i * nch + c]; }
         }
         const double s = tree_sum_lds(buf, nrows_global, P);
-        if(threadIdx.x == 0) { norm[c] = sqrtf((float)s); }
+        // one band reduces for all: the float goes into every band's own norm word (a store over xGMI for bands on
+        // other GPUs; visible to their projection kernels through the event recorded behind this launch)
+        const float nrm = sqrtf((float)s);
+        if(threadIdx.x < t.nout) { t.out[threadIdx.x][c] = nrm; }
 }
 
 // up to 2 * kMaxCh row blocks copied into this band's halo rows from the neighbours' edge rows
@@ -1449,7 +1493,11 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
         const unsigned cx = sx * 64 + lane;                           // coefficient column of this lane
         const unsigned cy0 = (a.geo.row0 / hs) + by * 8;              // first coefficient row (global)
         const bool covered = cx < k.cw && cy0 < k.ch;                 // block-granular: cw, ch multiples of 8
+#ifdef J2P_EXP_NOTRAFFIC
+        const unsigned ly0 = ((by * 8 * hs) & 63);                   // (timing experiment: every strip works on the same 64 rows)
+#else
         const unsigned ly0 = by * 8 * hs;                             // band-local canvas row
+#endif
         // A full-resolution channel whose coefficient plane is smaller than the canvas (the chroma planes pad
         // further than the luma plane: most 4:2:0 images) still goes through the reference's resampling code
         // with a 1 x 1 footprint (compute.c:348-370, 390-403): the DCT sees 0.f + x and the result is
@@ -1593,7 +1641,11 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
         {
                 int4 raw = make_int4(0, 0, 0, 0);
                 if(bcov) {
+#ifdef J2P_EXP_NOTRAFFIC
+                        const size_t blk = (size_t)((cy0 / 8 - k.crow0 / 8) & 7) * (k.cw / 8) + bx;
+#else
                         const size_t blk = (size_t)(cy0 / 8 - k.crow0 / 8) * (k.cw / 8) + bx;
+#endif
                         J2P_CHK(k, d, k.d + blk * 64 + rr * 8, 16, 211);
                         if constexpr(NT >= 3) {
                                 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -1703,7 +1755,11 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                 transpose8(e, scratch, lane);
                 idct8(e);
                 if(bcov) {
+#ifdef J2P_EXP_NOTRAFFIC
+                        float4 *dst = reinterpret_cast<float4 *>(k.pg + (size_t)(((cy0 - k.crow0) & 63) + rr) * k.cw + bx * 8);
+#else
                         float4 *dst = reinterpret_cast<float4 *>(k.pg + (size_t)(cy0 - k.crow0 + rr) * k.cw + bx * 8);
+#endif
                         J2P_CHK(k, pg, dst, 32, 214);
                         if constexpr(NT >= 2) {
                                 typedef float v4f __attribute__((ext_vector_type(4)));

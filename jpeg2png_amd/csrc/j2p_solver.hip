@@ -98,6 +98,10 @@ struct j2p_solver {
         bool joint_inwave = false;   // J2P_OPT_JOINT_INWAVE
         bool norm_in_project = false;   // J2P_OPT_NORM_IN_PROJECT (with fold): level 2 of the norm inside k_project
         int nt = 0;                     // 0..3: streams with the non-temporal hint (nt_policy; J2P_OPT_NT_GRADIENT)
+        bool nt_forced = false;         // set through J2P_OPT_NT_GRADIENT: the policy no longer touches it
+        bool live_registered = false;   // this solver's bytes are part of the device's live total (nt_policy)
+        size_t live_ws = 0, live_g = 0, live_planes = 0, live_d = 0;
+        bool phase_log = false;         // the gradient phase of the running iteration was issued with logging
         bool mixed_project = true;      // small canvases: all samplings in one projection launch (J2P_OPT_MIXED_PROJECT)
         unsigned long long *dbg_counters = nullptr;   // J2P_DEBUG builds: [0] address violations, [1] first site, [2] first offset
         bool norm_ready = false; // the gradient launch of this iteration also produced norm[]
@@ -162,8 +166,44 @@ struct PoolBlock {
 };
 std::mutex g_pool_lock;
 std::vector<PoolBlock> g_pool;
-constexpr size_t kPoolBlocks = 32;
-constexpr size_t kPoolBytes = (size_t)24 << 30;
+constexpr size_t kPoolBlocks = 16;                     // per device
+constexpr size_t kPoolBytesDefault = (size_t)8 << 30;  // per device; J2P_POOL_MIB overrides (0 = no caching)
+
+size_t pool_cap_bytes()
+{
+        static const size_t cap = [] {
+                const char *env = getenv("J2P_POOL_MIB");
+                if(env && *env) { return (size_t)strtoull(env, nullptr, 10) << 20; }
+                return kPoolBytesDefault;
+        }();
+        return cap;
+}
+
+void pool_drop_all()
+{
+        std::vector<PoolBlock> drop;
+        {
+                std::lock_guard<std::mutex> g(g_pool_lock);
+                drop.swap(g_pool);
+        }
+        for(const PoolBlock &b : drop) {
+                DeviceGuard guard(b.device);
+                (void)hipFree(b.ptr);
+        }
+}
+
+// hipMalloc for everything that does not go through the pool (log buffers, the stand-alone decode / DCT calls):
+// on out-of-memory the cached arenas go back to the device and the allocation is tried once more
+hipError_t dev_malloc(void **out, size_t bytes)
+{
+        hipError_t e = hipMalloc(out, bytes);
+        if(e == hipErrorOutOfMemory) {
+                (void)hipGetLastError();
+                pool_drop_all();
+                e = hipMalloc(out, bytes);
+        }
+        return e;
+}
 
 hipError_t pool_take(int device, size_t bytes, void **out, size_t *got)
 {
@@ -183,23 +223,8 @@ hipError_t pool_take(int device, size_t bytes, void **out, size_t *got)
                         return hipSuccess;
                 }
         }
-        hipError_t e = hipMalloc(out, bytes);
-        if(e == hipErrorOutOfMemory) {
-                // give the cache back to the device and try once more
-                std::vector<PoolBlock> drop;
-                {
-                        std::lock_guard<std::mutex> g(g_pool_lock);
-                        drop.swap(g_pool);
-                }
-                for(const PoolBlock &b : drop) {
-                        DeviceGuard guard(b.device);
-                        (void)hipFree(b.ptr);
-                }
-                (void)hipGetLastError();
-                e = hipMalloc(out, bytes);
-        }
         *got = bytes;
-        return e;
+        return dev_malloc(out, bytes);
 }
 
 void pool_give(int device, void *ptr, size_t bytes)
@@ -207,14 +232,42 @@ void pool_give(int device, void *ptr, size_t bytes)
         if(!ptr) { return; }
         {
                 std::lock_guard<std::mutex> g(g_pool_lock);
-                size_t total = bytes;
-                for(const PoolBlock &b : g_pool) { total += b.bytes; }
-                if(g_pool.size() < kPoolBlocks && total <= kPoolBytes) {
+                size_t total = bytes, blocks = 0;
+                for(const PoolBlock &b : g_pool) {
+                        if(b.device == device) { total += b.bytes; blocks++; }
+                }
+                if(blocks < kPoolBlocks && total <= pool_cap_bytes()) {
                         g_pool.push_back(PoolBlock{device, ptr, bytes});
                         return;
                 }
         }
         (void)hipFree(ptr);
+}
+
+// ---------------------------------------------------------------------------
+// What is live on each device, for the non-temporal policy (nt_policy): the Infinity Cache is shared by every
+// solver iterating on the GPU — the images of a batch, the components of `-s`, the bands of a tiled run that
+// share a device — so the policy looks at the sum of their working sets, not at one solver's.
+// ---------------------------------------------------------------------------
+struct LiveBytes {
+        size_t working_set = 0, g = 0, planes = 0, d = 0;
+};
+constexpr int kMaxDevices = 64;
+LiveBytes g_live[kMaxDevices];          // guarded by g_pool_lock
+
+void live_add(int device, const LiveBytes &b, int sign)
+{
+        if(device < 0 || device >= kMaxDevices) { return; }
+        std::lock_guard<std::mutex> g(g_pool_lock);
+        LiveBytes &l = g_live[device];
+        if(sign > 0) { l.working_set += b.working_set; l.g += b.g; l.planes += b.planes; l.d += b.d; }
+        else { l.working_set -= b.working_set; l.g -= b.g; l.planes -= b.planes; l.d -= b.d; }
+}
+LiveBytes live_on(int device)
+{
+        if(device < 0 || device >= kMaxDevices) { return LiveBytes{}; }
+        std::lock_guard<std::mutex> g(g_pool_lock);
+        return g_live[device];
 }
 
 // bump allocator over the arena: pass 1 (base == nullptr) only adds the sizes up
@@ -236,6 +289,30 @@ constexpr size_t kMixedProjectPixels = (size_t)1 << 20;  // canvases up to this 
 
 unsigned gcd_u(unsigned a, unsigned b) { return b ? gcd_u(b, a % b) : a; }
 unsigned lcm_u(unsigned a, unsigned b) { return a / gcd_u(a, b) * b; }
+
+// nt_policy: which streams of the iteration get the non-temporal hint, so that what stays without it can live in
+// the 256 MiB Infinity Cache.  Per byte and iteration x_k and x_{k-1} are touched 2-3 times, g and the prob state
+// twice, d once: keep the planes, then d and the prob state if they fit beside them, g last.
+// Measured on single Y planes (us per iteration; none / level 1 / level 2 / level 3):
+//   4096x3584 (252 MiB) 112.3 / 114.1            4096x4096 (288 MiB) 135.8 / 127.0
+//   4096x5120 (360 MiB) 175.0 / 163.7 / 159.6 / 163.4
+//   16384x2048 (576 MiB) 295 / 292.7 / 250.8 / 240.2     8192x8192 (1152 MiB) - / 541.5 / 528.3 / 527.0
+// The cache is the DEVICE's: the sums run over every live solver of the device (the images of a batch, the
+// components of `-s`, bands sharing a GPU), re-evaluated at create and at reset.  J2P_NT_SCOPE=solver: this
+// solver's own bytes only (round 2's policy; A/B).
+int nt_policy(const j2p_solver *s)
+{
+        static const bool own_only = [] {
+                const char *env = getenv("J2P_NT_SCOPE");
+                return env && strcmp(env, "solver") == 0;
+        }();
+        LiveBytes l = live_on(s->device);
+        if(own_only || !s->live_registered) { l = LiveBytes{s->live_ws, s->live_g, s->live_planes, s->live_d}; }
+        if(l.working_set <= kNtWorkingSet) { return 0; }                        // everything fits
+        if(l.working_set - l.g <= kNtWorkingSet) { return 1; }                  // everything but g fits
+        if(l.planes + l.d <= kNtWorkingSet) { return 2; }                       // planes and d fit
+        return 3;
+}
 
 ChanDev chan_dev(const j2p_solver *s, unsigned c)
 {
@@ -388,6 +465,7 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         if(part != 0 && s->nseg < 3) { return fail(J2P_ESTATE, "band too short to split the gradient phase"); }
         if(!st) { st = s->stream; }
         if(part != 2) {
+                s->phase_log = log;
                 // FISTA scalars in float, as compute.c:431-432,440
                 const float tnext = (1 + sqrtf(1 + 4 * (s->t * s->t))) / 2;
                 s->factor = (s->t - 1) / tnext;
@@ -485,6 +563,8 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
 {
         if(!s->grad_done) { return fail(J2P_ESTATE, "phase_project called before phase_gradient"); }
         if(s->rowsums_pending) { return fail(J2P_ESTATE, "phase_project before j2p_solver_phase_rowsums"); }
+        // the two phases of an iteration must agree on logging: where the norm is reduced depends on it
+        if(log != s->phase_log) { return fail(J2P_ESTATE, "phase_project: logging differs from this iteration's gradient phase"); }
         if(part == 2 && !s->proj_boundary_done) { return fail(J2P_ESTATE, "interior part of phase_project before the boundary part"); }
         if(part != 2 && s->proj_boundary_done) { return fail(J2P_ESTATE, "boundary part of phase_project issued twice"); }
         unsigned P = 1;
@@ -654,6 +734,7 @@ void j2p_solver_destroy(j2p_solver *s)
         if(!s) { return; }
         DeviceGuard guard(s->device);
         if(s->stream) { (void)hipStreamSynchronize(s->stream); }
+        if(s->live_registered) { live_add(s->device, LiveBytes{s->live_ws, s->live_g, s->live_planes, s->live_d}, -1); }
         pool_give(s->device, s->arena, s->arena_bytes);
         (void)hipFree(s->logsums);
         (void)hipFree(s->log_band);
@@ -662,18 +743,7 @@ void j2p_solver_destroy(j2p_solver *s)
         delete s;
 }
 
-void j2p_pool_trim(void)
-{
-        std::vector<PoolBlock> drop;
-        {
-                std::lock_guard<std::mutex> g(g_pool_lock);
-                drop.swap(g_pool);
-        }
-        for(const PoolBlock &b : drop) {
-                DeviceGuard guard(b.device);
-                (void)hipFree(b.ptr);
-        }
-}
+void j2p_pool_trim(void) { pool_drop_all(); }
 
 int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchannel, const j2p_plane planes[],
                       float weight, const float pweight[], unsigned iterations, j2p_band band, int band_local_arrays)
@@ -875,27 +945,19 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 carve.take(s->part_prob, (size_t)max_strips * nchannel);
         }
 
-        // ---- nt_policy: which streams of the iteration get the non-temporal hint, so that what stays without it can
-        // live in the 256 MiB Infinity Cache.  Per byte and iteration x_k and x_{k-1} are touched 2-3 times, g and the
-        // prob state twice, d once: keep the planes, then d and the prob state if they fit beside them, g last.
-        // Measured on Y planes (us per iteration; none / level 1 / level 2 / level 3):
-        //   4096x3584 (252 MiB) 112.3 / 114.1            4096x4096 (288 MiB) 135.8 / 127.0
-        //   4096x5120 (360 MiB) 175.0 / 163.7 / 159.6 / 163.4
-        //   16384x2048 (576 MiB) 295 / 292.7 / 250.8 / 240.2     8192x8192 (1152 MiB) - / 541.5 / 528.3 / 527.0
+        // ---- nt_policy (see nt_policy() above): this solver's bytes join the device's live total ----
         {
-                size_t working_set = 0, planes_bytes = 0, d_bytes = 0;
                 for(unsigned c = 0; c < nchannel; c++) {
                         const ChanHost &h = s->ch[c];
                         const size_t cells = (size_t)(h.crows ? h.crows : 1) * h.cw;
-                        working_set += (2 * plane_floats + (size_t)s->rows * W + cells) * sizeof(float) + cells * sizeof(int16_t);
-                        planes_bytes += 2 * plane_floats * sizeof(float);
-                        d_bytes += cells * sizeof(int16_t);
+                        s->live_ws += (2 * plane_floats + (size_t)s->rows * W + cells) * sizeof(float) + cells * sizeof(int16_t);
+                        s->live_planes += 2 * plane_floats * sizeof(float);
+                        s->live_d += cells * sizeof(int16_t);
                 }
-                const size_t g_bytes = (size_t)nchannel * s->rows * W * sizeof(float);
-                if(working_set <= kNtWorkingSet) { s->nt = 0; }                                   // everything fits
-                else if(working_set - g_bytes <= kNtWorkingSet) { s->nt = 1; }                    // everything but g fits
-                else if(planes_bytes + d_bytes <= kNtWorkingSet) { s->nt = 2; }                   // planes and d fit
-                else { s->nt = 3; }
+                s->live_g = (size_t)nchannel * s->rows * W * sizeof(float);
+                live_add(device, LiveBytes{s->live_ws, s->live_g, s->live_planes, s->live_d}, +1);
+                s->live_registered = true;
+                s->nt = nt_policy(s);
         }
 
         // ---- uploads (host arrays: whole-image unless band_local) ----
@@ -982,7 +1044,10 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
                 break;
         case J2P_OPT_JOINT_INWAVE: s->joint_inwave = value != 0; break;
         case J2P_OPT_NORM_IN_PROJECT: s->norm_in_project = value != 0; break;
-        case J2P_OPT_NT_GRADIENT: s->nt = value < 0 ? 0 : (value > 3 ? 3 : value); break;
+        case J2P_OPT_NT_GRADIENT:
+                s->nt_forced = value >= 0;                 // negative: back to the policy
+                s->nt = value < 0 ? nt_policy(s) : (value > 3 ? 3 : value);
+                break;
         case J2P_OPT_MIXED_PROJECT: s->mixed_project = value != 0; break;
         default: return fail(J2P_EINVAL, "unknown option %d", option);
         }
@@ -1039,6 +1104,7 @@ int j2p_solver_reset(j2p_solver *s)
         DeviceGuard guard(s->device);
         int rc = flush_timing(s);
         if(rc != J2P_OK) { return rc; }
+        if(!s->nt_forced) { s->nt = nt_policy(s); }       // other solvers may have come or gone on this device
         return launch_init(s);
 }
 
@@ -1111,9 +1177,9 @@ static void rows_from_sums(unsigned nch, float weight, const float *pweight, uns
 }  // extern "C"
 
 void j2p_rows_from_sums_carry(unsigned nch, float weight, const float *pweight, unsigned n, const double *sums,
-                              double *carried, j2p_log_row *rows)
+                              double *carried, bool carried_valid, j2p_log_row *rows)
 {
-        rows_from_sums(nch, weight, pweight, n, sums, carried, true, rows);
+        rows_from_sums(nch, weight, pweight, n, sums, carried, carried_valid, rows);
 }
 
 extern "C" {
@@ -1136,7 +1202,7 @@ int j2p_solver_set_logging(j2p_solver *s, int on)
         // depends on it)
         if(s->grad_done || s->interior_done) { return fail(J2P_ESTATE, "logging changes between iterations only"); }
         if(on && !s->log_band) {
-                HIP_TRY(hipMalloc(&s->log_band, (2 + kMaxCh) * sizeof(double)));
+                HIP_TRY(dev_malloc((void **)&s->log_band, (2 + kMaxCh) * sizeof(double)));
                 HIP_TRY(hipMemsetAsync(s->log_band, 0, (2 + kMaxCh) * sizeof(double), s->stream));
         }
         s->log_phases = on != 0;
@@ -1154,7 +1220,7 @@ int j2p_solver_run(j2p_solver *s, unsigned n, j2p_log_row *rows)
                 (void)hipFree(s->logsums);
                 s->logsums = nullptr;
                 s->logsums_cap = 0;
-                HIP_TRY(hipMalloc(&s->logsums, (size_t)n * kRow * sizeof(double)));
+                HIP_TRY(dev_malloc((void **)&s->logsums, (size_t)n * kRow * sizeof(double)));
                 s->logsums_cap = n;
         }
         for(unsigned i = 0; i < n; i++) {
@@ -1249,11 +1315,15 @@ int j2p_solver_alternate_rowsums(j2p_solver *s, const double *buffers[2])
 }
 
 int j2p_solver_norm_from_bands(j2p_solver *s, unsigned nband, const double *const rowsums[], const unsigned first_tile_row[],
-                               const unsigned tile_rows[])
+                               const unsigned tile_rows[], unsigned nout, float *const norm_out[])
 {
         if(!s || !rowsums || !first_tile_row || !tile_rows) { return fail(J2P_EINVAL, "NULL argument"); }
         if(nband == 0 || nband > (unsigned)kMaxBands) { return fail(J2P_EINVAL, "1..%d bands", kMaxBands); }
+        if(nout > (unsigned)kMaxBands || (nout && !norm_out)) { return fail(J2P_EINVAL, "norm_from_bands: bad output list"); }
         if(!s->grad_done || s->rowsums_pending) { return fail(J2P_ESTATE, "norm_from_bands needs a finished gradient phase"); }
+        // a whole-canvas solver above kNormInProjectPixels reduces its partials in one kernel and never forms the
+        // level-1 row sums this call reads
+        if(s->whole && !s->fold) { return fail(J2P_ESTATE, "norm_from_bands: this solver leaves no per-tile-row sums (whole canvas, norm folding off)"); }
         DeviceGuard guard(s->device);
         BandRowsums t;
         unsigned covered = 0;
@@ -1266,10 +1336,40 @@ int j2p_solver_norm_from_bands(j2p_solver *s, unsigned nband, const double *cons
         }
         if(covered != s->ntr_global) { return fail(J2P_EINVAL, "the bands cover %u of %u tile rows", covered, s->ntr_global); }
         t.nband = nband;
+        // where the float norm goes: this solver's own word(s), or the list given (every band's, this one included)
+        if(nout == 0) {
+                t.out[0] = s->norm;
+                t.nout = 1;
+        } else {
+                bool own = false;
+                for(unsigned b = 0; b < nout; b++) {
+                        if(!norm_out[b]) { return fail(J2P_EINVAL, "norm_from_bands: output %u is NULL", b); }
+                        t.out[b] = norm_out[b];
+                        own = own || norm_out[b] == s->norm;
+                }
+                if(!own) { return fail(J2P_EINVAL, "norm_from_bands: the output list must contain the solver's own norm"); }
+                t.nout = nout;
+        }
         unsigned P = 1;
         while(P < s->ntr_global) { P <<= 1; }
-        hipLaunchKernelGGL(k_norm_bands, dim3(s->nch), dim3(256), P * sizeof(double), s->stream, t, s->ntr_global, s->nch, s->norm);
+        hipLaunchKernelGGL(k_norm_bands, dim3(s->nch), dim3(256), P * sizeof(double), s->stream, t, s->ntr_global, s->nch);
         HIP_TRY(hipGetLastError());
+        s->norm_ready = true;
+        return J2P_OK;
+}
+
+int j2p_solver_norm_ptr(j2p_solver *s, float **norm)
+{
+        if(!s || !norm) { return fail(J2P_EINVAL, "NULL argument"); }
+        *norm = s->norm;
+        return J2P_OK;
+}
+
+int j2p_solver_norm_external(j2p_solver *s)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        if(!s->grad_done || s->rowsums_pending) { return fail(J2P_ESTATE, "norm_external needs a finished gradient phase"); }
+        if(s->norm_by_project) { return fail(J2P_ESTATE, "norm_external: this solver reduces the norm inside its projection kernel"); }
         s->norm_ready = true;
         return J2P_OK;
 }
@@ -1382,9 +1482,9 @@ int j2p_decode_plane(int device, unsigned w, unsigned h, const int16_t *data, co
         float qf[64];
         for(int j = 0; j < 64; j++) { qf[j] = (float)quant_table[j]; }
         int rc = J2P_OK;
-        hipError_t e = hipMalloc(&dd, n * sizeof(int16_t));
-        if(e == hipSuccess) { e = hipMalloc(&df, n * sizeof(float)); }
-        if(e == hipSuccess) { e = hipMalloc(&dq, sizeof(qf)); }
+        hipError_t e = dev_malloc((void **)&dd, n * sizeof(int16_t));
+        if(e == hipSuccess) { e = dev_malloc((void **)&df, n * sizeof(float)); }
+        if(e == hipSuccess) { e = dev_malloc((void **)&dq, sizeof(qf)); }
         if(e == hipSuccess) { e = hipMemcpy(dd, data, n * sizeof(int16_t), hipMemcpyHostToDevice); }
         if(e == hipSuccess) { e = hipMemcpy(dq, qf, sizeof(qf), hipMemcpyHostToDevice); }
         if(e == hipSuccess) {
@@ -1411,7 +1511,7 @@ int j2p_dct8x8_blocks(int device, float *blocks, size_t n, int inverse)
         if(!guard.ok) { return fail(J2P_EDEVICE, "hipSetDevice(%d) failed", device); }
         float *db = nullptr;
         int rc = J2P_OK;
-        hipError_t e = hipMalloc(&db, n * 64 * sizeof(float));
+        hipError_t e = dev_malloc((void **)&db, n * 64 * sizeof(float));
         if(e == hipSuccess) { e = hipMemcpy(db, blocks, n * 64 * sizeof(float), hipMemcpyHostToDevice); }
         if(e == hipSuccess) {
                 hipLaunchKernelGGL(k_dct_blocks, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, nullptr, db, n, inverse);
@@ -1423,23 +1523,24 @@ int j2p_dct8x8_blocks(int device, float *blocks, size_t n, int inverse)
         return rc;
 }
 
-int j2p_planes_to_rgb(const j2p_plane_ref planes[3], unsigned w, unsigned h, unsigned bits, uint8_t *out_host)
+// rows [y0, y1) of the image from three (solver, channel) pairs on one device that all hold those canvas rows
+static int rgb_rows(const j2p_plane_ref planes[3], unsigned w, unsigned y0, unsigned y1, unsigned bits, uint8_t *out_host)
 {
-        if(!planes || !out_host) { return fail(J2P_EINVAL, "NULL argument"); }
-        if(bits != 8 && bits != 16) { return fail(J2P_EINVAL, "bits must be 8 or 16 (png.c:22)"); }
-        if(w == 0 || h == 0) { return fail(J2P_EINVAL, "empty image"); }
         const float *ptr[3];
         unsigned stride[3];
         for(int i = 0; i < 3; i++) {
                 j2p_solver *s = planes[i].solver;
                 if(!s || planes[i].channel >= s->nch) { return fail(J2P_EINVAL, "plane %d: bad solver/channel", i); }
-                if(!s->whole) { return fail(J2P_ESTATE, "to_rgb needs whole-canvas solvers"); }
                 if(s->device != planes[0].solver->device) { return fail(J2P_EINVAL, "planes live on different devices"); }
-                if(s->W < w || s->H < h) { return fail(J2P_EINVAL, "plane %d: canvas %ux%u smaller than the image %ux%u", i, s->W, s->H, w, h); }
+                if(s->W < w || y0 < s->row0 || y1 > s->row0 + s->rows) {
+                        return fail(J2P_EINVAL, "plane %d: rows [%u,%u) x %u columns are not inside the solver's [%u,%u) x %u", i, y0, y1, w,
+                                    s->row0, s->row0 + s->rows, s->W);
+                }
                 if(s->grad_done) { return fail(J2P_ESTATE, "to_rgb between the two phases of an iteration"); }
-                ptr[i] = s->ch[planes[i].channel].xbuf[s->cur] + (size_t)kHalo * s->W;
+                ptr[i] = s->ch[planes[i].channel].xbuf[s->cur] + (size_t)(kHalo + (y0 - s->row0)) * s->W;
                 stride[i] = s->W;
         }
+        const unsigned h = y1 - y0;
         j2p_solver *s0 = planes[0].solver;
         DeviceGuard guard(s0->device);
         for(int i = 1; i < 3; i++) {
@@ -1456,6 +1557,26 @@ int j2p_planes_to_rgb(const j2p_plane_ref planes[3], unsigned w, unsigned h, uns
         pool_give(s0->device, dout, dout_bytes);
         if(e != hipSuccess) { return fail(J2P_EDEVICE, "planes_to_rgb: %s", hipGetErrorString(e)); }
         return J2P_OK;
+}
+
+int j2p_planes_to_rgb(const j2p_plane_ref planes[3], unsigned w, unsigned h, unsigned bits, uint8_t *out_host)
+{
+        if(!planes || !out_host) { return fail(J2P_EINVAL, "NULL argument"); }
+        if(bits != 8 && bits != 16) { return fail(J2P_EINVAL, "bits must be 8 or 16 (png.c:22)"); }
+        if(w == 0 || h == 0) { return fail(J2P_EINVAL, "empty image"); }
+        for(int i = 0; i < 3; i++) {
+                if(planes[i].solver && !planes[i].solver->whole) { return fail(J2P_ESTATE, "to_rgb needs whole-canvas solvers (bands: j2p_planes_rows_to_rgb)"); }
+        }
+        return rgb_rows(planes, w, 0, h, bits, out_host);
+}
+
+int j2p_planes_rows_to_rgb(const j2p_plane_ref planes[3], unsigned w, unsigned row_begin, unsigned row_end, unsigned bits,
+                           uint8_t *out_host)
+{
+        if(!planes || !out_host) { return fail(J2P_EINVAL, "NULL argument"); }
+        if(bits != 8 && bits != 16) { return fail(J2P_EINVAL, "bits must be 8 or 16 (png.c:22)"); }
+        if(w == 0 || row_begin >= row_end) { return fail(J2P_EINVAL, "empty row range"); }
+        return rgb_rows(planes, w, row_begin, row_end, bits, out_host);
 }
 
 int j2p_math_selftest(int device, size_t n, unsigned seed, unsigned long long *div_mismatches,

@@ -7,16 +7,23 @@
 // meet twice (reference loop compute.c:427-453):
 //
 //   1. ||g|| (compute.c:200-207) needs every band's gradient: each band records an event behind its gradient
-//      phase (whose last wavefronts have already reduced the band's 16-row tile rows), waits for the other bands'
-//      events and reduces ALL bands' row sums — read in place over xGMI — with the same fixed tree over the same
-//      global array as the single-GPU solver.  The result therefore does not depend on the number of bands.
+//      phase (whose last wavefronts have already reduced the band's 16-row tile rows).  ONE band — the root —
+//      waits for the other bands' events, reduces ALL bands' row sums — read in place over xGMI — with the same
+//      fixed tree over the same global array as the single-GPU solver, and stores the float norm into every band's
+//      own norm word; the other bands wait for that ONE event.  2 (N - 1) cross-device dependencies per iteration
+//      instead of N (N - 1), the same arithmetic: the result does not depend on the number of bands.
+//      (J2P_TILED_NORM=all: every band reduces for itself, as in round 2 — one hop less, N - 1 waits per band.)
 //   2. the next gradient reaches 2 rows into the neighbouring bands (TGV2, compute.c:137-143,165-183): the
 //      projection does the band's first and last block row first and records an event; the neighbours pull those
 //      rows into their halo rows after the interior of THEIR next gradient phase, which reads no halo row, so the
 //      copy and the cross-GPU wait hide behind roughly two thirds of an iteration of compute.
 //
 // Ordering between GPUs is by HIP events only (kernel-boundary visibility); no flag is polled on a device.
+// Host side: a band thread that needs another band's event sleeps on a condition variable until that event has
+// been RECORDED (hipStreamWaitEvent on an event not yet recorded would be a no-op); it never waits for the GPU.
 #include <hip/hip_runtime.h>
+#include <sys/resource.h>
+#include <stdlib.h>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -41,14 +48,18 @@ struct Band {
         bool split = false;                    // long enough for the two-part phases
         hipEvent_t ev_grad[2] = {nullptr, nullptr};    // behind the gradient phase of iteration it (slot it & 1)
         hipEvent_t ev_edge[2] = {nullptr, nullptr};    // behind the projection of the band's first/last block rows
-        std::atomic<uint64_t> grad_recorded{0}, edge_recorded{0};   // iterations whose event has been recorded
+        hipEvent_t ev_norm[2] = {nullptr, nullptr};    // root band only: behind the norm of iteration it
+        // iterations whose event has been recorded (guarded by j2p_tiled::seq_lock)
+        uint64_t grad_recorded = 0, edge_recorded = 0, norm_recorded = 0;
         j2p_exchange rows[2];                  // halo / edge row addresses of x buffer 0 and 1
         const double *rowsum[2] = {nullptr, nullptr};   // level-1 sums of even / odd iterations
+        float *norm = nullptr;                 // the band solver's norm word(s), [channel]
         unsigned first_tr = 0, ntr = 0;
         double *log_dev = nullptr;             // the band's {tv, tv2, prob[3]} of the iteration just finished
         double *log_host = nullptr;            // pinned: [chunk][kLogCols]
         unsigned log_cap = 0;
         std::thread thread;
+        double cpu_seconds = 0.;               // user + system time of the band thread inside band_iterations
         int rc = J2P_OK;
         char err[256] = "";
 };
@@ -61,6 +72,10 @@ struct j2p_tiled {
         std::vector<Band *> bands;
         uint64_t iter = 0;                     // iterations issued so far
         double carried[J2P_MAX_CHANNELS] = {0., 0., 0.};
+        bool carried_valid = true;             // false after iterations run without logging (their prob sums were not kept)
+        bool logging = false;                  // the band solvers currently run their logging kernels
+        bool norm_by_root = true;              // one band reduces ||g|| for all (default); false: every band for itself
+        unsigned root = 0;
         // command hand-over to the band threads
         std::mutex lock;
         std::condition_variable wake, done;
@@ -69,6 +84,10 @@ struct j2p_tiled {
         bool cmd_log = false, quit = false;
         unsigned finished = 0;
         std::atomic<bool> abort{false};
+        // "band p has recorded its event of iteration it": sequence numbers in Band, one lock and one condition
+        // variable for all of them (a band thread sleeps here; nothing spins)
+        std::mutex seq_lock;
+        std::condition_variable seq_cv;
 };
 
 namespace {
@@ -84,16 +103,33 @@ namespace {
                 if(e_ != hipSuccess) { return j2p_fail(J2P_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); } \
         } while(0)
 
-// wait (host) until band p has recorded its event of iteration `it`, then make `me`'s stream wait for it
-int wait_for(j2p_tiled *t, Band *me, Band *p, bool edge, uint64_t it)
+enum Which { kGrad, kEdge, kNorm };
+
+uint64_t &seq_of(Band *p, Which w) { return w == kGrad ? p->grad_recorded : (w == kEdge ? p->edge_recorded : p->norm_recorded); }
+
+// record band me's event of iteration `it` on its stream and tell the waiting band threads
+int record(j2p_tiled *t, Band *me, Which w, uint64_t it)
 {
-        std::atomic<uint64_t> &seq = edge ? p->edge_recorded : p->grad_recorded;
-        unsigned spins = 0;
-        while(seq.load(std::memory_order_acquire) <= it) {
-                if(t->abort.load(std::memory_order_relaxed)) { return j2p_fail(J2P_ESTATE, "another band failed"); }
-                if(++spins > 64) { std::this_thread::yield(); }
+        hipEvent_t ev = w == kGrad ? me->ev_grad[it & 1] : (w == kEdge ? me->ev_edge[it & 1] : me->ev_norm[it & 1]);
+        BAND_HIP(hipEventRecord(ev, me->stream));
+        {
+                std::lock_guard<std::mutex> g(t->seq_lock);
+                seq_of(me, w) = it + 1;
         }
-        BAND_HIP(hipStreamWaitEvent(me->stream, edge ? p->ev_edge[it & 1] : p->ev_grad[it & 1], 0));
+        t->seq_cv.notify_all();
+        return J2P_OK;
+}
+
+// sleep (host) until band p has recorded its event of iteration `it`, then make `me`'s stream wait for it
+int wait_for(j2p_tiled *t, Band *me, Band *p, Which w, uint64_t it)
+{
+        {
+                std::unique_lock<std::mutex> g(t->seq_lock);
+                t->seq_cv.wait(g, [&] { return seq_of(p, w) > it || t->abort.load(std::memory_order_relaxed); });
+                if(seq_of(p, w) <= it) { return j2p_fail(J2P_ESTATE, "another band failed"); }
+        }
+        hipEvent_t ev = w == kGrad ? p->ev_grad[it & 1] : (w == kEdge ? p->ev_edge[it & 1] : p->ev_norm[it & 1]);
+        BAND_HIP(hipStreamWaitEvent(me->stream, ev, 0));
         return J2P_OK;
 }
 
@@ -107,8 +143,8 @@ int pull_halos(j2p_tiled *t, unsigned b, uint64_t it)
         float *dst[2 * J2P_MAX_CHANNELS];
         const float *src[2 * J2P_MAX_CHANNELS];
         unsigned n = 0;
-        if(up) { BAND_TRY(wait_for(t, me, up, true, it)); }
-        if(down) { BAND_TRY(wait_for(t, me, down, true, it)); }
+        if(up) { BAND_TRY(wait_for(t, me, up, kEdge, it)); }
+        if(down) { BAND_TRY(wait_for(t, me, down, kEdge, it)); }
         for(unsigned c = 0; c < t->nch; c++) {
                 if(up) { dst[n] = me->rows[buf].recv_top[c]; src[n++] = up->rows[buf].send_bottom[c]; }
                 if(down) { dst[n] = me->rows[buf].recv_bottom[c]; src[n++] = down->rows[buf].send_top[c]; }
@@ -121,15 +157,19 @@ int band_iterations(j2p_tiled *t, unsigned b, unsigned n, bool log)
         Band *me = t->bands[b];
         BAND_HIP(hipSetDevice(me->device));
         // a band may run ahead of the others by up to one gradient phase, so the row sums alternate between two
-        // buffers: iteration it + 2 overwrites those of iteration it only after every band's norm(it) has run
+        // buffers: iteration it + 2 overwrites those of iteration it only after every reader's norm(it) has run
         const double *rowsums[2][32];
         unsigned first[32], count[32];
+        float *norm_out[32];
         for(unsigned p = 0; p < t->nband; p++) {
                 rowsums[0][p] = t->bands[p]->rowsum[0];
                 rowsums[1][p] = t->bands[p]->rowsum[1];
                 first[p] = t->bands[p]->first_tr;
                 count[p] = t->bands[p]->ntr;
+                norm_out[p] = t->bands[p]->norm;
         }
+        const bool by_root = t->norm_by_root;
+        Band *root = t->bands[t->root];
         for(unsigned i = 0; i < n; i++) {
                 const uint64_t it = t->iter + i;
                 // ---- phase A; the rows of the neighbours arrive behind the interior segments ----
@@ -142,23 +182,32 @@ int band_iterations(j2p_tiled *t, unsigned b, unsigned n, bool log)
                         if(it > 0) { BAND_TRY(pull_halos(t, b, it - 1)); }
                         BAND_TRY(j2p_solver_phase_gradient(me->solver));
                 }
-                BAND_HIP(hipEventRecord(me->ev_grad[it & 1], me->stream));
-                me->grad_recorded.store(it + 1, std::memory_order_release);
-                // ---- the global norm: every band's row sums, same tree everywhere ----
-                for(unsigned p = 0; p < t->nband; p++) {
-                        if(p != b) { BAND_TRY(wait_for(t, me, t->bands[p], false, it)); }
+                BAND_TRY(record(t, me, kGrad, it));
+                // ---- the global norm: every band's row sums, one fixed tree ----
+                if(!by_root) {
+                        for(unsigned p = 0; p < t->nband; p++) {
+                                if(p != b) { BAND_TRY(wait_for(t, me, t->bands[p], kGrad, it)); }
+                        }
+                        BAND_TRY(j2p_solver_norm_from_bands(me->solver, t->nband, rowsums[it & 1], first, count, 0, nullptr));
+                } else if(me == root) {
+                        for(unsigned p = 0; p < t->nband; p++) {
+                                if(p != b) { BAND_TRY(wait_for(t, me, t->bands[p], kGrad, it)); }
+                        }
+                        // ... and the result goes into every band's own norm word (peer stores)
+                        BAND_TRY(j2p_solver_norm_from_bands(me->solver, t->nband, rowsums[it & 1], first, count, t->nband, norm_out));
+                        BAND_TRY(record(t, me, kNorm, it));
+                } else {
+                        BAND_TRY(wait_for(t, me, root, kNorm, it));
+                        BAND_TRY(j2p_solver_norm_external(me->solver));
                 }
-                BAND_TRY(j2p_solver_norm_from_bands(me->solver, t->nband, rowsums[it & 1], first, count));
                 // ---- phase B, edge block rows first ----
                 if(me->split) {
                         BAND_TRY(j2p_solver_phase_project_part(me->solver, J2P_PROJECT_BOUNDARY));
-                        BAND_HIP(hipEventRecord(me->ev_edge[it & 1], me->stream));
-                        me->edge_recorded.store(it + 1, std::memory_order_release);
+                        BAND_TRY(record(t, me, kEdge, it));
                         BAND_TRY(j2p_solver_phase_project_part(me->solver, J2P_PROJECT_INTERIOR));
                 } else {
                         BAND_TRY(j2p_solver_phase_project(me->solver));
-                        BAND_HIP(hipEventRecord(me->ev_edge[it & 1], me->stream));
-                        me->edge_recorded.store(it + 1, std::memory_order_release);
+                        BAND_TRY(record(t, me, kEdge, it));
                 }
                 if(log) {
                         BAND_HIP(hipMemcpyAsync(me->log_host + (size_t)i * kLogCols, me->log_dev, kLogCols * sizeof(double),
@@ -166,6 +215,13 @@ int band_iterations(j2p_tiled *t, unsigned b, unsigned n, bool log)
                 }
         }
         return J2P_OK;
+}
+
+double thread_cpu_seconds()
+{
+        struct rusage u;
+        if(getrusage(RUSAGE_THREAD, &u) != 0) { return 0.; }
+        return (double)u.ru_utime.tv_sec + (double)u.ru_stime.tv_sec + 1e-6 * ((double)u.ru_utime.tv_usec + (double)u.ru_stime.tv_usec);
 }
 
 void band_main(j2p_tiled *t, unsigned b)
@@ -183,10 +239,16 @@ void band_main(j2p_tiled *t, unsigned b)
                         log = t->cmd_log;
                 }
                 Band *me = t->bands[b];
+                const double cpu0 = thread_cpu_seconds();
                 me->rc = band_iterations(t, b, n, log);
+                me->cpu_seconds += thread_cpu_seconds() - cpu0;
                 if(me->rc != J2P_OK) {
                         strncpy(me->err, j2p_last_error(), sizeof(me->err) - 1);
-                        t->abort.store(true);
+                        {
+                                std::lock_guard<std::mutex> g(t->seq_lock);
+                                t->abort.store(true);
+                        }
+                        t->seq_cv.notify_all();
                 }
                 {
                         std::lock_guard<std::mutex> g(t->lock);
@@ -221,12 +283,14 @@ void j2p_tiled_destroy(j2p_tiled *t)
                 for(int k = 0; k < 2; k++) {
                         if(b->ev_grad[k]) { (void)hipEventDestroy(b->ev_grad[k]); }
                         if(b->ev_edge[k]) { (void)hipEventDestroy(b->ev_edge[k]); }
+                        if(b->ev_norm[k]) { (void)hipEventDestroy(b->ev_norm[k]); }
                 }
                 if(b->log_host) { (void)hipHostFree(b->log_host); }
                 delete b;
         }
         if(prev >= 0) { (void)hipSetDevice(prev); }
         delete t;
+        j2p_pool_trim();        // band arenas are large and rarely reused at the same size: back to the device
 }
 
 int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const unsigned cuts[], unsigned nchannel,
@@ -270,6 +334,12 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
         t->H = H;
         t->weight = weight;
         for(unsigned c = 0; c < nchannel; c++) { t->pweight[c] = pweight[c]; }
+        {
+                // who reduces ||g||: the root band for all (default), or every band for itself (round 2's schedule)
+                const char *env = getenv("J2P_TILED_NORM");
+                t->norm_by_root = !(env && strcmp(env, "all") == 0);
+                t->root = 0;
+        }
         int prev = -1;
         (void)hipGetDevice(&prev);
         int rc = J2P_OK;
@@ -316,13 +386,16 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                 }
                 bd->first_tr = e.first_tile_row;
                 bd->ntr = e.local_tile_rows;
+                rc = j2p_solver_norm_ptr(bd->solver, &bd->norm);
+                if(rc != J2P_OK) { break; }
                 j2p_solver_halo_rows(bd->solver, 0, &bd->rows[0]);
                 j2p_solver_halo_rows(bd->solver, 1, &bd->rows[1]);
                 // the two-part phases need an interior: three 16-row segments and three block rows of every channel
                 bd->split = nband > 1 && bd->row1 - bd->row0 >= 3 * align && bd->row1 - bd->row0 >= 3 * J2P_TILE_ROWS;
                 for(int k = 0; k < 2 && rc == J2P_OK; k++) {
                         if(hipEventCreateWithFlags(&bd->ev_grad[k], hipEventDisableTiming) != hipSuccess ||
-                           hipEventCreateWithFlags(&bd->ev_edge[k], hipEventDisableTiming) != hipSuccess) {
+                           hipEventCreateWithFlags(&bd->ev_edge[k], hipEventDisableTiming) != hipSuccess ||
+                           hipEventCreateWithFlags(&bd->ev_norm[k], hipEventDisableTiming) != hipSuccess) {
                                 rc = j2p_fail(J2P_EDEVICE, "hipEventCreate failed");
                         }
                 }
@@ -332,7 +405,10 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                 j2p_tiled_destroy(t);
                 return rc;
         }
-        for(unsigned b = 0; b < nband; b++) { t->bands[b]->thread = std::thread(band_main, t, b); }
+        // a single band is a whole-canvas solver: j2p_tiled_run hands it to j2p_solver_run (no thread, no exchange)
+        if(nband > 1) {
+                for(unsigned b = 0; b < nband; b++) { t->bands[b]->thread = std::thread(band_main, t, b); }
+        }
         *out = t;
         return J2P_OK;
 }
@@ -369,15 +445,16 @@ int j2p_tiled_reset(j2p_tiled *t)
         if(!t) { return j2p_fail(J2P_EINVAL, "tiled solver is NULL"); }
         if(t->abort.load()) { return j2p_fail(J2P_ESTATE, "a band failed earlier; the tiled solver is unusable"); }
         // the band threads are idle between run() calls; every band back to iteration 0 from its resident inputs
-        for(Band *b : t->bands) {
-                BAND_TRY(j2p_solver_reset(b->solver));
-                b->grad_recorded.store(0);
-                b->edge_recorded.store(0);
+        for(Band *b : t->bands) { BAND_TRY(j2p_solver_reset(b->solver)); }
+        {
+                std::lock_guard<std::mutex> g(t->seq_lock);
+                for(Band *b : t->bands) { b->grad_recorded = b->edge_recorded = b->norm_recorded = 0; }
         }
         // a band's reset must not overtake a neighbour still pulling its edge rows: drain, this is not a hot path
         BAND_TRY(j2p_tiled_sync(t));
         t->iter = 0;
         for(unsigned c = 0; c < J2P_MAX_CHANNELS; c++) { t->carried[c] = 0.; }
+        t->carried_valid = true;
         return J2P_OK;
 }
 
@@ -386,14 +463,24 @@ int j2p_tiled_run(j2p_tiled *t, unsigned n, j2p_log_row *rows)
         if(!t) { return j2p_fail(J2P_EINVAL, "tiled solver is NULL"); }
         if(n == 0) { return J2P_OK; }
         if(t->abort.load()) { return j2p_fail(J2P_ESTATE, "a band failed earlier; the tiled solver is unusable"); }
+        if(t->nband == 1) {
+                // one band = a whole-canvas solver: its own loop (its norm reduction is not the band solvers')
+                BAND_TRY(j2p_solver_run(t->bands[0]->solver, n, rows));
+                t->iter += n;
+                return J2P_OK;
+        }
         const bool log = rows != nullptr;
+        if(log != t->logging) {
+                // the logging kernels run only while somebody reads their sums
+                for(Band *b : t->bands) { BAND_TRY(j2p_solver_set_logging(b->solver, log ? 1 : 0)); }
+                t->logging = log;
+        }
         if(log) {
                 int prev = -1;
                 (void)hipGetDevice(&prev);
                 for(Band *b : t->bands) {
                         (void)hipSetDevice(b->device);
                         if(!b->log_dev) {
-                                BAND_TRY(j2p_solver_set_logging(b->solver, 1));
                                 j2p_exchange e;
                                 BAND_TRY(j2p_solver_exchange_info(b->solver, &e));
                                 b->log_dev = e.log_local;
@@ -429,8 +516,22 @@ int j2p_tiled_run(j2p_tiled *t, unsigned n, j2p_log_row *rows)
                 for(Band *b : t->bands) {
                         for(size_t k = 0; k < sums.size(); k++) { sums[k] += b->log_host[k]; }
                 }
-                j2p_rows_from_sums_carry(t->nch, t->weight, t->pweight, n, sums.data(), t->carried, rows);
+                // the prob distance entering the first of these iterations is only known if the previous ones were
+                // logged too (or there were none): NaN otherwise, as j2p_solver_run reports it
+                j2p_rows_from_sums_carry(t->nch, t->weight, t->pweight, n, sums.data(), t->carried, t->carried_valid, rows);
+                t->carried_valid = true;
+        } else {
+                t->carried_valid = false;
         }
+        return J2P_OK;
+}
+
+int j2p_tiled_host_cpu_seconds(const j2p_tiled *t, double *seconds)
+{
+        if(!t || !seconds) { return j2p_fail(J2P_EINVAL, "NULL argument"); }
+        double s = 0.;
+        for(const Band *b : t->bands) { s += b->cpu_seconds; }
+        *seconds = s;
         return J2P_OK;
 }
 

@@ -143,3 +143,51 @@ def make_planes(W, H, subsampling="444", quality=10, seed=1234, y_only=False, ro
         pp = _pad8(p)
         planes.append(Plane(pp.shape[1], pp.shape[0], s[0], s[1], encode_plane(pp, qc), qc))
     return planes
+
+
+def make_y_plane_banded(W, H, quality, seed, band_rows=2048, workers=8):
+    """A large Y-only plane synthesised band by band in worker processes (identical to make_planes(..., y_only=True)
+    of the whole image: the content does not depend on the row split) — bounds the float64 temporaries and uses the
+    host's cores.  H must be a multiple of 8; band_rows a multiple of 64.  The workers are fresh interpreters
+    (`python -m jpeg2png_amd.synth ...`), not forks: the caller may hold an initialised HIP runtime."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tmp = tempfile.mkdtemp(prefix="j2p_synth_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    jobs = [(r0, min(H, r0 + band_rows)) for r0 in range(0, H, band_rows)]
+    parts = [None] * len(jobs)
+    try:
+        running = {}
+        nxt = 0
+        while nxt < len(jobs) or running:
+            while nxt < len(jobs) and len(running) < workers:
+                r0, r1 = jobs[nxt]
+                out = os.path.join(tmp, f"{nxt}.npy")
+                running[nxt] = (subprocess.Popen([sys.executable, "-W", "ignore::RuntimeWarning", "-m", "jpeg2png_amd.synth", str(W), str(H), str(quality), str(seed),
+                                                  str(r0), str(r1), out], cwd=root), out)
+                nxt += 1
+            for k in list(running):
+                proc, out = running[k]
+                if proc.poll() is None:
+                    continue
+                if proc.returncode != 0:
+                    raise RuntimeError(f"synth worker for band {k} failed ({proc.returncode})")
+                parts[k] = np.load(out)
+                os.unlink(out)
+                del running[k]
+            if running:
+                next(iter(running.values()))[0].wait()
+    finally:
+        for proc, _ in running.values():
+            proc.kill()
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return Plane(W, H, 1, 1, np.concatenate(parts), quant_table("luma", quality))
+
+
+if __name__ == "__main__":
+    import sys
+    _W, _H, _q, _seed, _r0, _r1 = (int(v) for v in sys.argv[1:7])
+    np.save(sys.argv[7], make_planes(_W, _H, "444", _q, seed=_seed, y_only=True, rows=(_r0, _r1))[0].data)

@@ -13,6 +13,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+PARITY_NOTES = []
+
+
+def parity_note(msg):
+    """one line for the "parity" section pytest prints after the run (also with -q): what was compared with the
+    reference and whether it was bit-identical — so that the driver's GPUTEST record says so"""
+    PARITY_NOTES.append(msg)
+
+
+def pytest_terminal_summary(terminalreporter):
+    if PARITY_NOTES:
+        terminalreporter.section("parity vs the compiled reference")
+        for line in PARITY_NOTES:
+            terminalreporter.write_line(line)
+
+
 @pytest.fixture(scope="session")
 def lib():
     """The in-tree HIP library; built on demand (hipcc cross-compiles without a GPU)."""

@@ -96,3 +96,27 @@ def test_pool_recycles_arenas(lib):
     for c in range(3):
         assert bit_equal(out[c], ref[c].fdata)          # a recycled (dirty) arena changes nothing
     lib.j2p_pool_trim()
+
+
+@pytest.mark.parametrize("separate", [False, True])
+def test_tiled_job_equals_single_solver_job(lib, separate):
+    """j2p_job.tile: one image over all the batch's devices (here device 0 three times): float planes and RGB bytes
+    equal the untiled job's; a canvas too short to tile falls back to the single-solver path"""
+    import jpeg2png_amd as j
+    planes = make_case(152, 296, "420", 10, seed=83)
+    weights, its = ([0.3, 0.1, 0.0], [12, 7, 5]) if separate else (0.3, 12)
+    with j.Batch(devices=[0, 0, 0], slots_per_device=1) as b:
+        a_f = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate))
+        a_rgb = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate, width=150, height=290, bits=8))
+        t_f = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate, tile=True))
+        t_rgb = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate, width=150, height=290, bits=8, tile=True))
+        t_rgb16 = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate, width=150, height=290, bits=16, tile=True))
+        a_rgb16 = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate, width=150, height=290, bits=16))
+        short = make_case(64, 48, "444", 20, seed=3)
+        s_t = b.wait(b.submit(short, 0.3, [0.001] * 3, 4, tile=True))
+        s_a = b.wait(b.submit(short, 0.3, [0.001] * 3, 4))
+    for c in range(3):
+        assert bit_equal(t_f[c], a_f[c]), f"channel {c}"
+        assert bit_equal(s_t[c], s_a[c])
+    assert np.array_equal(t_rgb, a_rgb)
+    assert np.array_equal(t_rgb16, a_rgb16)

@@ -254,3 +254,44 @@ def test_truncated_jpeg_message_without_a_gpu(cli, tmp_path):
     assert lines and lines[0].startswith("jpeg2png: libjpeg error: ")
     if g.returncode != 0:      # no GPU here: the next line must be the loud "no device" failure, not the warning
         assert len(lines) >= 2 and "HIP device" in lines[-1]
+
+
+TILE_CASES = [
+    ("tall_420_joint", 136, 400, 10, 2, ["-i", "9"]),
+    ("tall_420_separate_16bit", 120, 328, 20, 2, ["-s", "-i", "8,5,3", "-w", "0.3,0.1,0", "-1"]),
+    ("tall_444_joint_odd", 77, 301, 10, 0, ["-i", "6"]),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", TILE_CASES, ids=[c[0] for c in TILE_CASES])
+def test_one_tall_image_is_row_tiled_over_every_listed_gpu(cli, tmp_path, case):
+    """fewer files than GPUs in J2P_DEVICES: the image is solved as one band per listed device (the four "devices"
+    are this box's GPU four times) — decode_file -> compute of one image, jpeg2png.c:141-152 — with the bands
+    converting their own rows to RGB: PNG bytes and CSV rows must equal the reference program's"""
+    if not os.path.exists(REF_CLI):
+        pytest.skip("oracle/_ref/jpeg2png_ref not built (needs /root/reference)")
+    name, w, h, q, sub, flags = case
+    jpg = tmp_path / "in.jpg"
+    make_jpeg(jpg, w, h, q, sub, seed=40 + len(name))
+    ref_png, gpu_png = tmp_path / "ref.png", tmp_path / "gpu.png"
+    ref_csv, gpu_csv = tmp_path / "ref.csv", tmp_path / "gpu.csv"
+    r = run(REF_CLI, str(jpg), "-o", str(ref_png), "-q", "-c", str(ref_csv), "-t", "1", *flags)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, J2P_DEVICES="0,0,0,0")
+    g = subprocess.run([cli, str(jpg), "-o", str(gpu_png), "-q", "-c", str(gpu_csv), *flags], capture_output=True, text=True, env=env)
+    assert g.returncode == 0, g.stderr
+    assert ref_png.read_bytes() == gpu_png.read_bytes()
+    ref_rows = np.loadtxt(ref_csv, delimiter=",", skiprows=1, usecols=(1, 2, 3, 4, 5, 6), ndmin=2)
+    gpu_rows = np.loadtxt(gpu_csv, delimiter=",", skiprows=1, usecols=(1, 2, 3, 4, 5, 6), ndmin=2)
+    ref_rows = ref_rows[np.lexsort((ref_rows[:, 1], ref_rows[:, 0]))]
+    gpu_rows = gpu_rows[np.lexsort((gpu_rows[:, 1], gpu_rows[:, 0]))]
+    assert ref_rows.shape == gpu_rows.shape
+    np.testing.assert_allclose(gpu_rows, ref_rows, rtol=0, atol=2e-6 * max(1.0, np.abs(ref_rows).max()))
+
+
+def test_threads_default_is_the_core_count_like_openmp(cli):
+    """-t is optional and its default is the online core count (the reference leaves it to OpenMP,
+    jpeg2png.c:246-257): the usage text says so"""
+    r = run(cli, "-h")
+    assert "default: online cores" in r.stdout

@@ -90,3 +90,73 @@ def test_norm_fold_on_and_off_agree(lib):
                 outs.append([s.download(c) for c in range(len(planes))])
         for c in range(len(planes)):
             assert bit_equal(outs[0][c], outs[1][c])
+
+
+def test_one_band_is_a_whole_canvas_solver(lib):
+    """nband == 1 (the C API and TiledSolver(devices=[0]) reach it): a canvas above 2.5 Mpixel, whose whole-canvas
+    solver keeps its own norm reduction (no per-tile-row sums for k_norm_bands to read) — planes and CSV rows must
+    equal the plain solver's"""
+    import jpeg2png_amd as j
+    from jpeg2png_amd import synth
+    planes = synth.make_planes(2048, 1536, "444", 10, seed=91, y_only=True)       # 3.1 Mpixel
+    its = 6
+    with j.Solver(planes, 0.3, [0.001], its) as s:
+        want_rows = s.run(its, log=True)
+        want = s.download(0)
+    with j.TiledSolver(planes, 0.3, [0.001], its, devices=[0]) as t:
+        assert t.bands() == [(0, 0, 1536)]
+        rows = np.concatenate([t.run(2, log=True), t.run(4, log=True)])
+        assert bit_equal(t.download(0), want)
+        t.reset()
+        t.run(its)
+        assert bit_equal(t.download(0), want)
+    np.testing.assert_allclose(rows, want_rows, rtol=1e-9, atol=1e-12)
+    assert np.isfinite(rows).all()
+
+
+def test_norm_from_bands_refuses_a_solver_without_row_sums(lib):
+    """the underlying guard: a whole-canvas solver above 2.5 Mpixel leaves no level-1 sums, so the band reduction
+    must fail loudly instead of reducing uninitialised memory"""
+    import ctypes
+    import jpeg2png_amd as j
+    from jpeg2png_amd import synth
+    planes = synth.make_planes(2048, 1536, "444", 10, seed=91, y_only=True)
+    with j.Solver(planes, 0.3, [0.001], 2) as s:
+        s.phase_gradient()
+        e = s.exchange_info()
+        rs = (ctypes.c_void_p * 1)(e.partials_local)
+        first, count = (ctypes.c_uint * 1)(0), (ctypes.c_uint * 1)(e.global_tile_rows)
+        lib.j2p_solver_norm_from_bands.argtypes = [ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.c_void_p, ctypes.c_uint, ctypes.c_void_p]
+        assert lib.j2p_solver_norm_from_bands(s._h, 1, rs, first, count, 0, None) == -4      # J2P_ESTATE
+        s.phase_project()
+
+
+def test_unlogged_then_logged_runs_report_nan_for_the_unknown_distance(lib):
+    """the prob distance entering a logged run is only known if the iterations before it were logged: NaN in the
+    first row otherwise, exactly as j2p_solver_run reports it; tv / tv2 are exact either way"""
+    import jpeg2png_amd as j
+    planes = make_case(200, 330, "420", 10, seed=77)
+    pws = [0.001] * 3
+    _, want_rows = whole_canvas(planes, 0.3, pws, 9, log=True)
+    with j.TiledSolver(planes, 0.3, pws, 9, devices=[0] * 3) as t:
+        t.run(4)
+        rows = t.run(5, log=True)
+    assert np.isnan(rows[0, 0]) and np.isnan(rows[0, 1])
+    np.testing.assert_allclose(rows[0, 2:], want_rows[4, 2:], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(rows[1:], want_rows[5:], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("mode", ["root", "all"])
+def test_both_norm_schedules_give_the_same_bits(lib, mode, monkeypatch):
+    """one band reducing ||g|| for all (default) and every band reducing for itself (J2P_TILED_NORM=all): same tree
+    over the same array, so the same planes"""
+    import jpeg2png_amd as j
+    planes = make_case(264, 410, "420", 10, seed=78)
+    pws = [0.001] * 3
+    want, _ = whole_canvas(planes, 0.3, pws, 10)
+    monkeypatch.setenv("J2P_TILED_NORM", mode)
+    with j.TiledSolver(planes, 0.3, pws, 10, devices=[0] * 5) as t:
+        t.run(10)
+        for c in range(3):
+            assert bit_equal(t.download(c), want[c]), f"{mode}: channel {c}"
