@@ -18,7 +18,8 @@ Workloads (BASELINE.json configs):
             c    : the C row tiling (j2p_tiled: one process drives all N GPUs with one host thread per band;
                    bands exchange edge rows and norm row sums by peer access over xGMI, ordered by HIP events)
                    — rank 0 drives it; the other ranks of the launch wait in a gloo (CPU) barrier, so that no
-                   RCCL barrier kernel spins on their GPUs while rank 0's band kernels run there;
+                   RCCL barrier kernel spins on their GPUs while rank 0's band kernels run there; timed twice:
+                   its default schedule and the split-phase one (c_split, J2P_TILED_SPLIT=1);
             rccl : one process per GPU, RCCL send/recv of the halo rows + all-gather of the norm row sums
                    (jpeg2png_amd/tiled.py), the exchange north_star names.
           `value` is the faster of the two (`config.parallelism` says which), the other one is in
@@ -488,17 +489,22 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
     # (the RCCL harness needs one rank per GPU: not in the one-device rehearsal, and with a single rank only on request)
     want_rccl = (a.tiled_impl == "rccl" or (a.tiled_impl == "both" and world > 1)) and not (one_device and world > 1)
 
-    # ---- leg 1: the C engine, driven by rank 0 ----
-    if want_c:
+    # ---- legs 1a / 1b: the C engine, driven by rank 0 — its default schedule (one gradient and one projection launch per
+    # band and iteration, the halo rows pulled in front of the gradient) and the split one (J2P_TILED_SPLIT=1: interior /
+    # edge parts, the halo exchange hidden behind the interior launches) ----
+    def c_leg(name, split):
         ok = [True, ""]
         tsolver = eng = None
         if rank == 0:
             try:
+                os.environ["J2P_TILED_SPLIT"] = "1" if split else "0"          # read by j2p_tiled_create
                 devices = list(range(n_gpus)) if n_gpus > 1 and not one_device else [local_rank] * nband
                 tsolver = j.TiledSolver([whole_plane], WEIGHT, [PWEIGHT], its, devices=devices)
                 eng = tsolver.band_solver(0)
             except Exception as e:      # noqa: BLE001  (no peer access between the GPUs, a device this process cannot open ...)
                 ok = [False, f"{type(e).__name__}: {e}"]
+            finally:
+                os.environ.pop("J2P_TILED_SPLIT", None)
         ok = ranks.share(ok)
         if ok[0]:
             if rank == 0:
@@ -509,15 +515,21 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
             cpu_s = tsolver.host_cpu_seconds() if rank == 0 else 0.0
             if rank == 0:
                 tsolver.close()
-            legs["c"] = {"elapsed": elapsed, "g_ms": g_ms, "p_ms": p_ms, "samples": samples, "split": True,
-                         "host_cpu_s": round(cpu_s, 3),
-                         "parallelism": (f"row-tiled x{nband}: C engine (j2p_tiled), one process drives all GPUs, one host thread per "
-                                         "band; edge rows and norm row sums read over peer access, ordered by HIP events; one band "
-                                         "reduces ||g|| for all")}
+            legs[name] = {"elapsed": elapsed, "g_ms": g_ms, "p_ms": p_ms, "samples": samples, "split": split,
+                          "host_cpu_s": round(cpu_s, 3),
+                          "parallelism": (f"row-tiled x{nband}: C engine (j2p_tiled), one process drives all GPUs, one host thread per "
+                                          "band; edge rows and norm row sums read over peer access, ordered by HIP events; one band "
+                                          "reduces ||g|| for all; " + ("split phases (halo exchange behind the interior launches)" if split
+                                                                      else "one gradient and one projection launch per iteration"))}
         elif rank == 0:
-            print(f"bench: C row tiling unavailable: {ok[1]}", file=sys.stderr, flush=True)
-            legs["c_error"] = ok[1]
-    ranks.barrier()
+            print(f"bench: C row tiling ({name}) unavailable: {ok[1]}", file=sys.stderr, flush=True)
+            legs[name + "_error"] = ok[1]
+        ranks.barrier()
+
+    if want_c:
+        c_leg("c", False)
+        if "c" in legs:
+            c_leg("c_split", True)
 
     # ---- leg 2: one process per GPU over RCCL ----
     watchdog = None

@@ -121,6 +121,11 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value);
 int j2p_debug_build(void);
 int j2p_solver_debug_violations(j2p_solver *s, unsigned long long *count, unsigned *site, unsigned long long *offset);
 
+/* Timing tool (builds with -DJ2P_TRACE only, tools/wave_trace.py; J2P_ESTATE otherwise): while on, every wavefront
+ * of the two phase kernels appends {start, first data, end (10 ns ticks), id} — four 64-bit words — to a device
+ * buffer; a call with host_out copies up to max_records records out and empties the buffer. */
+int j2p_solver_trace(j2p_solver *s, int on, unsigned long long *host_out, unsigned max_records, unsigned *n);
+
 /* canvas geometry (compute.c:410-416) and band bookkeeping */
 int j2p_solver_canvas(const j2p_solver *s, unsigned *W, unsigned *H);
 int j2p_solver_band(const j2p_solver *s, unsigned *row_begin, unsigned *row_end);
@@ -215,7 +220,8 @@ int j2p_solver_copy_rows(j2p_solver *s, unsigned n, float *const dst[], const fl
  * lcm(16, 8 * h_samp), or NULL for near-equal bands.  run / sync / download mirror the j2p_solver calls; the
  * planes are bit-identical to a whole-canvas solver's whatever the cut.  (Reference loop: compute.c:427-453.)
  * nband == 1 is a plain whole-canvas solver behind the same calls.  Per iteration one band reduces ||g|| for all
- * (environment J2P_TILED_NORM=all: every band for itself).  host_cpu_seconds: user + system time the band
+ * (environment J2P_TILED_NORM=all: every band for itself); J2P_TILED_SPLIT=1 selects the two-part phases that hide the
+ * halo exchange behind the interior launches (measured slower on one GPU, j2p_tiled.hip; kept for A/B on xGMI).  host_cpu_seconds: user + system time the band
  * threads have spent issuing work so far. */
 typedef struct j2p_tiled j2p_tiled;
 int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const unsigned cuts[], unsigned nchannel,

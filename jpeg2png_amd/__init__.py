@@ -81,7 +81,7 @@ C_ABI_SYMBOLS = [
     "j2p_tiled_download", "j2p_tiled_host_cpu_seconds", "j2p_solver_norm_ptr", "j2p_solver_norm_external",
     "j2p_batch_create", "j2p_batch_destroy", "j2p_batch_submit", "j2p_batch_wait",
     "compute", "j2p_compute", "j2p_compute_tiled",
-    "j2p_debug_build", "j2p_solver_debug_violations",
+    "j2p_debug_build", "j2p_solver_debug_violations", "j2p_solver_trace",
 ]
 J2P_OPT_NORM_FOLD, J2P_OPT_JOINT_INWAVE, J2P_OPT_NORM_IN_PROJECT, J2P_OPT_NT_GRADIENT, J2P_OPT_MIXED_PROJECT = 1, 2, 4, 5, 6
 
@@ -361,6 +361,19 @@ class Solver:
         n, site, off = ctypes.c_ulonglong(), ctypes.c_uint(), ctypes.c_ulonglong()
         _check(self._lib.j2p_solver_debug_violations(self._h, ctypes.byref(n), ctypes.byref(site), ctypes.byref(off)))
         return n.value, site.value, off.value
+
+    def trace(self, on=True, fetch=False, max_records=1 << 19):
+        """J2P_TRACE builds (tools/wave_trace.py): switch the per-wavefront records on / off; fetch=True returns the
+        records collected so far as an [n, 4] uint64 array (start, first data, end in 10 ns ticks, id)"""
+        self._lib.j2p_solver_trace.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint,
+                                               ctypes.POINTER(ctypes.c_uint)]
+        if not fetch:
+            _check(self._lib.j2p_solver_trace(self._h, 1 if on else 0, None, 0, None))
+            return None
+        out = np.zeros((max_records, 4), dtype=np.uint64)
+        n = ctypes.c_uint()
+        _check(self._lib.j2p_solver_trace(self._h, 1 if on else 0, out.ctypes.data, max_records, ctypes.byref(n)))
+        return out[: n.value]
 
     def enable_timing(self, every=1):
         """record HIP events around the two phase kernels of every `every`-th iteration (0 = off)."""

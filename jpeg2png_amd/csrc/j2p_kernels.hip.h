@@ -76,6 +76,42 @@ __device__ __forceinline__ void dbg_check(const DbgChan &g, const DbgRange &r, c
 #endif
 
 // ---------------------------------------------------------------------------
+// -DJ2P_TRACE (tools/wave_trace.py; timing tool, never shipped): every wavefront of the two phase kernels leaves
+// one record {start, first data, end} in 10 ns ticks of the constant clock plus its hardware id (XCD, SE, CU, SIMD),
+// so that a launch can be laid out wave by wave: when wavefronts start, how long the first loads take, how long
+// a wavefront lives and how they are spread over the CUs.  Record 0 of the buffer is the append counter.
+// ---------------------------------------------------------------------------
+#ifdef J2P_TRACE
+struct TraceRec {
+        unsigned long long t_start, t_data, t_end, id;    // id = kernel tag << 56 | launch seq << 32 | xcc << 24 | hw_id bits
+};
+__device__ __forceinline__ unsigned long long trace_now() { return wall_clock64(); }
+__device__ __forceinline__ unsigned trace_hwid()
+{
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        return (hw & 0xffffffu) | ((xcc & 0xfu) << 24);
+}
+// slot = the launch's first record (reserved by the host) + the wavefront's index within the launch: no atomic —
+// a counter shared by every wavefront of the chip would serialise their exits at ~12 ns each and stretch the launch
+__device__ __forceinline__ void trace_put(unsigned long long *buf, unsigned cap, unsigned base, unsigned tag, unsigned seq,
+                                          unsigned long long t0, unsigned long long t1, unsigned long long t2)
+{
+        if(!buf || (threadIdx.x & 63) != 0) { return; }
+        const unsigned waves = (blockDim.x + 63) >> 6;
+        const unsigned long long slot = (unsigned long long)base +
+                ((unsigned long long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * waves + (threadIdx.x >> 6);
+        if(slot + 1 >= cap) { return; }
+        TraceRec *r = reinterpret_cast<TraceRec *>(buf) + 1 + slot;
+        r->t_start = t0;
+        r->t_data = t1;
+        r->t_end = t2;
+        r->id = ((unsigned long long)tag << 56) | ((unsigned long long)(seq & 0xffffffu) << 32) | trace_hwid();
+}
+#endif
+
+// ---------------------------------------------------------------------------
 // 8-point orthonormal DCT-II / DCT-III, one lane owns the whole 8-vector.
 // ---------------------------------------------------------------------------
 // sqrt(2/8)*cos(k*pi/16), sqrt(2/8)*sin(k*pi/16), and cos(pi/4) — the values of
@@ -209,6 +245,10 @@ struct Geo {
         // edge ones: 0, nseg - 1).  Plain arithmetic on kernel arguments: a table in memory would put two dependent
         // loads in front of every wavefront's first row fetch
         unsigned seg_off, seg_mul;
+#ifdef J2P_TRACE
+        unsigned long long *trace;   // TraceRec buffer (record 0 unused) or NULL
+        unsigned trace_cap, trace_seq, trace_base;
+#endif
 };
 
 struct GradArgs {
@@ -386,7 +426,10 @@ __device__ __forceinline__ v2f sqrt_fast(v2f x)
 }
 
 constexpr int kStripCols = 124;   // output columns per wavefront strip
-constexpr int kRing = 4;          // row slots = hand-unroll factor of the marching loop (1 channel; 3 otherwise: registers);
+#ifndef J2P_RING
+#define J2P_RING 4
+#endif
+constexpr int kRing = J2P_RING;   // row slots = hand-unroll factor of the marching loop (1 channel; 3 otherwise: registers);
                                   // rows are fetched (slots - 1) trips ahead (3 slots: 12 % slower; 2 or 5 ring turns per
                                   // loop iteration: slower too)
 
@@ -409,9 +452,10 @@ struct SourceTerms {
 // for the flush-denormal mode (one v_rsq_f32, then a coupled Newton step on sqrt and 1/(2 sqrt)
 // and a final residual correction), all packed.  Correctly rounded on that whole range — checked
 // EXHAUSTIVELY against sqrtf() by j2p_sqrt_exhaustive (every float, GPU test).  Not valid for 0.
-__device__ __forceinline__ v2f sqrt_rsq(v2f x)
+// `r` receives the v_rsq_f32 values the root was made of.
+__device__ __forceinline__ v2f sqrt_rsq(v2f x, v2f &r)
 {
-        const v2f r = v2f{__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)};
+        r = v2f{__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)};
         v2f s = x * r;
         v2f h = r * 0.5f;
         const v2f e = pk_fma(-h, s, v2f{0.5f, 0.5f});
@@ -419,6 +463,22 @@ __device__ __forceinline__ v2f sqrt_rsq(v2f x)
         s = pk_fma(s, e, s);
         const v2f d = pk_fma(-s, s, x);
         return pk_fma(d, h, s);
+}
+__device__ __forceinline__ v2f sqrt_rsq(v2f x)
+{
+        v2f r;
+        return sqrt_rsq(x, r);
+}
+// The refined reciprocal of n = sqrt_rsq(x) for the divisions that follow, seeded with the v_rsq_f32 value the root
+// was made of instead of a v_rcp_f32 of its own (two transcendental instructions — 16 issue cycles — less per pixel
+// pair and norm): rsq(x) is 1 / sqrt(x) to 1 ulp and n is sqrt(x) to 1/2 ulp, so the seed is 1 / n to 1.5 ulp; one
+// Newton step squares that error (3e-14, against 1.4e-14 from a v_rcp_f32 seed): the refined value is 1 / n to within
+// its own rounding either way, and the quotient sequence of div_shared — two exact-residual corrections — delivers
+// the correctly rounded quotient from any such reciprocal, i.e. the bits of `/`  (j2p_math_selftest compares).
+__device__ __forceinline__ v2f div_prepare_seeded(v2f d, v2f seed)
+{
+        const v2f e = pk_fma(-d, seed, v2f{1.f, 1.f});
+        return pk_fma(e, seed, seed);
 }
 
 // EXACT_ZERO: result must be sqrtf(x) including x == 0 (the log sums read the norm itself).
@@ -429,9 +489,6 @@ __device__ __forceinline__ v2f sqrt_rsq(v2f x)
 template <bool FAST, bool EXACT_ZERO>
 __device__ __forceinline__ v2f sqrt_pair(v2f x)
 {
-#ifdef J2P_EXP_NOARITH
-        return x * 0.75f + v2f{1.f, 1.f};
-#endif
         if(!FAST) { return v2f{sqrtf(x.x), sqrtf(x.y)}; }
         if(EXACT_ZERO) { return sqrt_fast(x); }
         return sqrt_rsq(x + v2f{0x1p-120f, 0x1p-120f});
@@ -443,6 +500,28 @@ __device__ __forceinline__ v2f divisor_of(v2f n)
         if(!FAST) { return v2f{n.x == 0.f ? 1.f : n.x, n.y == 0.f ? 1.f : n.y}; }   // divide by 1, scale by 0
         if(EXACT_ZERO) { return v2f{fmaxf(n.x, 0x1p-60f), fmaxf(n.y, 0x1p-60f)}; }
         return n;                                                                  // already >= 2^-60
+}
+// what source_terms needs of a sum of squares x: the norm n = sqrtf(x), the divisor d made from it and the refined
+// reciprocal r of d (unscreened path: r is not used)
+template <bool FAST, bool EXACT_ZERO>
+__device__ __forceinline__ void norm_and_reciprocal(v2f x, v2f &n, v2f &d, v2f &r)
+{
+#ifdef J2P_EXP_NOARITH
+        n = x * 0.75f + v2f{1.f, 1.f};
+        d = n;
+        r = n;
+        return;
+#endif
+        if constexpr(FAST && !EXACT_ZERO) {
+                v2f seed;
+                n = sqrt_rsq(x + v2f{0x1p-120f, 0x1p-120f}, seed);
+                d = n;
+                r = div_prepare_seeded(d, seed);
+        } else {
+                n = sqrt_pair<FAST, EXACT_ZERO>(x);
+                d = divisor_of<FAST, EXACT_ZERO>(n);
+                r = FAST ? div_prepare(d) : d;
+        }
 }
 template <bool FAST, int N>
 __device__ __forceinline__ void div_n(const v2f (&x)[N], v2f d, v2f r, v2f (&q)[N])
@@ -460,6 +539,28 @@ __device__ __forceinline__ void div_n(const v2f (&x)[N], v2f d, v2f r, v2f (&q)[
         }
 }
 
+// The four TGV2 numerators of a pixel pair (compute.c:165-182): s + gxx, gyy + s, s (its sign goes onto the quotient)
+// and the own term 2 gxx + 2 s + 2 gyy.  On the screened path every operand is a multiple of 2^-44 below 2^43, so
+// doubling commutes with every rounding involved — (2 gxx + 2 s) + 2 gyy == 2 ((gxx + s) + gyy), and gxx + s is the
+// first numerator (float addition commutes) — and the factor 2 moves through the division and onto the weight:
+// a2 * -((2 m) / n) == (2 a2) * -(m / n), all of it exact scaling.  Three multiplications and one addition less
+// per pixel; the unscreened path (subnormal operands possible) keeps the reference's expression.
+template <bool FAST>
+__device__ __forceinline__ void tgv_numerators(v2f xx, v2f sy, v2f yy, v2f (&num)[4])
+{
+        num[0] = sy + xx;
+        num[1] = yy + sy;
+        num[2] = sy;
+        if(FAST) { num[3] = num[0] + yy; }
+        else { num[3] = 2.f * xx + 2.f * sy + 2.f * yy; }
+}
+template <bool FAST>
+__device__ __forceinline__ v2f own_term(v2f a2, v2f q3)
+{
+        if(FAST) { return (2.f * a2) * -q3; }       // 2 a2: exact and wave-uniform (hoisted out of the march)
+        return a2 * -q3;
+}
+
 // Source terms of one image row for a lane's column pair.  gx,gy: forward differences of
 // this row, gxp,gyp: of the row above.  m_hx / m_hy zero the second differences on the first
 // column / first row (compute.c:137-143).  tv / tv2 receive the log sums when `log_row`.
@@ -469,13 +570,16 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
                                              bool log_row, double &tv, double &tv2, SourceTerms<NCH, TGV> &s)
 {
         // ---- TV (compute.c:84-104) ----
-        v2f n1 = v2f{0.f, 0.f};
+        // (the reference starts the sum at 0.f; a square is never -0, so 0.f + gx * gx is gx * gx bit for bit)
+        v2f n1 = gx[0] * gx[0];
+        n1 += gy[0] * gy[0];
 #pragma unroll
-        for(int c = 0; c < NCH; c++) {
+        for(int c = 1; c < NCH; c++) {
                 n1 += gx[c] * gx[c];
                 n1 += gy[c] * gy[c];
         }
-        n1 = sqrt_pair<FAST, LOG>(n1);
+        v2f d1, r1;
+        norm_and_reciprocal<FAST, LOG>(n1, n1, d1, r1);
         if(LOG && log_row) {
                 tv += (double)(a_tv * n1.x);
                 tv += (double)(a_tv * n1.y);
@@ -483,9 +587,7 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
         // A pixel with zero norm contributes nothing (compute.c:97).  Screened path: n == 0 implies
         // every numerator is exactly 0 (no square can underflow), so any positive divisor gives 0.
         // Unscreened path: divide by 1, scale by 0.
-        const v2f d1 = divisor_of<FAST, LOG>(n1);
         const v2f a1 = FAST ? v2f{a_tv, a_tv} : v2f{n1.x == 0.f ? 0.f : a_tv, n1.y == 0.f ? 0.f : a_tv};
-        const v2f r1 = FAST ? div_prepare(d1) : d1;
 #pragma unroll
         for(int c = 0; c < NCH; c++) {
                 if(NCH > 1) { __builtin_amdgcn_sched_barrier(0); }   // one channel at a time: bounds the live ranges
@@ -509,34 +611,31 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
                         const v2f gxy = MASKED ? (gx[c] - gxp[c]) * m_hy : gx[c] - gxp[c];
                         yy[c] = MASKED ? (gy[c] - gyp[c]) * m_hy : gy[c] - gyp[c];
                         sy[c] = (gxy + gyx) * 0.5f;                     // (g_xy + g_yx) / 2.
-                        n2 += xx[c] * xx[c] + 2.f * (sy[c] * sy[c]) + yy[c] * yy[c];
+                        const v2f term = xx[c] * xx[c] + 2.f * (sy[c] * sy[c]) + yy[c] * yy[c];
+                        if(c == 0) { n2 = term; }                       // 0.f + term is term: never -0
+                        else { n2 += term; }
                 }
-                n2 = sqrt_pair<FAST, LOG>(n2);
+                v2f d2, r2;
+                norm_and_reciprocal<FAST, LOG>(n2, n2, d2, r2);
                 if(LOG && log_row) {
                         tv2 += (double)(a_tgv * n2.x);
                         tv2 += (double)(a_tgv * n2.y);
                 }
-                const v2f d2 = divisor_of<FAST, LOG>(n2);
                 const v2f a2 = FAST ? v2f{a_tgv, a_tgv}
                                     : v2f{n2.x == 0.f ? 0.f : a_tgv, n2.y == 0.f ? 0.f : a_tgv};   // compute.c:158
-#ifdef J2P_EXP_NOARITH
-                const v2f r2 = d2;
-#else
-                const v2f r2 = FAST ? div_prepare(d2) : d2;
-#endif
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
                         if(NCH > 1) { __builtin_amdgcn_sched_barrier(0); }
                         // a2 * (expr / n2): division first (compute.c:165-182)
                         // the two negative numerators are divided as positives and the sign goes onto the quotient:
                         // (-v) / n == -(v / n) bit for bit, in the IEEE and in the short sequence alike
-                        const v2f num[4] = {sy[c] + xx[c], yy[c] + sy[c], sy[c], 2.f * xx[c] + 2.f * sy[c] + 2.f * yy[c]};
-                        v2f q[4];
+                        v2f num[4], q[4];
+                        tgv_numerators<FAST>(xx[c], sy[c], yy[c], num);
                         div_n<FAST, 4>(num, d2, r2, q);
                         const v2f tA = a2 * q[0];                                       // to (x-1,y), (x+1,y)
                         s.B[c] = a2 * q[1];                                             // to (x,y-1), (x,y+1)
                         const v2f tC = a2 * -q[2];                                      // to (x+1,y-1), (x-1,y+1)
-                        s.O[c] = a2 * -q[3];                                            // own
+                        s.O[c] = own_term<FAST>(a2, q[3]);                              // own
                         s.A[c] = tA;
                         s.CL[c] = left_of(tC);
                         s.CR[c] = right_of(tC);
@@ -571,22 +670,23 @@ __device__ __forceinline__ void source_terms_joint(int cidx, int lane, int parit
         mine[1] = gy * gy;
         mine[2] = tq;
         __syncthreads();
-        v2f n1 = v2f{0.f, 0.f}, n2 = v2f{0.f, 0.f};
+        // (sums start with channel 0's terms: 0.f + a square is the square, see source_terms)
+        v2f n1 = xchg[((size_t)(parity * J) * 64 + lane) * 3], n2 = xchg[((size_t)(parity * J) * 64 + lane) * 3 + 2];
+        n1 += xchg[((size_t)(parity * J) * 64 + lane) * 3 + 1];
 #pragma unroll
-        for(int c = 0; c < J; c++) {
+        for(int c = 1; c < J; c++) {
                 const v2f *o = xchg + ((size_t)(parity * J + c) * 64 + lane) * 3;
                 n1 += o[0];
                 n1 += o[1];
                 n2 += o[2];
         }
-        n1 = sqrt_pair<FAST, LOG>(n1);
+        v2f d1, r1;
+        norm_and_reciprocal<FAST, LOG>(n1, n1, d1, r1);
         if(LOG && log_row) {
                 tv += (double)(a_tv * n1.x);
                 tv += (double)(a_tv * n1.y);
         }
-        const v2f d1 = divisor_of<FAST, LOG>(n1);
         const v2f a1 = FAST ? v2f{a_tv, a_tv} : v2f{n1.x == 0.f ? 0.f : a_tv, n1.y == 0.f ? 0.f : a_tv};
-        const v2f r1 = FAST ? div_prepare(d1) : d1;
         {
                 const v2f num[3] = {a1 * gx, a1 * gy, a1 * -(gx + gy)};
                 v2f q[3];
@@ -596,21 +696,20 @@ __device__ __forceinline__ void source_terms_joint(int cidx, int lane, int parit
                 s.tvo[0] = q[2];
         }
         if(TGV) {
-                n2 = sqrt_pair<FAST, LOG>(n2);
+                v2f d2, r2;
+                norm_and_reciprocal<FAST, LOG>(n2, n2, d2, r2);
                 if(LOG && log_row) {
                         tv2 += (double)(a_tgv * n2.x);
                         tv2 += (double)(a_tgv * n2.y);
                 }
-                const v2f d2 = divisor_of<FAST, LOG>(n2);
                 const v2f a2 = FAST ? v2f{a_tgv, a_tgv} : v2f{n2.x == 0.f ? 0.f : a_tgv, n2.y == 0.f ? 0.f : a_tgv};
-                const v2f r2 = FAST ? div_prepare(d2) : d2;
-                const v2f num[4] = {sy + xx, yy + sy, sy, 2.f * xx + 2.f * sy + 2.f * yy};   // signs: see source_terms
-                v2f q[4];
+                v2f num[4], q[4];
+                tgv_numerators<FAST>(xx, sy, yy, num);                                  // signs: see source_terms
                 div_n<FAST, 4>(num, d2, r2, q);
                 const v2f tC = a2 * -q[2];
                 s.A[0] = a2 * q[0];
                 s.B[0] = a2 * q[1];
-                s.O[0] = a2 * -q[3];
+                s.O[0] = own_term<FAST>(a2, q[3]);
                 s.CL[0] = left_of(tC);
                 s.CR[0] = right_of(tC);
         }
@@ -756,6 +855,10 @@ void k_gradient(GradArgs a)
         const int wcol = J == 1 ? (int)bx * (int)(blockDim.x >> 6) + wave : (int)bx;   // J == 1: blockDim.x / 64 strips per workgroup
         const int cbase = J == 1 ? 0 : wave;                    // first channel of this wavefront
         if(wcol >= (int)a.geo.ntx) { return; }
+#ifdef J2P_TRACE
+        const unsigned long long tr_start = trace_now();
+        unsigned long long tr_data = 0;
+#endif
         const int W = (int)a.geo.W, H = (int)a.geo.H;
         const int rows = (int)a.geo.rows, row0 = (int)a.geo.row0;
         const int t0 = (int)(bseg * a.geo.rpw);                // band-local target rows [t0, t1)
@@ -923,6 +1026,10 @@ void k_gradient(GradArgs a)
                         unsigned b0;
                         make_y(free_tag, t0 - 2, mc, mp, ym, bm);
                         make_y(free_tag, t0 - 1, RC[0], RP[0], Y[0], b0);
+#ifdef J2P_TRACE
+                        // (the screen flag depends on the loaded rows: the stamp cannot be taken before they arrived)
+                        if((bm | b0) != 0xffffffffu) { tr_data = trace_now(); }
+#endif
                         bad2 = bm;
                         bad1 = b0;
                         diffs(free_tag, row0 + t0 - 2, ym, Y[0], GX[R - 1], GY[R - 1]);
@@ -1072,6 +1179,10 @@ void k_gradient(GradArgs a)
                         a.part_tv[2 * w + 1] = tv2_acc;
                 }
         }
+#ifdef J2P_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wavefront's stores have been acknowledged
+        trace_put(a.geo.trace, a.geo.trace_cap, a.geo.trace_base, 1u, a.geo.trace_seq, tr_start, tr_data, trace_now());
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1204,28 +1315,45 @@ __global__ __launch_bounds__(256) void k_norm_whole(const double *part, unsigned
 // add registers of one lane, the levels below move partner values between lanes.  Identical additions, hence the
 // identical double, as tree_sum_lds.  n <= 1024.  (Padding P up to 64 only adds exact zeros to sums that are >= 0.)
 constexpr unsigned kWaveTreeMax = 1024;
-__device__ __forceinline__ float norm_tree_wave(const double *rowsum, unsigned n, unsigned nch, unsigned c, int lane)
+// in two steps, so that the caller can put its own loads in flight between them: the row sums are requested first,
+// the planes' rows right behind them, and the tree runs while those are still on their way (one memory round trip
+// in front of the projection's arithmetic instead of two: 512x512 4:2:0 k_project 2.96 -> see profiles/ us to first data)
+struct WaveTreeRows {
+        double v[kWaveTreeMax / 64];
+        unsigned P;
+};
+__device__ __forceinline__ void norm_tree_load(const double *rowsum, unsigned n, unsigned nch, unsigned c, int lane, WaveTreeRows &t)
 {
         unsigned P = 64;
         while(P < n) { P <<= 1; }
-        double v[kWaveTreeMax / 64];
+        t.P = P;
 #pragma unroll
         for(unsigned j = 0; j < kWaveTreeMax / 64; j++) {
                 const unsigned i = (unsigned)lane + 64 * j;
-                v[j] = (j * 64 < P && i < n) ? rowsum[(size_t)i * nch + c] : 0.;
+                t.v[j] = (j * 64 < P && i < n) ? rowsum[(size_t)i * nch + c] : 0.;
         }
+}
+__device__ __forceinline__ float norm_tree_reduce(WaveTreeRows &t)
+{
+        const unsigned P = t.P;
 #pragma unroll
         for(unsigned half = kWaveTreeMax / 128; half >= 1; half >>= 1) {      // s = 64 * half
                 if(64 * half < P) {
 #pragma unroll
-                        for(unsigned j = 0; j < half; j++) { v[j] = v[j] + v[j + half]; }
+                        for(unsigned j = 0; j < half; j++) { t.v[j] = t.v[j] + t.v[j + half]; }
                 }
         }
-        double m = v[0];
+        double m = t.v[0];
 #pragma unroll
         for(int off = 32; off > 0; off >>= 1) { m = m + __shfl_down(m, off, 64); }
         m = __shfl(m, 0, 64);
         return sqrtf((float)m);                                               // compute.c:206
+}
+__device__ __forceinline__ float norm_tree_wave(const double *rowsum, unsigned n, unsigned nch, unsigned c, int lane)
+{
+        WaveTreeRows t;
+        norm_tree_load(rowsum, n, nch, c, lane, t);
+        return norm_tree_reduce(t);
 }
 
 // ---------------------------------------------------------------------------
@@ -1460,6 +1588,10 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
         float *const tp = sh.tp;
         float *const qs = sh.qs, *const qq = sh.qq, *const rqq = sh.rqq, *const rq = sh.rq;
         int &q_fast = sh.q_fast;
+#ifdef J2P_TRACE
+        const unsigned long long tr_start = trace_now();
+        unsigned long long tr_data = 0;
+#endif
 
         const unsigned zi = blockIdx.z;
         const int c = (int)a.chan_of_z[zi];
@@ -1488,7 +1620,8 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
         // (NIP is a template parameter because the tree costs two registers: 82 instead of 80, i.e. five instead of
         // six wavefronts per SIMD, 1.3 us per launch at 4096^2, where it is not used)
         float norm;
-        if constexpr(NIP) { norm = norm_tree_wave(a.norm_rowsums, a.norm_rows, a.norm_nch, (unsigned)c, lane); }
+        WaveTreeRows tree;
+        if constexpr(NIP) { norm_tree_load(a.norm_rowsums, a.norm_rows, a.norm_nch, (unsigned)c, lane, tree); }   // reduced below, behind the row loads
         else { norm = a.norm[c]; }
         const unsigned cx = sx * 64 + lane;                           // coefficient column of this lane
         const unsigned cy0 = (a.geo.row0 / hs) + by * 8;              // first coefficient row (global)
@@ -1533,6 +1666,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                         else { gv[r] = k.grad[base + (size_t)r * W]; }
                 }
         }
+        if constexpr(NIP) { norm = norm_tree_reduce(tree); }
         if(threadIdx.x < 64) {
                 const float q = k.q[threadIdx.x];
                 qs[threadIdx.x] = q;
@@ -1626,6 +1760,10 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
 #pragma unroll
                 for(int r = 0; r < 8; r++) { mean_old[r] = v[r]; }
         }
+#ifdef J2P_TRACE
+        asm volatile("; stepped pixels exist" ::"v"(v[0]) : "memory");    // (needs the loads: the stamp cannot move above them)
+        tr_data = trace_now();
+#endif
 
         // ---- forward DCT: columns pass (lane = column), transpose, rows pass (lane = block row) ----
         fdct8(v);
@@ -1777,6 +1915,10 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                         if(lane == 0) { a.part_prob[(size_t)c * a.strips_per_chan + strip] = dist; }
                 }
         }
+#ifdef J2P_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        trace_put(a.geo.trace, a.geo.trace_cap, a.geo.trace_base, 2u, a.geo.trace_seq, tr_start, tr_data, trace_now());
+#endif
 }
 
 // NIP: the norm comes from norm_tree_wave (ProjArgs::norm_rowsums) instead of ProjArgs::norm
@@ -1962,6 +2104,26 @@ __global__ __launch_bounds__(256) void k_math_selftest(size_t n, unsigned seed, 
                 const v2f si = v2f{sqrtf(sx.x), sqrtf(sx.y)};
                 bad_sqrt += __builtin_bit_cast(unsigned, sf.x) != __builtin_bit_cast(unsigned, si.x);
                 bad_sqrt += __builtin_bit_cast(unsigned, sf.y) != __builtin_bit_cast(unsigned, si.y);
+                // the norm -> reciprocal -> quotient chain of source_terms: root through v_rsq_f32, the reciprocal
+                // refined from that same v_rsq_f32 value (div_prepare_seeded), quotients against `/` by the IEEE root.
+                // Radicands as the kernel sees them: 0 or in [2^-88, 2^87); numerators 0 or within 2^45 of the norm.
+                {
+                        v2f rx = v2f{fabsf(rnd_float(h2 ^ h0, 39, 213)), fabsf(rnd_float(h3 ^ h1, 39, 213))};
+                        if((h2 & 0xff) == 7) { rx.x = 0.f; }
+                        v2f nn, dd, rr;
+                        norm_and_reciprocal<true, false>(rx, nn, dd, rr);
+                        const v2f ni = v2f{rx.x == 0.f ? 0x1p-60f : sqrtf(rx.x), rx.y == 0.f ? 0x1p-60f : sqrtf(rx.y)};
+                        bad_sqrt += __builtin_bit_cast(unsigned, nn.x) != __builtin_bit_cast(unsigned, ni.x);
+                        bad_sqrt += __builtin_bit_cast(unsigned, nn.y) != __builtin_bit_cast(unsigned, ni.y);
+                        // numerator = norm * a random factor in [2^-40, 2^2) (differences never exceed their norm by much)
+                        v2f num = v2f{ni.x * rnd_float(h1 ^ h3, 87, 128), ni.y * rnd_float(h0 ^ h2, 87, 128)};
+                        if((h1 & 0x7f) == 3) { num.x = 0.f; }
+                        if((h0 & 0x7f) == 5) { num.y = ni.y; }
+                        const v2f qs = div_shared(num, dd, rr);
+                        const v2f qd = v2f{num.x / ni.x, num.y / ni.y};
+                        bad_div += __builtin_bit_cast(unsigned, qs.x) != __builtin_bit_cast(unsigned, qd.x) && !(qs.x == 0.f && qd.x == 0.f);
+                        bad_div += __builtin_bit_cast(unsigned, qs.y) != __builtin_bit_cast(unsigned, qd.y) && !(qs.y == 0.f && qd.y == 0.f);
+                }
         }
         if(blockIdx.x == 0 && threadIdx.x == 0) {
                 // the zero-norm divisor of sqrt_pair<true, false>

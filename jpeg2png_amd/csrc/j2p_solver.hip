@@ -104,6 +104,9 @@ struct j2p_solver {
         bool phase_log = false;         // the gradient phase of the running iteration was issued with logging
         bool mixed_project = true;      // small canvases: all samplings in one projection launch (J2P_OPT_MIXED_PROJECT)
         unsigned long long *dbg_counters = nullptr;   // J2P_DEBUG builds: [0] address violations, [1] first site, [2] first offset
+        unsigned long long *trace = nullptr;          // J2P_TRACE builds: wave records (tools/wave_trace.py)
+        unsigned trace_cap = 0, trace_used = 0;      // records reserved by the launches so far
+        bool trace_on = false;
         bool norm_ready = false; // the gradient launch of this iteration also produced norm[]
         bool norm_by_project = false;   // ... or left level-1 row sums that k_project reduces itself
         unsigned *tickets = nullptr;     // device: [ntr_local] per-tile-row arrival counters + [1] finished-rows counter
@@ -366,6 +369,12 @@ Geo geo_of(const j2p_solver *s)
         g.rpw = s->rpw;
         g.seg_off = 0;
         g.seg_mul = 1;
+#ifdef J2P_TRACE
+        g.trace = s->trace_on ? s->trace : nullptr;
+        g.trace_cap = s->trace_cap;
+        g.trace_seq = s->iter;
+        g.trace_base = s->trace_used;
+#endif
         return g;
 }
 
@@ -518,6 +527,12 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         }
         if(part != 2) { mark(s); }
         HIP_TRY(hipGetLastError());
+#ifdef J2P_TRACE
+        if(s->trace_on) {       // one record per wavefront of the launch (J == 1: 4 strips per workgroup; joint: one strip)
+                const bool per_channel = s->nch > 1 && !s->joint_inwave;
+                s->trace_used += (per_channel ? s->ntx * s->nch : (s->ntx + 3) / 4 * 4) * nseg_launch;
+        }
+#endif
         if(part == 1) {
                 s->interior_done = true;
                 return J2P_OK;
@@ -561,6 +576,7 @@ int do_rowsums(j2p_solver *s)
 // channel (they hold the rows the neighbours need); J2P_PROJECT_INTERIOR (2) = the rest, ends the iteration
 int do_phase_project(j2p_solver *s, bool log, int part = 0)
 {
+        const hipStream_t st = s->stream;
         if(!s->grad_done) { return fail(J2P_ESTATE, "phase_project called before phase_gradient"); }
         if(s->rowsums_pending) { return fail(J2P_ESTATE, "phase_project before j2p_solver_phase_rowsums"); }
         // the two phases of an iteration must agree on logging: where the norm is reduced depends on it
@@ -573,7 +589,7 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
                 // the norm is already there, or every wavefront of k_project reduces the row sums itself
         } else if(s->fold) {
                 // level 1 came with the gradient launch (band solvers: the caller has gathered all bands' row sums)
-                hipLaunchKernelGGL(k_norm_finish, dim3(s->nch), dim3(256), P * sizeof(double), s->stream,
+                hipLaunchKernelGGL(k_norm_finish, dim3(s->nch), dim3(256), P * sizeof(double), st,
                                    (const double *)s->rowsum_all, s->ntr_global, s->nch, s->norm);
         } else if(s->whole) {
                 // stage as many of the partials at once as the CU's LDS holds (P <= 4096)
@@ -582,10 +598,10 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
                         stage = s->ntr_local * s->ntx;
                         if((P + stage) * sizeof(double) > kNormLdsBytes) { stage = kNormLdsBytes / sizeof(double) - P; }
                 }
-                hipLaunchKernelGGL(k_norm_whole, dim3(s->nch), dim3(256), (P + stage) * sizeof(double), s->stream,
+                hipLaunchKernelGGL(k_norm_whole, dim3(s->nch), dim3(256), (P + stage) * sizeof(double), st,
                                    (const double *)s->part_g2, s->ntx, s->ntr_local, s->nch, s->norm, stage);
         } else {
-                hipLaunchKernelGGL(k_norm_finish, dim3(s->nch), dim3(256), P * sizeof(double), s->stream,
+                hipLaunchKernelGGL(k_norm_finish, dim3(s->nch), dim3(256), P * sizeof(double), st,
                                    (const double *)s->rowsum_all, s->ntr_global, s->nch, s->norm);
         }
         ProjArgs a;
@@ -622,9 +638,12 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
                 }
                 if(max_strips) {
                         const dim3 grid((max_strips + 3) / 4, 1, s->nch);
-                        if(log) { hipLaunchKernelGGL((k_project_mixed<true, false>), grid, dim3(256), 0, s->stream, a); }
-                        else if(s->norm_by_project) { hipLaunchKernelGGL((k_project_mixed<false, true>), grid, dim3(256), 0, s->stream, a); }
-                        else { hipLaunchKernelGGL((k_project_mixed<false, false>), grid, dim3(256), 0, s->stream, a); }
+                        if(log) { hipLaunchKernelGGL((k_project_mixed<true, false>), grid, dim3(256), 0, st, a); }
+                        else if(s->norm_by_project) { hipLaunchKernelGGL((k_project_mixed<false, true>), grid, dim3(256), 0, st, a); }
+                        else { hipLaunchKernelGGL((k_project_mixed<false, false>), grid, dim3(256), 0, st, a); }
+#ifdef J2P_TRACE
+                        if(s->trace_on) { s->trace_used += grid.x * grid.z * 4; }
+#endif
                 }
         } else {
         // one launch per sampling class present (usually: luma 1x1, both chroma 2x2)
@@ -647,20 +666,26 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
         // has the register-resident path that carries the hint)
 #define J2P_LAUNCH_PROJECT(WS_, HS_)                                                               \
         do {                                                                                       \
-                if(log) { hipLaunchKernelGGL((k_project<true, WS_, HS_>), grid, dim3(256), 0, s->stream, a); }  \
-                else if(s->norm_by_project) { hipLaunchKernelGGL((k_project<false, WS_, HS_, 0, true>), grid, dim3(256), 0, s->stream, a); } \
-                else { hipLaunchKernelGGL((k_project<false, WS_, HS_>), grid, dim3(256), 0, s->stream, a); }    \
+                if(log) { hipLaunchKernelGGL((k_project<true, WS_, HS_>), grid, dim3(256), 0, st, a); }  \
+                else if(s->norm_by_project) { hipLaunchKernelGGL((k_project<false, WS_, HS_, 0, true>), grid, dim3(256), 0, st, a); } \
+                else { hipLaunchKernelGGL((k_project<false, WS_, HS_>), grid, dim3(256), 0, st, a); }    \
         } while(0)
                 if(ws == 1 && hs == 1 && s->nt >= 1 && !inwave_nt_off && !log && !s->norm_by_project) {
-                        if(s->nt >= 3) { hipLaunchKernelGGL((k_project<false, 1, 1, 3>), grid, dim3(256), 0, s->stream, a); }
-                        else if(s->nt == 2) { hipLaunchKernelGGL((k_project<false, 1, 1, 2>), grid, dim3(256), 0, s->stream, a); }
-                        else { hipLaunchKernelGGL((k_project<false, 1, 1, 1>), grid, dim3(256), 0, s->stream, a); }
+                        if(s->nt >= 3) { hipLaunchKernelGGL((k_project<false, 1, 1, 3>), grid, dim3(256), 0, st, a); }
+                        else if(s->nt == 2) { hipLaunchKernelGGL((k_project<false, 1, 1, 2>), grid, dim3(256), 0, st, a); }
+                        else { hipLaunchKernelGGL((k_project<false, 1, 1, 1>), grid, dim3(256), 0, st, a); }
                 }
                 else if(ws == 1 && hs == 1) { J2P_LAUNCH_PROJECT(1, 1); }
                 else if(ws == 2 && hs == 2) { J2P_LAUNCH_PROJECT(2, 2); }
                 else if(ws == 2 && hs == 1) { J2P_LAUNCH_PROJECT(2, 1); }
                 else if(ws == 1 && hs == 2) { J2P_LAUNCH_PROJECT(1, 2); }
                 else { J2P_LAUNCH_PROJECT(0, 0); }
+#ifdef J2P_TRACE
+                if(s->trace_on) {
+                        s->trace_used += grid.x * grid.z * 4;
+                        a.geo.trace_base = s->trace_used;       // the next sampling class's launch
+                }
+#endif
 #undef J2P_LAUNCH_PROJECT
         }
         }
@@ -738,6 +763,7 @@ void j2p_solver_destroy(j2p_solver *s)
         pool_give(s->device, s->arena, s->arena_bytes);
         (void)hipFree(s->logsums);
         (void)hipFree(s->log_band);
+        (void)hipFree(s->trace);
         for(hipEvent_t e : s->ev) { (void)hipEventDestroy(e); }
         if(s->own_stream && s->stream) { (void)hipStreamDestroy(s->stream); }
         delete s;
@@ -886,6 +912,11 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 // strips, three such planes on three streams 124.5 -> 131.3 Gpx-it/s, 1024^2 22.5 -> 21.4 us; 2048^2 and
                 // larger keep 16 rows and their times.  A limit of 4096 costs the 512^2 image 5 %.)
                 while(g > 4 && (unsigned long long)per_strip_row * ((H + g - 1) / g) < 2048ull) { g >>= 1; }
+                // (timing experiments: J2P_RPW = 4 / 8 / 16 / 32 / 64 for every solver of the process; whole canvases only above 16)
+                if(const char *env = getenv("J2P_RPW")) {
+                        const int v = atoi(env);
+                        if(v == 4 || v == 8 || v == 16 || v == 32 || v == 64) { g = (unsigned)v; }
+                }
                 s->rpw = g;
         }
         s->nseg = (s->rows + s->rpw - 1) / s->rpw;
@@ -1052,6 +1083,35 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
         default: return fail(J2P_EINVAL, "unknown option %d", option);
         }
         return J2P_OK;
+}
+
+int j2p_solver_trace(j2p_solver *s, int on, unsigned long long *host_out, unsigned max_records, unsigned *n)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+#ifdef J2P_TRACE
+        DeviceGuard guard(s->device);
+        constexpr unsigned kCap = 1u << 19;                     // records (16 MiB)
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        if(!s->trace) {
+                HIP_TRY(dev_malloc((void **)&s->trace, (size_t)kCap * 32));
+                HIP_TRY(hipMemset(s->trace, 0, (size_t)kCap * 32));
+                s->trace_cap = kCap;
+        }
+        if(host_out && n) {
+                unsigned long long count = s->trace_used;
+                if(count > s->trace_cap - 1) { count = s->trace_cap - 1; }
+                if(count > max_records) { count = max_records; }
+                HIP_TRY(hipMemcpy(host_out, s->trace + 4, (size_t)count * 32, hipMemcpyDeviceToHost));
+                *n = (unsigned)count;
+                HIP_TRY(hipMemset(s->trace, 0, (size_t)(count + 1) * 32));     // start over
+                s->trace_used = 0;
+        }
+        s->trace_on = on != 0;
+        return J2P_OK;
+#else
+        (void)on; (void)host_out; (void)max_records; (void)n;
+        return fail(J2P_ESTATE, "not a J2P_TRACE build");
+#endif
 }
 
 int j2p_debug_build(void)

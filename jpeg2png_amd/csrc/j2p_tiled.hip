@@ -13,10 +13,15 @@
 //      own norm word; the other bands wait for that ONE event.  2 (N - 1) cross-device dependencies per iteration
 //      instead of N (N - 1), the same arithmetic: the result does not depend on the number of bands.
 //      (J2P_TILED_NORM=all: every band reduces for itself, as in round 2 — one hop less, N - 1 waits per band.)
-//   2. the next gradient reaches 2 rows into the neighbouring bands (TGV2, compute.c:137-143,165-183): the
-//      projection does the band's first and last block row first and records an event; the neighbours pull those
-//      rows into their halo rows after the interior of THEIR next gradient phase, which reads no halo row, so the
-//      copy and the cross-GPU wait hide behind roughly two thirds of an iteration of compute.
+//   2. the next gradient reaches 2 rows into the neighbouring bands (TGV2, compute.c:137-143,165-183): a band
+//      records an event behind its projection and the neighbours pull its two edge rows into their halo rows in
+//      front of their next gradient phase (one small copy kernel).  A band's iteration is then four launches
+//      (copy, gradient, [norm,] projection).  The split schedule — the projection does the band's first and last
+//      block row first, the neighbours pull after the INTERIOR of their next gradient phase and run the two edge
+//      segments last, so that the copy and the cross-GPU wait hide behind compute — remains behind J2P_TILED_SPLIT=1:
+//      measured on a band that has a GPU to itself its three extra launches (a launch boundary and a nearly empty
+//      chip each) cost more than the wait they hide: 292 against 276 us per iteration, 245 for the same rows solved
+//      whole (profiles/r03_band_alone.jsonl).
 //
 // Ordering between GPUs is by HIP events only (kernel-boundary visibility); no flag is polled on a device.
 // Host side: a band thread that needs another band's event sleeps on a condition variable until that event has
@@ -75,6 +80,7 @@ struct j2p_tiled {
         bool carried_valid = true;             // false after iterations run without logging (their prob sums were not kept)
         bool logging = false;                  // the band solvers currently run their logging kernels
         bool norm_by_root = true;              // one band reduces ||g|| for all (default); false: every band for itself
+        bool want_split = false;               // two-part phases (interior / edges) on bands tall enough (J2P_TILED_SPLIT=1)
         unsigned root = 0;
         // command hand-over to the band threads
         std::mutex lock;
@@ -172,7 +178,8 @@ int band_iterations(j2p_tiled *t, unsigned b, unsigned n, bool log)
         Band *root = t->bands[t->root];
         for(unsigned i = 0; i < n; i++) {
                 const uint64_t it = t->iter + i;
-                // ---- phase A; the rows of the neighbours arrive behind the interior segments ----
+                // ---- phase A.  Default: the neighbours' rows first, then ONE gradient launch.  Split schedule
+                // (J2P_TILED_SPLIT=1): the interior segments first, the rows and the two edge segments behind them ----
                 if(me->split) {
                         BAND_TRY(j2p_solver_phase_gradient_part(me->solver, J2P_GRADIENT_INTERIOR, nullptr));
                         if(it > 0) { BAND_TRY(pull_halos(t, b, it - 1)); }
@@ -200,7 +207,7 @@ int band_iterations(j2p_tiled *t, unsigned b, unsigned n, bool log)
                         BAND_TRY(wait_for(t, me, root, kNorm, it));
                         BAND_TRY(j2p_solver_norm_external(me->solver));
                 }
-                // ---- phase B, edge block rows first ----
+                // ---- phase B (split schedule: the edge block rows, which the neighbours pull, first) ----
                 if(me->split) {
                         BAND_TRY(j2p_solver_phase_project_part(me->solver, J2P_PROJECT_BOUNDARY));
                         BAND_TRY(record(t, me, kEdge, it));
@@ -339,6 +346,8 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                 const char *env = getenv("J2P_TILED_NORM");
                 t->norm_by_root = !(env && strcmp(env, "all") == 0);
                 t->root = 0;
+                env = getenv("J2P_TILED_SPLIT");
+                if(env) { t->want_split = atoi(env) != 0; }
         }
         int prev = -1;
         (void)hipGetDevice(&prev);
@@ -391,7 +400,7 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                 j2p_solver_halo_rows(bd->solver, 0, &bd->rows[0]);
                 j2p_solver_halo_rows(bd->solver, 1, &bd->rows[1]);
                 // the two-part phases need an interior: three 16-row segments and three block rows of every channel
-                bd->split = nband > 1 && bd->row1 - bd->row0 >= 3 * align && bd->row1 - bd->row0 >= 3 * J2P_TILE_ROWS;
+                bd->split = t->want_split && nband > 1 && bd->row1 - bd->row0 >= 3 * align && bd->row1 - bd->row0 >= 3 * J2P_TILE_ROWS;
                 for(int k = 0; k < 2 && rc == J2P_OK; k++) {
                         if(hipEventCreateWithFlags(&bd->ev_grad[k], hipEventDisableTiming) != hipSuccess ||
                            hipEventCreateWithFlags(&bd->ev_edge[k], hipEventDisableTiming) != hipSuccess ||

@@ -147,16 +147,24 @@ def test_unlogged_then_logged_runs_report_nan_for_the_unknown_distance(lib):
     np.testing.assert_allclose(rows[1:], want_rows[5:], rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("mode", ["root", "all"])
-def test_both_norm_schedules_give_the_same_bits(lib, mode, monkeypatch):
-    """one band reducing ||g|| for all (default) and every band reducing for itself (J2P_TILED_NORM=all): same tree
-    over the same array, so the same planes"""
+@pytest.mark.parametrize("norm,split", [("root", "0"), ("all", "0"), ("root", "1"), ("all", "1")])
+def test_every_schedule_of_the_tiling_gives_the_same_bits(lib, norm, split, monkeypatch):
+    """one band reducing ||g|| for all (default) or every band for itself (J2P_TILED_NORM=all); one gradient and one
+    projection launch per band and iteration (default) or the split phases that hide the halo exchange behind the
+    interior launches (J2P_TILED_SPLIT=1): the same tree over the same array and the same kernels on the same rows,
+    so the same planes and the same CSV rows"""
     import jpeg2png_amd as j
     planes = make_case(264, 410, "420", 10, seed=78)
     pws = [0.001] * 3
-    want, _ = whole_canvas(planes, 0.3, pws, 10)
-    monkeypatch.setenv("J2P_TILED_NORM", mode)
+    want, want_rows = whole_canvas(planes, 0.3, pws, 10, log=True)
+    monkeypatch.setenv("J2P_TILED_NORM", norm)
+    monkeypatch.setenv("J2P_TILED_SPLIT", split)
     with j.TiledSolver(planes, 0.3, pws, 10, devices=[0] * 5) as t:
         t.run(10)
         for c in range(3):
-            assert bit_equal(t.download(c), want[c]), f"{mode}: channel {c}"
+            assert bit_equal(t.download(c), want[c]), f"{norm}/{split}: channel {c}"
+        t.reset()
+        rows = t.run(10, log=True)
+        for c in range(3):
+            assert bit_equal(t.download(c), want[c]), f"{norm}/{split}, logged: channel {c}"
+    np.testing.assert_allclose(rows, want_rows, rtol=1e-9, atol=1e-12)
