@@ -337,6 +337,17 @@ int j2p_math_selftest(int device, size_t n, unsigned seed, unsigned long long *d
  * float in [2^-100, 2^127) (about 1.9e9 values); both counters must come back 0 */
 int j2p_sqrt_exhaustive(int device, unsigned long long *rsq_mismatches, unsigned long long *fast_mismatches);
 
+/* test hook: exhaustive checks of the SHORT division (one residual correction, j2p_kernels.hip.h: div_exact_recip).
+ *   pass 3: denominators first .. first + count - 1 of the 2^23 floats of [1, 2), reciprocal by IEEE division (what
+ *           phase B uses), each against all 2^23 numerator mantissas: the quotient against `/`  — all 2^23 denominators
+ *           = 2^46 quotients, the proof by enumeration the kernels rely on (report[0] must be 0);
+ *   pass 1: every norm phase A can meet: its reciprocal refined from the v_rsq_f32 seed by two Newton steps against
+ *           1.f / n;  pass 2: radicands first .. of the 2^24 floats of [1, 4) x all numerators with THAT reciprocal —
+ *           the form phase A would use; both fail exactly where theory says (norms with an all-ones mantissa), which
+ *           is why phase A keeps the long form.
+ * report[0] = number of mismatches, report[1..8] = the first offenders' bit patterns. */
+int j2p_division_exhaustive(int device, int pass, unsigned first, unsigned count, unsigned long long report[9]);
+
 #ifdef __cplusplus
 }
 #endif

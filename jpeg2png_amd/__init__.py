@@ -81,7 +81,7 @@ C_ABI_SYMBOLS = [
     "j2p_tiled_download", "j2p_tiled_host_cpu_seconds", "j2p_solver_norm_ptr", "j2p_solver_norm_external",
     "j2p_batch_create", "j2p_batch_destroy", "j2p_batch_submit", "j2p_batch_wait",
     "compute", "j2p_compute", "j2p_compute_tiled",
-    "j2p_debug_build", "j2p_solver_debug_violations", "j2p_solver_trace",
+    "j2p_debug_build", "j2p_solver_debug_violations", "j2p_solver_trace", "j2p_division_exhaustive",
 ]
 J2P_OPT_NORM_FOLD, J2P_OPT_JOINT_INWAVE, J2P_OPT_NORM_IN_PROJECT, J2P_OPT_NT_GRADIENT, J2P_OPT_MIXED_PROJECT = 1, 2, 4, 5, 6
 
@@ -243,6 +243,15 @@ def sqrt_exhaustive(device=0):
     lib.j2p_sqrt_exhaustive.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]
     _check(lib.j2p_sqrt_exhaustive(device, ctypes.byref(a), ctypes.byref(b)))
     return a.value, b.value
+
+
+def division_exhaustive(which, first=0, count=0, device=0):
+    """exhaustive checks of the short division, pass 1 / 2 / 3 (include/jpeg2png_amd.h): (mismatches, first offenders)"""
+    lib = load_library()
+    lib.j2p_division_exhaustive.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.c_uint, ctypes.POINTER(ctypes.c_ulonglong)]
+    rep = (ctypes.c_ulonglong * 9)()
+    _check(lib.j2p_division_exhaustive(device, which, first, count, rep))
+    return rep[0], [hex(v) for v in rep[1:] if v]
 
 
 class Solver:

@@ -31,6 +31,8 @@
 //                     cache-resident, the instruction stream unchanged — the compute side on its own
 //   J2P_EXP_NOHALO    k_gradient re-reads its own first / last rows instead of the 2 + 2 halo rows of a strip:
 //                     what the 1.15x over-fetch costs
+//   J2P_EXP_SHORTDIV  k_gradient WITHOUT the all-ones-mantissa test its short division needs (wrong once in ~1e6
+//                     pixels): what that test costs
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -375,6 +377,23 @@ __device__ __forceinline__ v2f div_shared(v2f x, v2f d, v2f r)
         const v2f q1 = pk_fma(pk_fma(-d, q0, x), r, q0);
         return pk_fma(pk_fma(-d, q1, x), r, q1);
 }
+// ---- the SHORT division (phase B; candidates for phase A, see k_recip_exhaustive) ----
+// With r the CORRECTLY ROUNDED reciprocal of d, one residual correction is enough (Markstein): q0 = RN(x r),
+// e = x - d q0 (exact, one fma), q = RN(q0 + e r) is RN(x / d).  Three packed operations per quotient instead of five.
+// Not taken on trust: j2p_division_exhaustive enumerates EVERY denominator mantissa against EVERY numerator mantissa
+// (2^46 quotients, GPU test) with r = 1.f / d; operand ranges as for div_shared (no intermediate can be subnormal).
+__device__ __forceinline__ v2f recip_exact(v2f d, v2f seed)
+{
+        const v2f one = v2f{1.f, 1.f};
+        const v2f r1 = pk_fma(pk_fma(-d, seed, one), seed, seed);
+        return pk_fma(pk_fma(-d, r1, one), r1, r1);
+}
+__device__ __forceinline__ v2f div_exact_recip(v2f x, v2f d, v2f r)
+{
+        const v2f q0 = x * r;
+        return pk_fma(pk_fma(-d, q0, x), r, q0);
+}
+
 // the same for N numerators over one denominator, written breadth-first so that the N
 // independent fma chains are interleaved instead of issued back to back
 template <int N>
@@ -501,8 +520,14 @@ __device__ __forceinline__ v2f divisor_of(v2f n)
         if(EXACT_ZERO) { return v2f{fmaxf(n.x, 0x1p-60f), fmaxf(n.y, 0x1p-60f)}; }
         return n;                                                                  // already >= 2^-60
 }
-// what source_terms needs of a sum of squares x: the norm n = sqrtf(x), the divisor d made from it and the refined
-// reciprocal r of d (unscreened path: r is not used)
+// what the source terms need of a sum of squares x: the norm n = sqrtf(x), the divisor d made from it and the
+// reciprocal r of d that the quotients are refined from (unscreened path: r is not used).
+// SHORT (the screened path without log sums): r is refined TWICE from the v_rsq_f32 value the root was made of, which
+// makes it the correctly rounded 1 / n for every norm but those with an all-ones mantissa (k_recip_exhaustive: all
+// norms enumerated), and each quotient then needs ONE residual correction (div_exact_recip; k_div_exhaustive: every
+// radicand x every numerator enumerated, clean except at those norms).  The march sends rows that may hold such a
+// norm down the unscreened path (allones_candidate).  Per pixel pair 4 + 7 x 3 packed operations instead of
+// 2 + 2 transcendental + 7 x 5.
 template <bool FAST, bool EXACT_ZERO>
 __device__ __forceinline__ void norm_and_reciprocal(v2f x, v2f &n, v2f &d, v2f &r)
 {
@@ -516,14 +541,14 @@ __device__ __forceinline__ void norm_and_reciprocal(v2f x, v2f &n, v2f &d, v2f &
                 v2f seed;
                 n = sqrt_rsq(x + v2f{0x1p-120f, 0x1p-120f}, seed);
                 d = n;
-                r = div_prepare_seeded(d, seed);
+                r = recip_exact(d, seed);
         } else {
                 n = sqrt_pair<FAST, EXACT_ZERO>(x);
                 d = divisor_of<FAST, EXACT_ZERO>(n);
                 r = FAST ? div_prepare(d) : d;
         }
 }
-template <bool FAST, int N>
+template <bool FAST, bool EXACT_ZERO, int N>
 __device__ __forceinline__ void div_n(const v2f (&x)[N], v2f d, v2f r, v2f (&q)[N])
 {
 #ifdef J2P_EXP_NOARITH
@@ -531,12 +556,28 @@ __device__ __forceinline__ void div_n(const v2f (&x)[N], v2f d, v2f r, v2f (&q)[
         for(int i = 0; i < N; i++) { q[i] = x[i] * d; }
         return;
 #endif
-        if(FAST) {
+        if constexpr(FAST && !EXACT_ZERO) {
+#pragma unroll
+                for(int i = 0; i < N; i++) { q[i] = div_exact_recip(x[i], d, r); }
+        } else if(FAST) {
                 div_shared_n<N>(x, d, r, q);
         } else {
 #pragma unroll
                 for(int i = 0; i < N; i++) { q[i] = v2f{x[i].x / d.x, x[i].y / d.y}; }
         }
+}
+// true when one of the four radicands of a pixel pair MAY give a norm with an all-ones mantissa: such a norm is the root
+// of a radicand whose own mantissa ends in 0x7ffffe or 0x7fffff, so "the low 16 bits are >= 0xfffe" is necessary — one
+// row in ~120 trips a wavefront, which then takes the unscreened (IEEE) path for that row; three packed 16-bit maxima and
+// one compare per pixel pair
+__device__ __forceinline__ bool allones_candidate(v2f r1, v2f r2)
+{
+        typedef unsigned short v2h __attribute__((ext_vector_type(2)));
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        const v2u a = __builtin_bit_cast(v2u, r1), b = __builtin_bit_cast(v2u, r2);
+        const v2h m = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(v2h, a.x), __builtin_bit_cast(v2h, a.y)),
+                                                __builtin_elementwise_max(__builtin_bit_cast(v2h, b.x), __builtin_bit_cast(v2h, b.y)));
+        return m.x >= (unsigned short)0xfffe;
 }
 
 // The four TGV2 numerators of a pixel pair (compute.c:165-182): s + gxx, gyy + s, s (its sign goes onto the quotient)
@@ -561,15 +602,24 @@ __device__ __forceinline__ v2f own_term(v2f a2, v2f q3)
         return a2 * -q3;
 }
 
-// Source terms of one image row for a lane's column pair.  gx,gy: forward differences of
-// this row, gxp,gyp: of the row above.  m_hx / m_hy zero the second differences on the first
-// column / first row (compute.c:137-143).  tv / tv2 receive the log sums when `log_row`.
-template <int NCH, bool TGV, bool LOG, bool FAST, bool MASKED = true>
-__device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&gy)[NCH], const v2f (&gxp)[NCH],
-                                             const v2f (&gyp)[NCH], v2f m_hx, v2f m_hy, float a_tv, float a_tgv,
-                                             bool log_row, double &tv, double &tv2, SourceTerms<NCH, TGV> &s)
+// Source terms of one image row for a lane's column pair, in two steps.  gx,gy: forward differences of this row,
+// gxp,gyp: of the row above.  m_hx / m_hy zero the second differences on the first column / first row
+// (compute.c:137-143).
+//   source_prepare : the second differences and the two sums of squares under the norms (the same arithmetic on every
+//                    path) — from which the march decides which path the row takes
+//   source_finish  : norms, quotients, weights.  FAST: the screened path (short sequences, see norm_and_reciprocal);
+//                    otherwise plain `/` and sqrtf().  tv / tv2 receive the log sums when `log_row`.
+template <int NCH, bool TGV>
+struct SourcePrep {
+        v2f n1r, n2r;                              // gx^2 + gy^2 summed over the channels; the TGV2 counterpart
+        v2f xx[NCH], sy[NCH], yy[NCH];
+};
+
+template <int NCH, bool TGV, bool MASKED>
+__device__ __forceinline__ void source_prepare(const v2f (&gx)[NCH], const v2f (&gy)[NCH], const v2f (&gxp)[NCH],
+                                               const v2f (&gyp)[NCH], v2f m_hx, v2f m_hy, SourcePrep<NCH, TGV> &p)
 {
-        // ---- TV (compute.c:84-104) ----
+        // ---- TV (compute.c:84-89) ----
         // (the reference starts the sum at 0.f; a square is never -0, so 0.f + gx * gx is gx * gx bit for bit)
         v2f n1 = gx[0] * gx[0];
         n1 += gy[0] * gy[0];
@@ -578,8 +628,35 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
                 n1 += gx[c] * gx[c];
                 n1 += gy[c] * gy[c];
         }
-        v2f d1, r1;
-        norm_and_reciprocal<FAST, LOG>(n1, n1, d1, r1);
+        p.n1r = n1;
+        p.n2r = v2f{0.f, 0.f};
+        // ---- TGV2 (compute.c:136-152) ----
+        if(TGV) {
+                v2f n2 = v2f{0.f, 0.f};
+#pragma unroll
+                for(int c = 0; c < NCH; c++) {
+                        // MASKED == false: the caller knows every mask is 1 here (v * 1.f is v, so dropping
+                        // the products changes no bit)
+                        p.xx[c] = MASKED ? (gx[c] - left_of(gx[c])) * m_hx : gx[c] - left_of(gx[c]);
+                        const v2f gyx = MASKED ? (gy[c] - left_of(gy[c])) * m_hx : gy[c] - left_of(gy[c]);
+                        const v2f gxy = MASKED ? (gx[c] - gxp[c]) * m_hy : gx[c] - gxp[c];
+                        p.yy[c] = MASKED ? (gy[c] - gyp[c]) * m_hy : gy[c] - gyp[c];
+                        p.sy[c] = (gxy + gyx) * 0.5f;                     // (g_xy + g_yx) / 2.
+                        const v2f term = p.xx[c] * p.xx[c] + 2.f * (p.sy[c] * p.sy[c]) + p.yy[c] * p.yy[c];
+                        if(c == 0) { n2 = term; }                       // 0.f + term is term: never -0
+                        else { n2 += term; }
+                }
+                p.n2r = n2;
+        }
+}
+
+template <int NCH, bool TGV, bool LOG, bool FAST>
+__device__ __forceinline__ void source_finish(const v2f (&gx)[NCH], const v2f (&gy)[NCH], const SourcePrep<NCH, TGV> &p, float a_tv,
+                                              float a_tgv, bool log_row, double &tv, double &tv2, SourceTerms<NCH, TGV> &s)
+{
+        // ---- TV (compute.c:90-104) ----
+        v2f n1, d1, r1;
+        norm_and_reciprocal<FAST, LOG>(p.n1r, n1, d1, r1);
         if(LOG && log_row) {
                 tv += (double)(a_tv * n1.x);
                 tv += (double)(a_tv * n1.y);
@@ -593,30 +670,15 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
                 if(NCH > 1) { __builtin_amdgcn_sched_barrier(0); }   // one channel at a time: bounds the live ranges
                 const v2f num[3] = {a1 * gx[c], a1 * gy[c], a1 * -(gx[c] + gy[c])};
                 v2f q[3];
-                div_n<FAST, 3>(num, d1, r1, q);
+                div_n<FAST, LOG, 3>(num, d1, r1, q);
                 s.tvxL[c] = left_of(q[0]);
                 s.tvy[c] = q[1];
                 s.tvo[c] = q[2];
         }
-        // ---- TGV2 (compute.c:136-183) ----
+        // ---- TGV2 (compute.c:153-183) ----
         if(TGV) {
-                v2f n2 = v2f{0.f, 0.f};
-                v2f xx[NCH], sy[NCH], yy[NCH];
-#pragma unroll
-                for(int c = 0; c < NCH; c++) {
-                        // MASKED == false: the caller knows every mask is 1 here (v * 1.f is v, so dropping
-                        // the products changes no bit)
-                        xx[c] = MASKED ? (gx[c] - left_of(gx[c])) * m_hx : gx[c] - left_of(gx[c]);
-                        const v2f gyx = MASKED ? (gy[c] - left_of(gy[c])) * m_hx : gy[c] - left_of(gy[c]);
-                        const v2f gxy = MASKED ? (gx[c] - gxp[c]) * m_hy : gx[c] - gxp[c];
-                        yy[c] = MASKED ? (gy[c] - gyp[c]) * m_hy : gy[c] - gyp[c];
-                        sy[c] = (gxy + gyx) * 0.5f;                     // (g_xy + g_yx) / 2.
-                        const v2f term = xx[c] * xx[c] + 2.f * (sy[c] * sy[c]) + yy[c] * yy[c];
-                        if(c == 0) { n2 = term; }                       // 0.f + term is term: never -0
-                        else { n2 += term; }
-                }
-                v2f d2, r2;
-                norm_and_reciprocal<FAST, LOG>(n2, n2, d2, r2);
+                v2f n2, d2, r2;
+                norm_and_reciprocal<FAST, LOG>(p.n2r, n2, d2, r2);
                 if(LOG && log_row) {
                         tv2 += (double)(a_tgv * n2.x);
                         tv2 += (double)(a_tgv * n2.y);
@@ -628,10 +690,10 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
                         if(NCH > 1) { __builtin_amdgcn_sched_barrier(0); }
                         // a2 * (expr / n2): division first (compute.c:165-182)
                         // the two negative numerators are divided as positives and the sign goes onto the quotient:
-                        // (-v) / n == -(v / n) bit for bit, in the IEEE and in the short sequence alike
+                        // (-v) / n == -(v / n) bit for bit, in the IEEE and in the short sequences alike
                         v2f num[4], q[4];
-                        tgv_numerators<FAST>(xx[c], sy[c], yy[c], num);
-                        div_n<FAST, 4>(num, d2, r2, q);
+                        tgv_numerators<FAST>(p.xx[c], p.sy[c], p.yy[c], num);
+                        div_n<FAST, LOG, 4>(num, d2, r2, q);
                         const v2f tA = a2 * q[0];                                       // to (x-1,y), (x+1,y)
                         s.B[c] = a2 * q[1];                                             // to (x,y-1), (x,y+1)
                         const v2f tC = a2 * -q[2];                                      // to (x+1,y-1), (x-1,y+1)
@@ -643,18 +705,16 @@ __device__ __forceinline__ void source_terms(const v2f (&gx)[NCH], const v2f (&g
         }
 }
 
-
-// The same for ONE channel of a jointly optimised image whose other channels live in the other
+// source_prepare for ONE channel of a jointly optimised image whose other channels live in the other
 // wavefronts of the workgroup (J wavefronts = J channels, same strip).  Only the two norms couple
 // the channels (compute.c:84-89, 148-152): every wavefront publishes the squares of its own
 // differences, and after one barrier every wavefront adds them up in the reference's order
 // ((((0 + gx0^2) + gy0^2) + gx1^2) + ... ; per-channel Hessian terms likewise), so all of them
-// hold bit-identical norms and the rest of the work stays private to the channel.
-// `xchg` is a double-buffered LDS area: [2][J][64 lanes][3] float2.
-template <int J, bool TGV, bool LOG, bool FAST, bool MASKED = true>
-__device__ __forceinline__ void source_terms_joint(int cidx, int lane, int parity, v2f *xchg, v2f gx, v2f gy, v2f gxp, v2f gyp,
-                                                   v2f m_hx, v2f m_hy, float a_tv, float a_tgv, bool log_row, double &tv,
-                                                   double &tv2, SourceTerms<1, TGV> &s)
+// hold bit-identical sums — and take the same path — and the rest of the work (source_finish<1, ...>)
+// stays private to the channel.  `xchg` is a double-buffered LDS area: [2][J][64 lanes][3] float2.
+template <int J, bool TGV, bool MASKED>
+__device__ __forceinline__ void source_prepare_joint(int cidx, int lane, int parity, v2f *xchg, v2f gx, v2f gy, v2f gxp, v2f gyp,
+                                                     v2f m_hx, v2f m_hy, SourcePrep<1, TGV> &p)
 {
         v2f xx = v2f{0.f, 0.f}, sy = xx, yy = xx, tq = xx;
         if(TGV) {
@@ -665,14 +725,18 @@ __device__ __forceinline__ void source_terms_joint(int cidx, int lane, int parit
                 sy = (gxy + gyx) * 0.5f;
                 tq = xx * xx + 2.f * (sy * sy) + yy * yy;
         }
+        p.xx[0] = xx;
+        p.sy[0] = sy;
+        p.yy[0] = yy;
         v2f *mine = xchg + ((size_t)(parity * J + cidx) * 64 + lane) * 3;
         mine[0] = gx * gx;
         mine[1] = gy * gy;
         mine[2] = tq;
         __syncthreads();
-        // (sums start with channel 0's terms: 0.f + a square is the square, see source_terms)
-        v2f n1 = xchg[((size_t)(parity * J) * 64 + lane) * 3], n2 = xchg[((size_t)(parity * J) * 64 + lane) * 3 + 2];
-        n1 += xchg[((size_t)(parity * J) * 64 + lane) * 3 + 1];
+        // (sums start with channel 0's terms: 0.f + a square is the square, see source_prepare)
+        const v2f *o0 = xchg + ((size_t)(parity * J) * 64 + lane) * 3;
+        v2f n1 = o0[0], n2 = o0[2];
+        n1 += o0[1];
 #pragma unroll
         for(int c = 1; c < J; c++) {
                 const v2f *o = xchg + ((size_t)(parity * J + c) * 64 + lane) * 3;
@@ -680,39 +744,8 @@ __device__ __forceinline__ void source_terms_joint(int cidx, int lane, int parit
                 n1 += o[1];
                 n2 += o[2];
         }
-        v2f d1, r1;
-        norm_and_reciprocal<FAST, LOG>(n1, n1, d1, r1);
-        if(LOG && log_row) {
-                tv += (double)(a_tv * n1.x);
-                tv += (double)(a_tv * n1.y);
-        }
-        const v2f a1 = FAST ? v2f{a_tv, a_tv} : v2f{n1.x == 0.f ? 0.f : a_tv, n1.y == 0.f ? 0.f : a_tv};
-        {
-                const v2f num[3] = {a1 * gx, a1 * gy, a1 * -(gx + gy)};
-                v2f q[3];
-                div_n<FAST, 3>(num, d1, r1, q);
-                s.tvxL[0] = left_of(q[0]);
-                s.tvy[0] = q[1];
-                s.tvo[0] = q[2];
-        }
-        if(TGV) {
-                v2f d2, r2;
-                norm_and_reciprocal<FAST, LOG>(n2, n2, d2, r2);
-                if(LOG && log_row) {
-                        tv2 += (double)(a_tgv * n2.x);
-                        tv2 += (double)(a_tgv * n2.y);
-                }
-                const v2f a2 = FAST ? v2f{a_tgv, a_tgv} : v2f{n2.x == 0.f ? 0.f : a_tgv, n2.y == 0.f ? 0.f : a_tgv};
-                v2f num[4], q[4];
-                tgv_numerators<FAST>(xx, sy, yy, num);                                  // signs: see source_terms
-                div_n<FAST, 4>(num, d2, r2, q);
-                const v2f tC = a2 * -q[2];
-                s.A[0] = a2 * q[0];
-                s.B[0] = a2 * q[1];
-                s.O[0] = own_term<FAST>(a2, q[3]);
-                s.CL[0] = left_of(tC);
-                s.CR[0] = right_of(tC);
-        }
+        p.n1r = n1;
+        p.n2r = n2;
 }
 
 // ---------------------------------------------------------------------------
@@ -1055,24 +1088,23 @@ void k_gradient(GradArgs a)
                                 const bool log_row = LOG && pair_own && r >= t0 && r < t1 && cbase == 0;
                                 const float hy = gr <= 0 || gr >= H ? 0.f : in_f;  // gxy, gyy = 0 on the first row (compute.c:141-143)
                                 const v2f m_hy = v2f{hy, hy};
-                                if(J > 1) {
+                                // second differences and the sums under the two norms (the same on every path), then the
+                                // path: screened unless the rows involved hold a value outside the screen's range or one
+                                // of the norms may have an all-ones mantissa (see norm_and_reciprocal)
+                                SourcePrep<NCH, TGV> prep;
+                                if constexpr(J > 1) {
                                         const int parity = (r - t0 + 1) & 1;
-                                        if(badmask == 0) {
-                                                source_terms_joint<J, TGV, LOG, true, !FREE>(cbase, lane, parity, xchg, GX[P][0], GY[P][0], GX[PM1][0],
-                                                                                      GY[PM1][0], m_hx, m_hy, a.a_tv, a.a_tgv, log_row,
-                                                                                      tv_acc, tv2_acc, reinterpret_cast<SourceTerms<1, TGV> &>(s));
-                                        } else {
-                                                source_terms_joint<J, TGV, LOG, false, !FREE>(cbase, lane, parity, xchg, GX[P][0], GY[P][0], GX[PM1][0],
-                                                                                       GY[PM1][0], m_hx, m_hy, a.a_tv, a.a_tgv, log_row,
-                                                                                       tv_acc, tv2_acc, reinterpret_cast<SourceTerms<1, TGV> &>(s));
-                                        }
-                                } else if(badmask == 0) {
-                                        source_terms<NCH, TGV, LOG, true, !FREE>(GX[P], GY[P], GX[PM1], GY[PM1], m_hx, m_hy, a.a_tv, a.a_tgv,
-                                                                          log_row, tv_acc, tv2_acc, s);
+                                        source_prepare_joint<J, TGV, !FREE>(cbase, lane, parity, xchg, GX[P][0], GY[P][0], GX[PM1][0], GY[PM1][0],
+                                                                            m_hx, m_hy, prep);
                                 } else {
-                                        source_terms<NCH, TGV, LOG, false, !FREE>(GX[P], GY[P], GX[PM1], GY[PM1], m_hx, m_hy, a.a_tv, a.a_tgv,
-                                                                           log_row, tv_acc, tv2_acc, s);
+                                        source_prepare<NCH, TGV, !FREE>(GX[P], GY[P], GX[PM1], GY[PM1], m_hx, m_hy, prep);
                                 }
+                                bool slow = badmask != 0;
+#ifndef J2P_EXP_SHORTDIV
+                                if constexpr(!LOG) { slow = slow || __builtin_amdgcn_ballot_w64(allones_candidate(prep.n1r, prep.n2r)) != 0; }
+#endif
+                                if(!slow) { source_finish<NCH, TGV, LOG, true>(GX[P], GY[P], prep, a.a_tv, a.a_tgv, log_row, tv_acc, tv2_acc, s); }
+                                else { source_finish<NCH, TGV, LOG, false>(GX[P], GY[P], prep, a.a_tv, a.a_tgv, log_row, tv_acc, tv2_acc, s); }
                         }
                         // ---- target row t = r-1: rows t-1, t, t+1 live in slots PM2, PM1, P ----
                         const int t = r - 1;
@@ -1464,12 +1496,25 @@ __device__ __forceinline__ bool num_suspect(v2f x)
 {
         return !(in_fast_range(x.x, 0x1p-100f, 0x1p61f) && in_fast_range(x.y, 0x1p-100f, 0x1p61f));
 }
+// ... for a batch of values at once, on the bit patterns (as k_gradient's make_y does): hi = largest |x|, lo = smallest
+// NON-ZERO |x| minus one ulp (0 - 1 wraps to the top, so zeros drop out of the minimum); two compares at the end
+struct NumScreen {
+        unsigned hi = 0u, lo = ~0u;
+        __device__ __forceinline__ void add(v2f x)
+        {
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                const v2u u = __builtin_bit_cast(v2u, x) & 0x7fffffffu;
+                const v2u um = u - 1u;
+                hi = max(hi, max(u.x, u.y));
+                lo = min(lo, min(um.x, um.y));
+        }
+        __device__ __forceinline__ bool suspect() const
+        {
+                constexpr unsigned kLo = 0x0d800000u, kHi = 0x5e000000u;     // bits of 2^-100 and 2^61 (NaN and infinity lie above)
+                return hi >= kHi || lo < kLo - 1u;
+        }
+};
 __device__ __forceinline__ bool den_ok(float d) { return d >= 0x1p-20f && d <= 0x1p26f; }
-__device__ __forceinline__ float div_prepare1(float d)
-{
-        const float r = __builtin_amdgcn_rcpf(d);
-        return __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r);
-}
 
 
 // Phase B front/back end for a SUBSAMPLED channel whose 64 x 8 coefficient strip lies wholly
@@ -1489,7 +1534,7 @@ __device__ __forceinline__ void sub_load_step_mean(const ChanDev &k, size_t base
         typedef float vws __attribute__((ext_vector_type(WS)));
         const bool have_norm = norm != 0.f;                                   // compute.c:212
         const bool fast = den_ok(norm);
-        const float rn = fast ? div_prepare1(norm) : 0.f;
+        const float rn = fast ? 1.f / norm : 0.f;                             // correctly rounded: what div_exact_recip needs
 #pragma unroll
         for(int half = 0; half < 2; half++) {
                 // half the rows at a time: bounds the registers held by loads in flight
@@ -1504,15 +1549,15 @@ __device__ __forceinline__ void sub_load_step_mean(const ChanDev &k, size_t base
                         xc[i] = *reinterpret_cast<const vws *>(k.xcur + off);
                         xp[i] = *reinterpret_cast<const vws *>(k.xprev + off);
                 }
-                bool sus = false;
+                NumScreen scr;
                 if(WS == 2) {
 #pragma unroll
-                        for(int i = 0; i < 4 * HS; i++) { sus |= num_suspect(v2f{gv[i][0], gv[i][WS - 1]}); }
+                        for(int i = 0; i < 4 * HS; i++) { scr.add(v2f{gv[i][0], gv[i][WS - 1]}); }
                 } else {
 #pragma unroll
-                        for(int i = 0; i < 4 * HS; i += 2) { sus |= num_suspect(v2f{gv[i][0], gv[i + 1][0]}); }
+                        for(int i = 0; i < 4 * HS; i += 2) { scr.add(v2f{gv[i][0], gv[i + 1][0]}); }
                 }
-                const bool use_fast = fast && __builtin_amdgcn_ballot_w64(sus) == 0;
+                const bool use_fast = fast && __builtin_amdgcn_ballot_w64(scr.suspect()) == 0;
 #pragma unroll
                 for(int i = 0; i < 4 * HS; i++) {
                         vws y = xc[i] + factor * (xc[i] - xp[i]);                 // compute.c:435
@@ -1520,11 +1565,11 @@ __device__ __forceinline__ void sub_load_step_mean(const ChanDev &k, size_t base
                                 vws q;
                                 if(use_fast) {
                                         if(WS == 2) {
-                                                const v2f qq = div_shared(v2f{gv[i][0], gv[i][WS - 1]}, v2f{norm, norm}, v2f{rn, rn});
+                                                const v2f qq = div_exact_recip(v2f{gv[i][0], gv[i][WS - 1]}, v2f{norm, norm}, v2f{rn, rn});
                                                 q[0] = qq.x;
                                                 q[WS - 1] = qq.y;
                                         } else {
-                                                const v2f qq = div_shared(v2f{gv[i][0], 0.f}, v2f{norm, norm}, v2f{rn, rn});
+                                                const v2f qq = div_exact_recip(v2f{gv[i][0], 0.f}, v2f{norm, norm}, v2f{rn, rn});
                                                 q[0] = qq.x;
                                         }
                                 } else {
@@ -1577,8 +1622,8 @@ struct __attribute__((aligned(16))) ProjShared {
         float tp[4 * kTpWave];
         float qs[64];    // q
         float qq[64];    // q*q
-        float rqq[64];   // refined 1/(q*q)
-        float rq[64];    // refined 1/q   (log only)
+        float rqq[64];   // 1/(q*q), correctly rounded
+        float rq[64];    // 1/q, correctly rounded   (log only)
         int q_fast;
 };
 
@@ -1671,8 +1716,8 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                 const float q = k.q[threadIdx.x];
                 qs[threadIdx.x] = q;
                 qq[threadIdx.x] = q * q;
-                rqq[threadIdx.x] = div_prepare1(q * q);
-                rq[threadIdx.x] = div_prepare1(q);
+                rqq[threadIdx.x] = 1.f / (q * q);                    // correctly rounded reciprocals (div_exact_recip)
+                rq[threadIdx.x] = 1.f / q;
                 const bool ok = den_ok(q * q) && den_ok(q);
                 const unsigned long long all_ok = __builtin_amdgcn_ballot_w64(ok);
                 if(threadIdx.x == 0) { q_fast = all_ok == ~0ull; }
@@ -1694,21 +1739,21 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                 sub_load_step_mean<(kSub ? WS : 1), (kSub ? HS : 1)>(k, sub_base, W, a.factor, a.step, norm, tile, v);
         } else if(full) {
                 v2f y2[4], g2[4];
-                bool sus = false;
+                NumScreen scr;
 #pragma unroll
                 for(int p = 0; p < 4; p++) {
                         const v2f xc = v2f{xcv[2 * p], xcv[2 * p + 1]}, xp = v2f{xpv[2 * p], xpv[2 * p + 1]};
                         g2[p] = v2f{gv[2 * p], gv[2 * p + 1]};
                         y2[p] = xc + a.factor * (xc - xp);                  // compute.c:435
-                        sus |= num_suspect(g2[p]);
+                        scr.add(g2[p]);
                 }
                 if(norm != 0.f) {                                           // compute.c:212
-                        if(den_ok(norm) && __builtin_amdgcn_ballot_w64(sus) == 0) {
+                        if(den_ok(norm) && __builtin_amdgcn_ballot_w64(scr.suspect()) == 0) {
                                 const v2f nn = v2f{norm, norm};
-                                const float rn1 = div_prepare1(norm);
+                                const float rn1 = 1.f / norm;               // correctly rounded, once per wavefront
                                 const v2f rn = v2f{rn1, rn1};
 #pragma unroll
-                                for(int p = 0; p < 4; p++) { y2[p] = y2[p] - a.step * div_shared(g2[p], nn, rn); }
+                                for(int p = 0; p < 4; p++) { y2[p] = y2[p] - a.step * div_exact_recip(g2[p], nn, rn); }
                         } else {
 #pragma unroll
                                 for(int p = 0; p < 4; p++) { y2[p] = y2[p] - a.step * v2f{g2[p].x / norm, g2[p].y / norm}; }
@@ -1795,7 +1840,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                 }
                 const int rw[4] = {raw.x, raw.y, raw.z, raw.w};
                 v2f t2[4], q2[4];
-                bool sus = false;
+                NumScreen scr;
 #pragma unroll
                 for(int p = 0; p < 4; p++) {
                         // two int16 per dword: low half = even coefficient
@@ -1803,25 +1848,27 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                         const v2f q = *reinterpret_cast<const v2f *>(&qs[rr * 8 + 2 * p]);
                         const v2f lo = (df - 0.5f) * q, hi = (df + 0.5f) * q;
                         v2f x = v2f{v[2 * p], v[2 * p + 1]};
-                        x = v2f{x.x > hi.x ? hi.x : (x.x < lo.x ? lo.x : x.x), x.y > hi.y ? hi.y : (x.y < lo.y ? lo.y : x.y)};
+                        // x > hi ? hi : (x < lo ? lo : x)  (compute.c:327-329) as the median of the three: lo < hi, neither is
+                        // a zero (q >= 1, d integer), so whichever operand is returned carries the same bits
+                        x = v2f{__builtin_amdgcn_fmed3f(x.x, lo.x, hi.x), __builtin_amdgcn_fmed3f(x.y, lo.y, hi.y)};
                         v[2 * p] = x.x;
                         v[2 * p + 1] = x.y;
                         t2[p] = x - df * q;
                         q2[p] = q;
-                        sus |= num_suspect(t2[p]);
+                        scr.add(t2[p]);
                 }
                 if(k.prob_on) {
-                        if(q_fast && __builtin_amdgcn_ballot_w64(sus) == 0) {
+                        if(q_fast && __builtin_amdgcn_ballot_w64(scr.suspect()) == 0) {
 #pragma unroll
                                 for(int p = 0; p < 4; p++) {
                                         const v2f d2 = *reinterpret_cast<const v2f *>(&qq[rr * 8 + 2 * p]);
                                         const v2f r2 = *reinterpret_cast<const v2f *>(&rqq[rr * 8 + 2 * p]);
-                                        const v2f ev = div_shared(t2[p], d2, r2);
+                                        const v2f ev = div_exact_recip(t2[p], d2, r2);
                                         e[2 * p] = ev.x;
                                         e[2 * p + 1] = ev.y;
                                         if(LOG) {                                    // compute_simd_step.c:22-26
                                                 const v2f r1 = *reinterpret_cast<const v2f *>(&rq[rr * 8 + 2 * p]);
-                                                const v2f tq = div_shared(t2[p], q2[p], r1);
+                                                const v2f tq = div_exact_recip(t2[p], q2[p], r1);
                                                 const v2f sq = tq * tq;
                                                 dist += (double)sq.x;
                                                 dist += (double)sq.y;
@@ -1923,8 +1970,11 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
 
 // NIP: the norm comes from norm_tree_wave (ProjArgs::norm_rowsums) instead of ProjArgs::norm
 // (80 registers for the 1x1 form = six wavefronts per SIMD; forcing seven or eight spills: 66 -> 76 / 97 us)
+#ifndef J2P_PROJECT_WAVES
+#define J2P_PROJECT_WAVES 0
+#endif
 template <bool LOG, int WS, int HS, int NT = 0, bool NIP = false>
-__global__ __launch_bounds__(256) void k_project(ProjArgs a)
+__global__ __launch_bounds__(256, (J2P_PROJECT_WAVES && WS == 1 && HS == 1 && !LOG && !NIP ? J2P_PROJECT_WAVES : 1)) void k_project(ProjArgs a)
 {
         __shared__ ProjShared sh;
         project_strip<LOG, WS, HS, NT, NIP>(a, sh);
@@ -2104,8 +2154,20 @@ __global__ __launch_bounds__(256) void k_math_selftest(size_t n, unsigned seed, 
                 const v2f si = v2f{sqrtf(sx.x), sqrtf(sx.y)};
                 bad_sqrt += __builtin_bit_cast(unsigned, sf.x) != __builtin_bit_cast(unsigned, si.x);
                 bad_sqrt += __builtin_bit_cast(unsigned, sf.y) != __builtin_bit_cast(unsigned, si.y);
-                // the norm -> reciprocal -> quotient chain of source_terms: root through v_rsq_f32, the reciprocal
-                // refined from that same v_rsq_f32 value (div_prepare_seeded), quotients against `/` by the IEEE root.
+                // phase B's short division over its whole operand range: denominators in [2^-20, 2^26] with their IEEE
+                // reciprocal, numerators 0 or in [2^-100, 2^61)
+                {
+                        const v2f dd = v2f{fabsf(rnd_float(h0 ^ h3, 107, 152)), fabsf(rnd_float(h1 ^ h2, 107, 152))};
+                        v2f nn = v2f{rnd_float(h3 + h0, 27, 187), rnd_float(h2 + h1, 27, 187)};
+                        if((h3 & 0xff) == 9) { nn.x = 0.f; }
+                        if((h2 & 0xff) == 11) { nn.y = dd.y; }
+                        const v2f qm = div_exact_recip(nn, dd, v2f{1.f / dd.x, 1.f / dd.y});
+                        const v2f qi2 = v2f{nn.x / dd.x, nn.y / dd.y};
+                        bad_div += __builtin_bit_cast(unsigned, qm.x) != __builtin_bit_cast(unsigned, qi2.x) && !(qm.x == 0.f && qi2.x == 0.f);
+                        bad_div += __builtin_bit_cast(unsigned, qm.y) != __builtin_bit_cast(unsigned, qi2.y) && !(qm.y == 0.f && qi2.y == 0.f);
+                }
+                // the norm -> reciprocal -> quotient chain of source_finish: root through v_rsq_f32, the reciprocal refined
+                // twice from that same v_rsq_f32 value (recip_exact), one-correction quotients against `/` by the IEEE root.
                 // Radicands as the kernel sees them: 0 or in [2^-88, 2^87); numerators 0 or within 2^45 of the norm.
                 {
                         v2f rx = v2f{fabsf(rnd_float(h2 ^ h0, 39, 213)), fabsf(rnd_float(h3 ^ h1, 39, 213))};
@@ -2119,10 +2181,12 @@ __global__ __launch_bounds__(256) void k_math_selftest(size_t n, unsigned seed, 
                         v2f num = v2f{ni.x * rnd_float(h1 ^ h3, 87, 128), ni.y * rnd_float(h0 ^ h2, 87, 128)};
                         if((h1 & 0x7f) == 3) { num.x = 0.f; }
                         if((h0 & 0x7f) == 5) { num.y = ni.y; }
-                        const v2f qs = div_shared(num, dd, rr);
+                        // (rows whose radicands could give an all-ones norm take the IEEE path in the kernel: skipped here too)
+                        const bool skip = allones_candidate(rx + v2f{0x1p-120f, 0x1p-120f}, v2f{1.f, 1.f});
+                        const v2f qs = div_exact_recip(num, dd, rr);
                         const v2f qd = v2f{num.x / ni.x, num.y / ni.y};
-                        bad_div += __builtin_bit_cast(unsigned, qs.x) != __builtin_bit_cast(unsigned, qd.x) && !(qs.x == 0.f && qd.x == 0.f);
-                        bad_div += __builtin_bit_cast(unsigned, qs.y) != __builtin_bit_cast(unsigned, qd.y) && !(qs.y == 0.f && qd.y == 0.f);
+                        bad_div += !skip && __builtin_bit_cast(unsigned, qs.x) != __builtin_bit_cast(unsigned, qd.x) && !(qs.x == 0.f && qd.x == 0.f);
+                        bad_div += !skip && __builtin_bit_cast(unsigned, qs.y) != __builtin_bit_cast(unsigned, qd.y) && !(qs.y == 0.f && qd.y == 0.f);
                 }
         }
         if(blockIdx.x == 0 && threadIdx.x == 0) {
@@ -2152,6 +2216,73 @@ __global__ __launch_bounds__(256) void k_sqrt_exhaustive(unsigned long long *mis
         }
         if(bad_rsq) { atomicAdd(&mism[0], bad_rsq); }
         if(bad_fast) { atomicAdd(&mism[1], bad_fast); }
+}
+
+// ---------------------------------------------------------------------------
+// Exhaustive checks behind the SHORT division of the gradient kernel (div_exact_recip): the reciprocal of a norm
+// refined by TWO Newton steps from the v_rsq_f32 seed is the correctly rounded 1 / n, and with a correctly rounded
+// reciprocal ONE residual correction yields the correctly rounded quotient (Markstein: q0 = RN(a r), e = a - n q0
+// exactly, q = RN(q0 + e r)).  Theorems with side conditions — so both steps are enumerated instead of trusted:
+//   pass 1: every radicand in [2^-100, 2^127) (all the norms the kernel can meet): n, seed -> r; counts r != 1.f / n
+//   pass 2: every radicand in [1, 4) (every mantissa of n, both exponent parities) x every numerator mantissa
+//           in [1, 2) — 2^47 quotients; scaling either operand by a power of two scales every step exactly, and the
+//           kernel's operand screen keeps all of it normal — counts q != a / n (sign handled by symmetry of RN)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_recip_exhaustive(unsigned long long *mism /* [0] count, [1..8] first offenders (bits of the radicand) */)
+{
+        constexpr unsigned lo = 27u << 23, hi = 254u << 23;
+        unsigned long long bad = 0;
+        for(unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; 2 * i + 1 < (unsigned long long)(hi - lo);
+            i += (unsigned long long)gridDim.x * 256) {
+                const v2f x = v2f{__builtin_bit_cast(float, (unsigned)(lo + 2 * i)), __builtin_bit_cast(float, (unsigned)(lo + 2 * i + 1))};
+                v2f seed;
+                const v2f n = sqrt_rsq(x, seed);
+                const v2f r = recip_exact(n, seed);
+                const v2f want = v2f{1.f / n.x, 1.f / n.y};
+                const bool bx = __builtin_bit_cast(unsigned, r.x) != __builtin_bit_cast(unsigned, want.x);
+                const bool by = __builtin_bit_cast(unsigned, r.y) != __builtin_bit_cast(unsigned, want.y);
+                if(bx || by) {
+                        const unsigned long long k = atomicAdd(&mism[0], (unsigned long long)bx + by);
+                        if(k < 8) { mism[1 + k] = __builtin_bit_cast(unsigned, bx ? x.x : x.y); }
+                }
+                bad += 0;
+        }
+        (void)bad;
+}
+
+// radicands [first, first + count) of the 2^24 floats of [1, 4), each against all 2^23 numerator mantissas
+// DIRECT: the denominators themselves are enumerated — [first, first + count) of the 2^23 floats of [1, 2) — with
+// r = 1.f / d, the form phase B uses (reciprocals of the norm and of the quantisation table by IEEE division)
+template <bool DIRECT>
+__global__ __launch_bounds__(256) void k_div_exhaustive(unsigned first, unsigned count, unsigned long long *mism /* [0] count, [1..8]: radicand bits << 32 | numerator bits */)
+{
+        const unsigned idx = blockIdx.x * 4 + (threadIdx.x >> 6);        // one wavefront per radicand / denominator
+        if(idx >= count) { return; }
+        const int lane = (int)threadIdx.x & 63;
+        const float x = __builtin_bit_cast(float, 0x3f800000u + first + idx);
+        v2f seed, n, r;
+        if(DIRECT) {
+                n = v2f{x, x};
+                r = v2f{1.f / x, 1.f / x};
+        } else {
+                n = sqrt_rsq(v2f{x, x}, seed);
+                r = recip_exact(n, seed);
+        }
+        unsigned long long bad = 0;
+        // lane l takes numerator mantissas 2 l, 2 l + 1, then + 128, ...
+        for(unsigned m = (unsigned)lane * 2; m < (1u << 23); m += 128) {
+                const v2f a = v2f{__builtin_bit_cast(float, 0x3f800000u + m), __builtin_bit_cast(float, 0x3f800000u + m + 1)};
+                const v2f q = div_exact_recip(a, n, r);
+                const v2f want = v2f{a.x / n.x, a.y / n.y};
+                const bool bx = __builtin_bit_cast(unsigned, q.x) != __builtin_bit_cast(unsigned, want.x);
+                const bool by = __builtin_bit_cast(unsigned, q.y) != __builtin_bit_cast(unsigned, want.y);
+                if(bx || by) {
+                        bad += (unsigned long long)bx + by;
+                        const unsigned long long k = atomicAdd(&mism[9], 1ull);
+                        if(k < 8) { mism[1 + k] = ((unsigned long long)(0x3f800000u + first + idx) << 32) | (0x3f800000u + m + (bx ? 0 : 1)); }
+                }
+        }
+        if(bad) { atomicAdd(&mism[0], bad); }
 }
 
 }  // namespace j2p

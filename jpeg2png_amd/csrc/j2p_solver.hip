@@ -1680,4 +1680,29 @@ int j2p_sqrt_exhaustive(int device, unsigned long long *rsq_mismatches, unsigned
         return J2P_OK;
 }
 
+// one pass (or slice of a pass) of the short division's exhaustive checks (see k_recip_exhaustive);
+// report[0] = mismatches, report[1..8] = the first offenders
+int j2p_division_exhaustive(int device, int pass, unsigned first, unsigned count, unsigned long long report[9])
+{
+        if(pass < 1 || pass > 3) { return fail(J2P_EINVAL, "pass must be 1, 2 or 3"); }
+        if(!report) { return fail(J2P_EINVAL, "NULL argument"); }
+        int ndev = 0;
+        if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { return fail(J2P_EDEVICE, "no HIP device available"); }
+        DeviceGuard guard(device);
+        if(!guard.ok) { return fail(J2P_EDEVICE, "hipSetDevice(%d) failed", device); }
+        unsigned long long *dm = nullptr, hm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        HIP_TRY(dev_malloc((void **)&dm, sizeof(hm)));
+        hipError_t e = hipMemset(dm, 0, sizeof(hm));
+        if(e == hipSuccess) {
+                if(pass == 1) { hipLaunchKernelGGL(k_recip_exhaustive, dim3(8192), dim3(256), 0, nullptr, dm); }
+                else if(pass == 2) { hipLaunchKernelGGL(k_div_exhaustive<false>, dim3((count + 3) / 4), dim3(256), 0, nullptr, first, count, dm); }
+                else { hipLaunchKernelGGL(k_div_exhaustive<true>, dim3((count + 3) / 4), dim3(256), 0, nullptr, first, count, dm); }
+                e = hipMemcpy(hm, dm, sizeof(hm), hipMemcpyDeviceToHost);
+        }
+        (void)hipFree(dm);
+        if(e != hipSuccess) { return fail(J2P_EDEVICE, "division_exhaustive: %s", hipGetErrorString(e)); }
+        for(int i = 0; i < 9; i++) { report[i] = hm[i]; }
+        return J2P_OK;
+}
+
 }  // extern "C"

@@ -45,6 +45,45 @@ def test_square_roots_exhaustively(lib):
     assert j.sqrt_exhaustive() == (0, 0)
 
 
+def test_short_division_exhaustively(lib):
+    """phase B's one-correction division (div_exact_recip with an IEEE reciprocal) equals `/` for EVERY denominator
+    mantissa against EVERY numerator mantissa — 2^46 quotients, about 16 s of GPU; scaling either operand by a power
+    of two scales every step exactly and the kernels' operand screens keep all of it normal, so this is all cases"""
+    import jpeg2png_amd as j
+    bad, offenders = 0, []
+    for first in range(0, 1 << 23, 1 << 16):
+        b, off = j.division_exhaustive(3, first, 1 << 16)
+        bad += b
+        offenders += off
+    assert bad == 0, offenders[:8]
+
+
+def test_phase_a_short_division_fails_only_where_the_kernel_does_not_use_it(lib):
+    """phase A refines the reciprocal of a norm twice from the v_rsq_f32 seed and corrects each quotient once.  Pass 1:
+    that reciprocal is the correctly rounded 1 / n for EVERY norm except those with an all-ones mantissa — two radicands
+    per binade pair, whose own mantissa ends in 0x7ffffe / 0x7fffff.  Pass 2 (sampled here; tools/division_exhaustive.py
+    runs all 2^47 quotients, profiles/r03_division_exhaustive.jsonl): the one-correction quotient is `/` for every
+    numerator except at those radicands.  k_gradient sends every row holding a radicand whose low 16 bits are >= 0xfffe
+    down the IEEE path (allones_candidate), which covers them."""
+    import jpeg2png_amd as j
+    bad, offenders = j.division_exhaustive(1)
+    assert bad == 226                                   # 2 radicands in each of the 113 binade pairs of [2^-100, 2^127)
+    for bits in offenders:
+        assert int(bits, 16) & 0xffff >= 0xfffe
+    total = 1 << 24
+    size = 1 << 14
+    rng = np.random.default_rng(3)
+    firsts = [0, (1 << 23) - size, 1 << 23, total - size] + [int(v) for v in rng.integers(0, total // size, 28) * size]
+    for first in firsts:
+        b, off = j.division_exhaustive(2, first, size)
+        for o in off:
+            assert (int(o, 16) >> 32) & 0xffff >= 0xfffe, f"slice {first}: {o}"
+        if first != total - size:
+            assert b == 0, f"slice {first}: {off}"
+        else:
+            assert 0 < b <= 8                           # the two radicands just below 4
+
+
 def test_decode_plane_bit_exact(lib, oracle):
     import jpeg2png_amd as j
     from jpeg2png_amd import synth
