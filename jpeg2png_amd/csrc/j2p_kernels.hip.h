@@ -361,6 +361,14 @@ __device__ __forceinline__ float lane_from_right(float v)   // value held by lan
 __device__ __forceinline__ v2f left_of(v2f a) { return v2f{lane_from_left(a.y), a.x}; }
 __device__ __forceinline__ v2f right_of(v2f a) { return v2f{a.y, lane_from_right(a.x)}; }
 
+// The lane shifts feed one addition or subtraction each.  Written per element, the shifted operand goes into the
+// instruction itself (v_add_f32_dpp / v_subrev_f32_dpp) and its partner is one plain v_add_f32: no v_mov_b32_dpp and no
+// v_mov_b32 to line the pair up for a packed operation (11.5 -> ~7 issue cycles per shifted pair, eight of them per row)
+__device__ __forceinline__ v2f add_left_of(v2f g, v2f t) { return v2f{g.x + lane_from_left(t.y), g.y + t.x}; }     // g + left_of(t)
+__device__ __forceinline__ v2f add_right_of(v2f g, v2f t) { return v2f{g.x + t.y, g.y + lane_from_right(t.x)}; }  // g + right_of(t)
+__device__ __forceinline__ v2f minus_left_of(v2f a) { return v2f{a.x - lane_from_left(a.y), a.y - a.x}; }         // a - left_of(a)
+__device__ __forceinline__ v2f right_of_minus(v2f a) { return v2f{a.y - a.x, lane_from_right(a.x) - a.y}; }       // right_of(a) - a
+
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
 // shared part of the division: reciprocal refined by one Newton step
@@ -463,8 +471,8 @@ struct MarchTag {
 
 template <int NCH, bool TGV>
 struct SourceTerms {
-        v2f tvxL[NCH], tvo[NCH], tvy[NCH];                        // TV: from (x-1), own, to the row below
-        v2f A[NCH], O[NCH], B[NCH], CL[NCH], CR[NCH];             // TGV2 (A is shifted left/right at its use)
+        v2f tvx[NCH], tvo[NCH], tvy[NCH];                         // TV: to (x+1) (shifted at its use), own, to the row below
+        v2f A[NCH], O[NCH], B[NCH], C[NCH];                       // TGV2 (A and C are shifted left / right at their uses)
 };
 
 // sqrtf for 2^-100 <= x < 2^127 through the reciprocal square root: the compiler's own expansion
@@ -637,8 +645,8 @@ __device__ __forceinline__ void source_prepare(const v2f (&gx)[NCH], const v2f (
                 for(int c = 0; c < NCH; c++) {
                         // MASKED == false: the caller knows every mask is 1 here (v * 1.f is v, so dropping
                         // the products changes no bit)
-                        p.xx[c] = MASKED ? (gx[c] - left_of(gx[c])) * m_hx : gx[c] - left_of(gx[c]);
-                        const v2f gyx = MASKED ? (gy[c] - left_of(gy[c])) * m_hx : gy[c] - left_of(gy[c]);
+                        p.xx[c] = MASKED ? minus_left_of(gx[c]) * m_hx : minus_left_of(gx[c]);
+                        const v2f gyx = MASKED ? minus_left_of(gy[c]) * m_hx : minus_left_of(gy[c]);
                         const v2f gxy = MASKED ? (gx[c] - gxp[c]) * m_hy : gx[c] - gxp[c];
                         p.yy[c] = MASKED ? (gy[c] - gyp[c]) * m_hy : gy[c] - gyp[c];
                         p.sy[c] = (gxy + gyx) * 0.5f;                     // (g_xy + g_yx) / 2.
@@ -671,7 +679,7 @@ __device__ __forceinline__ void source_finish(const v2f (&gx)[NCH], const v2f (&
                 const v2f num[3] = {a1 * gx[c], a1 * gy[c], a1 * -(gx[c] + gy[c])};
                 v2f q[3];
                 div_n<FAST, LOG, 3>(num, d1, r1, q);
-                s.tvxL[c] = left_of(q[0]);
+                s.tvx[c] = q[0];
                 s.tvy[c] = q[1];
                 s.tvo[c] = q[2];
         }
@@ -694,13 +702,10 @@ __device__ __forceinline__ void source_finish(const v2f (&gx)[NCH], const v2f (&
                         v2f num[4], q[4];
                         tgv_numerators<FAST>(p.xx[c], p.sy[c], p.yy[c], num);
                         div_n<FAST, LOG, 4>(num, d2, r2, q);
-                        const v2f tA = a2 * q[0];                                       // to (x-1,y), (x+1,y)
+                        s.A[c] = a2 * q[0];                                             // to (x-1,y), (x+1,y)
                         s.B[c] = a2 * q[1];                                             // to (x,y-1), (x,y+1)
-                        const v2f tC = a2 * -q[2];                                      // to (x+1,y-1), (x-1,y+1)
+                        s.C[c] = a2 * -q[2];                                            // to (x+1,y-1), (x-1,y+1)
                         s.O[c] = own_term<FAST>(a2, q[3]);                              // own
-                        s.A[c] = tA;
-                        s.CL[c] = left_of(tC);
-                        s.CR[c] = right_of(tC);
                 }
         }
 }
@@ -718,8 +723,8 @@ __device__ __forceinline__ void source_prepare_joint(int cidx, int lane, int par
 {
         v2f xx = v2f{0.f, 0.f}, sy = xx, yy = xx, tq = xx;
         if(TGV) {
-                xx = MASKED ? (gx - left_of(gx)) * m_hx : gx - left_of(gx);
-                const v2f gyx = MASKED ? (gy - left_of(gy)) * m_hx : gy - left_of(gy);
+                xx = MASKED ? minus_left_of(gx) * m_hx : minus_left_of(gx);
+                const v2f gyx = MASKED ? minus_left_of(gy) * m_hx : minus_left_of(gy);
                 const v2f gxy = MASKED ? (gx - gxp) * m_hy : gx - gxp;
                 yy = MASKED ? (gy - gyp) * m_hy : gy - gyp;
                 sy = (gxy + gyx) * 0.5f;
@@ -973,7 +978,7 @@ void k_gradient(GradArgs a)
                 const float m_gy = gr >= 0 && gr < H - 1 ? 1.f : 0.f;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
-                        gx[c] = FREE ? right_of(yc[c]) - yc[c] : (right_of(yc[c]) - yc[c]) * m_gx;
+                        gx[c] = FREE ? right_of_minus(yc[c]) : right_of_minus(yc[c]) * m_gx;
                         gy[c] = FREE ? yn[c] - yc[c] : (yn[c] - yc[c]) * m_gy;
                 }
         };
@@ -1117,16 +1122,16 @@ void k_gradient(GradArgs a)
                                         v2f g = v2f{0.f, 0.f};
                                         if(FREE || (unsigned)gt < k.ch * k.hs) { g += p_scale[c] * PV[PM1][c]; }   // row t, fetched R-1 trips ago
                                         g += up.tvy[c];                  // TV from (x, t-1)
-                                        g += mid.tvxL[c];                // TV from (x-1, t)
+                                        g = add_left_of(g, mid.tvx[c]);  // TV from (x-1, t)
                                         g += mid.tvo[c];                 // TV own
                                         if(TGV) {
-                                                g += up.B[c];            // (x,   t-1)
-                                                g += up.CR[c];           // (x+1, t-1)
-                                                g += left_of(mid.A[c]);  // (x-1, t)
-                                                g += mid.O[c];           // own
-                                                g += right_of(mid.A[c]); // (x+1, t)
-                                                g += s.CL[c];            // (x-1, t+1)
-                                                g += s.B[c];             // (x,   t+1)
+                                                g += up.B[c];                    // (x,   t-1)
+                                                g = add_right_of(g, up.C[c]);    // (x+1, t-1)
+                                                g = add_left_of(g, mid.A[c]);    // (x-1, t)
+                                                g += mid.O[c];                   // own
+                                                g = add_right_of(g, mid.A[c]);   // (x+1, t)
+                                                g = add_left_of(g, s.C[c]);      // (x-1, t+1)
+                                                g += s.B[c];                     // (x,   t+1)
                                         }
                                         if(pair_own) {
 #ifdef J2P_EXP_NOTRAFFIC
