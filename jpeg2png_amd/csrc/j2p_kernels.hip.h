@@ -347,6 +347,18 @@ __device__ __forceinline__ double block_sum(double v, double *red /* >= 4 double
 // ---------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// Everything below is written once for a lane's PIXEL VECTOR V: v2f = two neighbouring columns per lane, the arithmetic
+// issuing as packed operations (128-column strips: what canvases that fill the chip use), or float = one column per
+// lane (64-column strips: twice the wavefronts with half the work each, for canvases whose launches would otherwise
+// leave most wavefront slots empty — packed f32 operations cost two plain ones on gfx950, so nothing is lost per pixel
+// but the halo columns).  The few places that care which of the two they are dealing with are these overloads.
+template <class V>
+__device__ __forceinline__ V splat(float s);
+template <>
+__device__ __forceinline__ float splat<float>(float s) { return s; }
+template <>
+__device__ __forceinline__ v2f splat<v2f>(float s) { return v2f{s, s}; }
+
 // wave_shr:1 / wave_shl:1 with bound_ctrl: the lane without a source reads 0, and because no "old" value
 // has to be supplied the compiler does not spend a v_mov on initialising the destination
 __device__ __forceinline__ float lane_from_left(float v)    // value held by lane-1 (0 in lane 0)
@@ -357,57 +369,114 @@ __device__ __forceinline__ float lane_from_right(float v)   // value held by lan
 {
         return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
-// columns x-1 / x+1 of a lane's column pair
+// columns x-1 / x+1 of a lane's pixel vector
 __device__ __forceinline__ v2f left_of(v2f a) { return v2f{lane_from_left(a.y), a.x}; }
 __device__ __forceinline__ v2f right_of(v2f a) { return v2f{a.y, lane_from_right(a.x)}; }
+__device__ __forceinline__ float left_of(float a) { return lane_from_left(a); }
+__device__ __forceinline__ float right_of(float a) { return lane_from_right(a); }
 
-// The lane shifts feed one addition or subtraction each.  Written per element, the shifted operand goes into the
-// instruction itself (v_add_f32_dpp / v_subrev_f32_dpp) and its partner is one plain v_add_f32: no v_mov_b32_dpp and no
-// v_mov_b32 to line the pair up for a packed operation (11.5 -> ~7 issue cycles per shifted pair, eight of them per row)
+// The lane shifts feed one addition or subtraction each.  Written per element, the shifted operand can go into the
+// instruction itself (v_add_f32_dpp / v_subrev_f32_dpp) with one plain v_add_f32 as its partner
 __device__ __forceinline__ v2f add_left_of(v2f g, v2f t) { return v2f{g.x + lane_from_left(t.y), g.y + t.x}; }     // g + left_of(t)
 __device__ __forceinline__ v2f add_right_of(v2f g, v2f t) { return v2f{g.x + t.y, g.y + lane_from_right(t.x)}; }  // g + right_of(t)
 __device__ __forceinline__ v2f minus_left_of(v2f a) { return v2f{a.x - lane_from_left(a.y), a.y - a.x}; }         // a - left_of(a)
 __device__ __forceinline__ v2f right_of_minus(v2f a) { return v2f{a.y - a.x, lane_from_right(a.x) - a.y}; }       // right_of(a) - a
+__device__ __forceinline__ float add_left_of(float g, float t) { return g + lane_from_left(t); }
+__device__ __forceinline__ float add_right_of(float g, float t) { return g + lane_from_right(t); }
+__device__ __forceinline__ float minus_left_of(float a) { return a - lane_from_left(a); }
+__device__ __forceinline__ float right_of_minus(float a) { return lane_from_right(a) - a; }
 
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float pk_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// hardware approximations (1 ulp) and the IEEE forms, per element
+__device__ __forceinline__ v2f hw_rcp(v2f d) { return v2f{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)}; }
+__device__ __forceinline__ float hw_rcp(float d) { return __builtin_amdgcn_rcpf(d); }
+__device__ __forceinline__ v2f hw_rsq(v2f x) { return v2f{__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)}; }
+__device__ __forceinline__ float hw_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ v2f ieee_sqrt(v2f x) { return v2f{sqrtf(x.x), sqrtf(x.y)}; }
+__device__ __forceinline__ float ieee_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ v2f ieee_div(v2f x, v2f d) { return v2f{x.x / d.x, x.y / d.y}; }
+__device__ __forceinline__ float ieee_div(float x, float d) { return x / d; }
+// a where n != 0, 0 where n == 0 (compute.c:97,158); n where n != 0, 1 where n == 0; max(n, m)
+__device__ __forceinline__ v2f weight_unless_zero(v2f n, float a) { return v2f{n.x == 0.f ? 0.f : a, n.y == 0.f ? 0.f : a}; }
+__device__ __forceinline__ float weight_unless_zero(float n, float a) { return n == 0.f ? 0.f : a; }
+__device__ __forceinline__ v2f one_if_zero(v2f n) { return v2f{n.x == 0.f ? 1.f : n.x, n.y == 0.f ? 1.f : n.y}; }
+__device__ __forceinline__ float one_if_zero(float n) { return n == 0.f ? 1.f : n; }
+__device__ __forceinline__ v2f at_least(v2f n, float m) { return v2f{fmaxf(n.x, m), fmaxf(n.y, m)}; }
+__device__ __forceinline__ float at_least(float n, float m) { return fmaxf(n, m); }
+// acc += (double)(a * n) element by element, in column order (the log sums, compute.c:92,156)
+__device__ __forceinline__ void add_scaled(double &acc, float a, v2f n)
+{
+        acc += (double)(a * n.x);
+        acc += (double)(a * n.y);
+}
+__device__ __forceinline__ void add_scaled(double &acc, float a, float n) { acc += (double)(a * n); }
+// acc += (double)v element by element (compute.c:203)
+__device__ __forceinline__ void add_elements(double &acc, v2f v)
+{
+        acc += (double)v.x;
+        acc += (double)v.y;
+}
+__device__ __forceinline__ void add_elements(double &acc, float v) { acc += (double)v; }
+// the operand screen on bit patterns (see make_y in k_gradient): hi = largest |y|, lo = smallest non-zero |y| minus an ulp
+__device__ __forceinline__ void screen_update(unsigned &hi, unsigned &lo, v2f y)
+{
+        // (bit-cast the VECTOR: hipcc 7.2 turns element-wise casts of .x and .y into two reads of .x)
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        const v2u u = __builtin_bit_cast(v2u, y) & 0x7fffffffu;
+        const v2u um = u - 1u;
+        hi = max(hi, max(u.x, u.y));
+        lo = min(lo, min(um.x, um.y));
+}
+__device__ __forceinline__ void screen_update(unsigned &hi, unsigned &lo, float y)
+{
+        const unsigned u = __builtin_bit_cast(unsigned, y) & 0x7fffffffu;
+        hi = max(hi, u);
+        lo = min(lo, u - 1u);
+}
 
 // shared part of the division: reciprocal refined by one Newton step
-__device__ __forceinline__ v2f div_prepare(v2f d)
+template <class V>
+__device__ __forceinline__ V div_prepare(V d)
 {
-        const v2f r = v2f{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-        const v2f e = pk_fma(-d, r, v2f{1.f, 1.f});
+        const V r = hw_rcp(d);
+        const V e = pk_fma(-d, r, splat<V>(1.f));
         return pk_fma(e, r, r);
 }
 // x / d given r = div_prepare(d)
-__device__ __forceinline__ v2f div_shared(v2f x, v2f d, v2f r)
+template <class V>
+__device__ __forceinline__ V div_shared(V x, V d, V r)
 {
-        const v2f q0 = x * r;
-        const v2f q1 = pk_fma(pk_fma(-d, q0, x), r, q0);
+        const V q0 = x * r;
+        const V q1 = pk_fma(pk_fma(-d, q0, x), r, q0);
         return pk_fma(pk_fma(-d, q1, x), r, q1);
 }
-// ---- the SHORT division (phase B; candidates for phase A, see k_recip_exhaustive) ----
+// ---- the SHORT division ----
 // With r the CORRECTLY ROUNDED reciprocal of d, one residual correction is enough (Markstein): q0 = RN(x r),
-// e = x - d q0 (exact, one fma), q = RN(q0 + e r) is RN(x / d).  Three packed operations per quotient instead of five.
+// e = x - d q0 (exact, one fma), q = RN(q0 + e r) is RN(x / d).  Three operations per quotient instead of five.
 // Not taken on trust: j2p_division_exhaustive enumerates EVERY denominator mantissa against EVERY numerator mantissa
 // (2^46 quotients, GPU test) with r = 1.f / d; operand ranges as for div_shared (no intermediate can be subnormal).
-__device__ __forceinline__ v2f recip_exact(v2f d, v2f seed)
+template <class V>
+__device__ __forceinline__ V recip_exact(V d, V seed)
 {
-        const v2f one = v2f{1.f, 1.f};
-        const v2f r1 = pk_fma(pk_fma(-d, seed, one), seed, seed);
+        const V one = splat<V>(1.f);
+        const V r1 = pk_fma(pk_fma(-d, seed, one), seed, seed);
         return pk_fma(pk_fma(-d, r1, one), r1, r1);
 }
-__device__ __forceinline__ v2f div_exact_recip(v2f x, v2f d, v2f r)
+template <class V>
+__device__ __forceinline__ V div_exact_recip(V x, V d, V r)
 {
-        const v2f q0 = x * r;
+        const V q0 = x * r;
         return pk_fma(pk_fma(-d, q0, x), r, q0);
 }
 
 // the same for N numerators over one denominator, written breadth-first so that the N
 // independent fma chains are interleaved instead of issued back to back
-template <int N>
-__device__ __forceinline__ void div_shared_n(const v2f (&x)[N], v2f d, v2f r, v2f (&q)[N])
+template <int N, class V>
+__device__ __forceinline__ void div_shared_n(const V (&x)[N], V d, V r, V (&q)[N])
 {
-        v2f q0[N], e0[N], q1[N], e1[N];
+        V q0[N], e0[N], q1[N], e1[N];
 #pragma unroll
         for(int i = 0; i < N; i++) { q0[i] = x[i] * r; }
 #pragma unroll
@@ -451,8 +520,18 @@ __device__ __forceinline__ v2f sqrt_fast(v2f x)
         r = v2f{vs.x > 0.f ? up.x : r.x, vs.y > 0.f ? up.y : r.y};
         return r;
 }
+__device__ __forceinline__ float sqrt_fast(float x)
+{
+        const float s = __builtin_amdgcn_sqrtf(x);
+        const int si = __builtin_bit_cast(int, s);
+        const float dn = __builtin_bit_cast(float, si - 1), up = __builtin_bit_cast(float, si + 1);
+        const float vp = pk_fma(-dn, s, x), vs = pk_fma(-up, s, x);
+        float r = vp <= 0.f ? dn : s;
+        r = vs > 0.f ? up : r;
+        return r;
+}
 
-constexpr int kStripCols = 124;   // output columns per wavefront strip
+constexpr int kStripCols = 124;   // output columns per wavefront strip with two columns per lane (one: 60)
 #ifndef J2P_RING
 #define J2P_RING 4
 #endif
@@ -462,70 +541,61 @@ constexpr int kRing = J2P_RING;   // row slots = hand-unroll factor of the march
 
 // compile-time description of a strip for k_gradient's march: `value` = it touches no image / band / coverage
 // edge (clamps and masks are the identity), `unit` = additionally every channel of the wavefront is sampled 1x1
-// and covers all of the strip's columns (the prob state of a lane's column pair is one 8-byte load)
+// and covers all of the strip's columns (the prob state of a lane's pixel vector is one load at a row offset)
 template <bool FREE, bool UNIT>
 struct MarchTag {
         static constexpr bool value = FREE;
         static constexpr bool unit = UNIT;
 };
 
-template <int NCH, bool TGV>
+template <int NCH, bool TGV, class V = v2f>
 struct SourceTerms {
-        v2f tvx[NCH], tvo[NCH], tvy[NCH];                         // TV: to (x+1) (shifted at its use), own, to the row below
-        v2f A[NCH], O[NCH], B[NCH], C[NCH];                       // TGV2 (A and C are shifted left / right at their uses)
+        V tvx[NCH], tvo[NCH], tvy[NCH];                           // TV: to (x+1) (shifted at its use), own, to the row below
+        V A[NCH], O[NCH], B[NCH], C[NCH];                         // TGV2 (A and C are shifted left / right at their uses)
 };
 
 // sqrtf for 2^-100 <= x < 2^127 through the reciprocal square root: the compiler's own expansion
 // for the flush-denormal mode (one v_rsq_f32, then a coupled Newton step on sqrt and 1/(2 sqrt)
-// and a final residual correction), all packed.  Correctly rounded on that whole range — checked
+// and a final residual correction).  Correctly rounded on that whole range — checked
 // EXHAUSTIVELY against sqrtf() by j2p_sqrt_exhaustive (every float, GPU test).  Not valid for 0.
 // `r` receives the v_rsq_f32 values the root was made of.
-__device__ __forceinline__ v2f sqrt_rsq(v2f x, v2f &r)
+template <class V>
+__device__ __forceinline__ V sqrt_rsq(V x, V &r)
 {
-        r = v2f{__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)};
-        v2f s = x * r;
-        v2f h = r * 0.5f;
-        const v2f e = pk_fma(-h, s, v2f{0.5f, 0.5f});
+        r = hw_rsq(x);
+        V s = x * r;
+        V h = r * 0.5f;
+        const V e = pk_fma(-h, s, splat<V>(0.5f));
         h = pk_fma(h, e, h);
         s = pk_fma(s, e, s);
-        const v2f d = pk_fma(-s, s, x);
+        const V d = pk_fma(-s, s, x);
         return pk_fma(d, h, s);
 }
-__device__ __forceinline__ v2f sqrt_rsq(v2f x)
+template <class V>
+__device__ __forceinline__ V sqrt_rsq(V x)
 {
-        v2f r;
+        V r;
         return sqrt_rsq(x, r);
-}
-// The refined reciprocal of n = sqrt_rsq(x) for the divisions that follow, seeded with the v_rsq_f32 value the root
-// was made of instead of a v_rcp_f32 of its own (two transcendental instructions — 16 issue cycles — less per pixel
-// pair and norm): rsq(x) is 1 / sqrt(x) to 1 ulp and n is sqrt(x) to 1/2 ulp, so the seed is 1 / n to 1.5 ulp; one
-// Newton step squares that error (3e-14, against 1.4e-14 from a v_rcp_f32 seed): the refined value is 1 / n to within
-// its own rounding either way, and the quotient sequence of div_shared — two exact-residual corrections — delivers
-// the correctly rounded quotient from any such reciprocal, i.e. the bits of `/`  (j2p_math_selftest compares).
-__device__ __forceinline__ v2f div_prepare_seeded(v2f d, v2f seed)
-{
-        const v2f e = pk_fma(-d, seed, v2f{1.f, 1.f});
-        return pk_fma(e, seed, seed);
 }
 
 // EXACT_ZERO: result must be sqrtf(x) including x == 0 (the log sums read the norm itself).
 // Otherwise only a positive divisor is needed when x == 0 (every numerator is 0 then): on the
 // screened path x is 0 or >= 2^-88, so x + 2^-120 is x itself unless x == 0, where the root comes
-// out as exactly 2^-60 (checked by j2p_math_selftest) — one packed add instead of clamping both
+// out as exactly 2^-60 (checked by j2p_math_selftest) — one add instead of clamping both
 // the radicand and the root.
-template <bool FAST, bool EXACT_ZERO>
-__device__ __forceinline__ v2f sqrt_pair(v2f x)
+template <bool FAST, bool EXACT_ZERO, class V>
+__device__ __forceinline__ V sqrt_pair(V x)
 {
-        if(!FAST) { return v2f{sqrtf(x.x), sqrtf(x.y)}; }
+        if(!FAST) { return ieee_sqrt(x); }
         if(EXACT_ZERO) { return sqrt_fast(x); }
-        return sqrt_rsq(x + v2f{0x1p-120f, 0x1p-120f});
+        return sqrt_rsq(x + splat<V>(0x1p-120f));
 }
 // divisor for the quotients of a pixel whose norm is n (see sqrt_pair)
-template <bool FAST, bool EXACT_ZERO>
-__device__ __forceinline__ v2f divisor_of(v2f n)
+template <bool FAST, bool EXACT_ZERO, class V>
+__device__ __forceinline__ V divisor_of(V n)
 {
-        if(!FAST) { return v2f{n.x == 0.f ? 1.f : n.x, n.y == 0.f ? 1.f : n.y}; }   // divide by 1, scale by 0
-        if(EXACT_ZERO) { return v2f{fmaxf(n.x, 0x1p-60f), fmaxf(n.y, 0x1p-60f)}; }
+        if(!FAST) { return one_if_zero(n); }                                       // divide by 1, scale by 0
+        if(EXACT_ZERO) { return at_least(n, 0x1p-60f); }
         return n;                                                                  // already >= 2^-60
 }
 // what the source terms need of a sum of squares x: the norm n = sqrtf(x), the divisor d made from it and the
@@ -536,28 +606,29 @@ __device__ __forceinline__ v2f divisor_of(v2f n)
 // radicand x every numerator enumerated, clean except at those norms).  The march sends rows that may hold such a
 // norm down the unscreened path (allones_candidate).  Per pixel pair 4 + 7 x 3 packed operations instead of
 // 2 + 2 transcendental + 7 x 5.
-template <bool FAST, bool EXACT_ZERO>
-__device__ __forceinline__ void norm_and_reciprocal(v2f x, v2f &n, v2f &d, v2f &r)
+template <bool FAST, bool EXACT_ZERO, class V>
+__device__ __forceinline__ void norm_and_reciprocal(V x, V &n, V &d, V &r)
 {
 #ifdef J2P_EXP_NOARITH
-        n = x * 0.75f + v2f{1.f, 1.f};
+        n = x * 0.75f + splat<V>(1.f);
         d = n;
         r = n;
         return;
 #endif
         if constexpr(FAST && !EXACT_ZERO) {
-                v2f seed;
-                n = sqrt_rsq(x + v2f{0x1p-120f, 0x1p-120f}, seed);
+                V seed;
+                n = sqrt_rsq(x + splat<V>(0x1p-120f), seed);
                 d = n;
                 r = recip_exact(d, seed);
         } else {
                 n = sqrt_pair<FAST, EXACT_ZERO>(x);
                 d = divisor_of<FAST, EXACT_ZERO>(n);
-                r = FAST ? div_prepare(d) : d;
+                if constexpr(FAST) { r = div_prepare(d); }
+                else { r = d; }
         }
 }
-template <bool FAST, bool EXACT_ZERO, int N>
-__device__ __forceinline__ void div_n(const v2f (&x)[N], v2f d, v2f r, v2f (&q)[N])
+template <bool FAST, bool EXACT_ZERO, int N, class V>
+__device__ __forceinline__ void div_n(const V (&x)[N], V d, V r, V (&q)[N])
 {
 #ifdef J2P_EXP_NOARITH
 #pragma unroll
@@ -567,17 +638,17 @@ __device__ __forceinline__ void div_n(const v2f (&x)[N], v2f d, v2f r, v2f (&q)[
         if constexpr(FAST && !EXACT_ZERO) {
 #pragma unroll
                 for(int i = 0; i < N; i++) { q[i] = div_exact_recip(x[i], d, r); }
-        } else if(FAST) {
+        } else if constexpr(FAST) {
                 div_shared_n<N>(x, d, r, q);
         } else {
 #pragma unroll
-                for(int i = 0; i < N; i++) { q[i] = v2f{x[i].x / d.x, x[i].y / d.y}; }
+                for(int i = 0; i < N; i++) { q[i] = ieee_div(x[i], d); }
         }
 }
-// true when one of the four radicands of a pixel pair MAY give a norm with an all-ones mantissa: such a norm is the root
+// true when one of the radicands of a lane's pixels MAY give a norm with an all-ones mantissa: such a norm is the root
 // of a radicand whose own mantissa ends in 0x7ffffe or 0x7fffff, so "the low 16 bits are >= 0xfffe" is necessary — one
-// row in ~120 trips a wavefront, which then takes the unscreened (IEEE) path for that row; three packed 16-bit maxima and
-// one compare per pixel pair
+// row in ~120 trips of a wavefront, which then takes the unscreened (IEEE) path for that row; a few 16-bit maxima and
+// one compare per lane
 __device__ __forceinline__ bool allones_candidate(v2f r1, v2f r2)
 {
         typedef unsigned short v2h __attribute__((ext_vector_type(2)));
@@ -587,15 +658,21 @@ __device__ __forceinline__ bool allones_candidate(v2f r1, v2f r2)
                                                 __builtin_elementwise_max(__builtin_bit_cast(v2h, b.x), __builtin_bit_cast(v2h, b.y)));
         return m.x >= (unsigned short)0xfffe;
 }
+__device__ __forceinline__ bool allones_candidate(float r1, float r2)
+{
+        typedef unsigned short v2h __attribute__((ext_vector_type(2)));
+        const v2h m = __builtin_elementwise_max(__builtin_bit_cast(v2h, r1), __builtin_bit_cast(v2h, r2));
+        return m.x >= (unsigned short)0xfffe;
+}
 
-// The four TGV2 numerators of a pixel pair (compute.c:165-182): s + gxx, gyy + s, s (its sign goes onto the quotient)
+// The four TGV2 numerators of a pixel (compute.c:165-182): s + gxx, gyy + s, s (its sign goes onto the quotient)
 // and the own term 2 gxx + 2 s + 2 gyy.  On the screened path every operand is a multiple of 2^-44 below 2^43, so
 // doubling commutes with every rounding involved — (2 gxx + 2 s) + 2 gyy == 2 ((gxx + s) + gyy), and gxx + s is the
 // first numerator (float addition commutes) — and the factor 2 moves through the division and onto the weight:
 // a2 * -((2 m) / n) == (2 a2) * -(m / n), all of it exact scaling.  Three multiplications and one addition less
 // per pixel; the unscreened path (subnormal operands possible) keeps the reference's expression.
-template <bool FAST>
-__device__ __forceinline__ void tgv_numerators(v2f xx, v2f sy, v2f yy, v2f (&num)[4])
+template <bool FAST, class V>
+__device__ __forceinline__ void tgv_numerators(V xx, V sy, V yy, V (&num)[4])
 {
         num[0] = sy + xx;
         num[1] = yy + sy;
@@ -603,33 +680,33 @@ __device__ __forceinline__ void tgv_numerators(v2f xx, v2f sy, v2f yy, v2f (&num
         if(FAST) { num[3] = num[0] + yy; }
         else { num[3] = 2.f * xx + 2.f * sy + 2.f * yy; }
 }
-template <bool FAST>
-__device__ __forceinline__ v2f own_term(v2f a2, v2f q3)
+template <bool FAST, class V>
+__device__ __forceinline__ V own_term(V a2, V q3)
 {
         if(FAST) { return (2.f * a2) * -q3; }       // 2 a2: exact and wave-uniform (hoisted out of the march)
         return a2 * -q3;
 }
 
-// Source terms of one image row for a lane's column pair, in two steps.  gx,gy: forward differences of this row,
+// Source terms of one image row for a lane's pixel vector, in two steps.  gx,gy: forward differences of this row,
 // gxp,gyp: of the row above.  m_hx / m_hy zero the second differences on the first column / first row
 // (compute.c:137-143).
 //   source_prepare : the second differences and the two sums of squares under the norms (the same arithmetic on every
 //                    path) — from which the march decides which path the row takes
 //   source_finish  : norms, quotients, weights.  FAST: the screened path (short sequences, see norm_and_reciprocal);
 //                    otherwise plain `/` and sqrtf().  tv / tv2 receive the log sums when `log_row`.
-template <int NCH, bool TGV>
+template <int NCH, bool TGV, class V = v2f>
 struct SourcePrep {
-        v2f n1r, n2r;                              // gx^2 + gy^2 summed over the channels; the TGV2 counterpart
-        v2f xx[NCH], sy[NCH], yy[NCH];
+        V n1r, n2r;                                // gx^2 + gy^2 summed over the channels; the TGV2 counterpart
+        V xx[NCH], sy[NCH], yy[NCH];
 };
 
-template <int NCH, bool TGV, bool MASKED>
-__device__ __forceinline__ void source_prepare(const v2f (&gx)[NCH], const v2f (&gy)[NCH], const v2f (&gxp)[NCH],
-                                               const v2f (&gyp)[NCH], v2f m_hx, v2f m_hy, SourcePrep<NCH, TGV> &p)
+template <int NCH, bool TGV, bool MASKED, class V>
+__device__ __forceinline__ void source_prepare(const V (&gx)[NCH], const V (&gy)[NCH], const V (&gxp)[NCH],
+                                               const V (&gyp)[NCH], V m_hx, V m_hy, SourcePrep<NCH, TGV, V> &p)
 {
         // ---- TV (compute.c:84-89) ----
         // (the reference starts the sum at 0.f; a square is never -0, so 0.f + gx * gx is gx * gx bit for bit)
-        v2f n1 = gx[0] * gx[0];
+        V n1 = gx[0] * gx[0];
         n1 += gy[0] * gy[0];
 #pragma unroll
         for(int c = 1; c < NCH; c++) {
@@ -637,20 +714,20 @@ __device__ __forceinline__ void source_prepare(const v2f (&gx)[NCH], const v2f (
                 n1 += gy[c] * gy[c];
         }
         p.n1r = n1;
-        p.n2r = v2f{0.f, 0.f};
+        p.n2r = splat<V>(0.f);
         // ---- TGV2 (compute.c:136-152) ----
         if(TGV) {
-                v2f n2 = v2f{0.f, 0.f};
+                V n2 = splat<V>(0.f);
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
                         // MASKED == false: the caller knows every mask is 1 here (v * 1.f is v, so dropping
                         // the products changes no bit)
                         p.xx[c] = MASKED ? minus_left_of(gx[c]) * m_hx : minus_left_of(gx[c]);
-                        const v2f gyx = MASKED ? minus_left_of(gy[c]) * m_hx : minus_left_of(gy[c]);
-                        const v2f gxy = MASKED ? (gx[c] - gxp[c]) * m_hy : gx[c] - gxp[c];
+                        const V gyx = MASKED ? minus_left_of(gy[c]) * m_hx : minus_left_of(gy[c]);
+                        const V gxy = MASKED ? (gx[c] - gxp[c]) * m_hy : gx[c] - gxp[c];
                         p.yy[c] = MASKED ? (gy[c] - gyp[c]) * m_hy : gy[c] - gyp[c];
                         p.sy[c] = (gxy + gyx) * 0.5f;                     // (g_xy + g_yx) / 2.
-                        const v2f term = p.xx[c] * p.xx[c] + 2.f * (p.sy[c] * p.sy[c]) + p.yy[c] * p.yy[c];
+                        const V term = p.xx[c] * p.xx[c] + 2.f * (p.sy[c] * p.sy[c]) + p.yy[c] * p.yy[c];
                         if(c == 0) { n2 = term; }                       // 0.f + term is term: never -0
                         else { n2 += term; }
                 }
@@ -658,26 +735,23 @@ __device__ __forceinline__ void source_prepare(const v2f (&gx)[NCH], const v2f (
         }
 }
 
-template <int NCH, bool TGV, bool LOG, bool FAST>
-__device__ __forceinline__ void source_finish(const v2f (&gx)[NCH], const v2f (&gy)[NCH], const SourcePrep<NCH, TGV> &p, float a_tv,
-                                              float a_tgv, bool log_row, double &tv, double &tv2, SourceTerms<NCH, TGV> &s)
+template <int NCH, bool TGV, bool LOG, bool FAST, class V>
+__device__ __forceinline__ void source_finish(const V (&gx)[NCH], const V (&gy)[NCH], const SourcePrep<NCH, TGV, V> &p, float a_tv,
+                                              float a_tgv, bool log_row, double &tv, double &tv2, SourceTerms<NCH, TGV, V> &s)
 {
         // ---- TV (compute.c:90-104) ----
-        v2f n1, d1, r1;
+        V n1, d1, r1;
         norm_and_reciprocal<FAST, LOG>(p.n1r, n1, d1, r1);
-        if(LOG && log_row) {
-                tv += (double)(a_tv * n1.x);
-                tv += (double)(a_tv * n1.y);
-        }
+        if(LOG && log_row) { add_scaled(tv, a_tv, n1); }
         // A pixel with zero norm contributes nothing (compute.c:97).  Screened path: n == 0 implies
         // every numerator is exactly 0 (no square can underflow), so any positive divisor gives 0.
         // Unscreened path: divide by 1, scale by 0.
-        const v2f a1 = FAST ? v2f{a_tv, a_tv} : v2f{n1.x == 0.f ? 0.f : a_tv, n1.y == 0.f ? 0.f : a_tv};
+        const V a1 = FAST ? splat<V>(a_tv) : weight_unless_zero(n1, a_tv);
 #pragma unroll
         for(int c = 0; c < NCH; c++) {
                 if(NCH > 1) { __builtin_amdgcn_sched_barrier(0); }   // one channel at a time: bounds the live ranges
-                const v2f num[3] = {a1 * gx[c], a1 * gy[c], a1 * -(gx[c] + gy[c])};
-                v2f q[3];
+                const V num[3] = {a1 * gx[c], a1 * gy[c], a1 * -(gx[c] + gy[c])};
+                V q[3];
                 div_n<FAST, LOG, 3>(num, d1, r1, q);
                 s.tvx[c] = q[0];
                 s.tvy[c] = q[1];
@@ -685,21 +759,17 @@ __device__ __forceinline__ void source_finish(const v2f (&gx)[NCH], const v2f (&
         }
         // ---- TGV2 (compute.c:153-183) ----
         if(TGV) {
-                v2f n2, d2, r2;
+                V n2, d2, r2;
                 norm_and_reciprocal<FAST, LOG>(p.n2r, n2, d2, r2);
-                if(LOG && log_row) {
-                        tv2 += (double)(a_tgv * n2.x);
-                        tv2 += (double)(a_tgv * n2.y);
-                }
-                const v2f a2 = FAST ? v2f{a_tgv, a_tgv}
-                                    : v2f{n2.x == 0.f ? 0.f : a_tgv, n2.y == 0.f ? 0.f : a_tgv};   // compute.c:158
+                if(LOG && log_row) { add_scaled(tv2, a_tgv, n2); }
+                const V a2 = FAST ? splat<V>(a_tgv) : weight_unless_zero(n2, a_tgv);   // compute.c:158
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
                         if(NCH > 1) { __builtin_amdgcn_sched_barrier(0); }
                         // a2 * (expr / n2): division first (compute.c:165-182)
                         // the two negative numerators are divided as positives and the sign goes onto the quotient:
                         // (-v) / n == -(v / n) bit for bit, in the IEEE and in the short sequences alike
-                        v2f num[4], q[4];
+                        V num[4], q[4];
                         tgv_numerators<FAST>(p.xx[c], p.sy[c], p.yy[c], num);
                         div_n<FAST, LOG, 4>(num, d2, r2, q);
                         s.A[c] = a2 * q[0];                                             // to (x-1,y), (x+1,y)
@@ -716,16 +786,16 @@ __device__ __forceinline__ void source_finish(const v2f (&gx)[NCH], const v2f (&
 // differences, and after one barrier every wavefront adds them up in the reference's order
 // ((((0 + gx0^2) + gy0^2) + gx1^2) + ... ; per-channel Hessian terms likewise), so all of them
 // hold bit-identical sums — and take the same path — and the rest of the work (source_finish<1, ...>)
-// stays private to the channel.  `xchg` is a double-buffered LDS area: [2][J][64 lanes][3] float2.
-template <int J, bool TGV, bool MASKED>
-__device__ __forceinline__ void source_prepare_joint(int cidx, int lane, int parity, v2f *xchg, v2f gx, v2f gy, v2f gxp, v2f gyp,
-                                                     v2f m_hx, v2f m_hy, SourcePrep<1, TGV> &p)
+// stays private to the channel.  `xchg` is a double-buffered LDS area: [2][J][64 lanes][3] pixel vectors.
+template <int J, bool TGV, bool MASKED, class V>
+__device__ __forceinline__ void source_prepare_joint(int cidx, int lane, int parity, V *xchg, V gx, V gy, V gxp, V gyp,
+                                                     V m_hx, V m_hy, SourcePrep<1, TGV, V> &p)
 {
-        v2f xx = v2f{0.f, 0.f}, sy = xx, yy = xx, tq = xx;
+        V xx = splat<V>(0.f), sy = xx, yy = xx, tq = xx;
         if(TGV) {
                 xx = MASKED ? minus_left_of(gx) * m_hx : minus_left_of(gx);
-                const v2f gyx = MASKED ? minus_left_of(gy) * m_hx : minus_left_of(gy);
-                const v2f gxy = MASKED ? (gx - gxp) * m_hy : gx - gxp;
+                const V gyx = MASKED ? minus_left_of(gy) * m_hx : minus_left_of(gy);
+                const V gxy = MASKED ? (gx - gxp) * m_hy : gx - gxp;
                 yy = MASKED ? (gy - gyp) * m_hy : gy - gyp;
                 sy = (gxy + gyx) * 0.5f;
                 tq = xx * xx + 2.f * (sy * sy) + yy * yy;
@@ -733,18 +803,18 @@ __device__ __forceinline__ void source_prepare_joint(int cidx, int lane, int par
         p.xx[0] = xx;
         p.sy[0] = sy;
         p.yy[0] = yy;
-        v2f *mine = xchg + ((size_t)(parity * J + cidx) * 64 + lane) * 3;
+        V *mine = xchg + ((size_t)(parity * J + cidx) * 64 + lane) * 3;
         mine[0] = gx * gx;
         mine[1] = gy * gy;
         mine[2] = tq;
         __syncthreads();
         // (sums start with channel 0's terms: 0.f + a square is the square, see source_prepare)
-        const v2f *o0 = xchg + ((size_t)(parity * J) * 64 + lane) * 3;
-        v2f n1 = o0[0], n2 = o0[2];
+        const V *o0 = xchg + ((size_t)(parity * J) * 64 + lane) * 3;
+        V n1 = o0[0], n2 = o0[2];
         n1 += o0[1];
 #pragma unroll
         for(int c = 1; c < J; c++) {
-                const v2f *o = xchg + ((size_t)(parity * J + c) * 64 + lane) * 3;
+                const V *o = xchg + ((size_t)(parity * J + c) * 64 + lane) * 3;
                 n1 += o[0];
                 n1 += o[1];
                 n2 += o[2];
@@ -870,12 +940,16 @@ constexpr int kGradWaves3 = 2;    // ... the three-channels-in-one-wavefront sch
 // d (read once per iteration by k_project) at 3.  What is left without the hint is what should stay cache-resident:
 // 4096^2 Y (288 MiB): level 1, 137 -> 127 us per iteration; 16384x2048 (576 MiB, the planes x_k, x_{k-1} are exactly
 // 256 MiB): level 3, 292 -> 240 us; when everything fits the hint costs 1-2 %.
-template <int NCH, bool TGV, bool LOG, int J = 1, int NT = 0>
-__global__ __launch_bounds__((J == 1 ? 256 : 64 * J), (NCH == 1 ? kGradWaves1 : NCH == 2 ? 3 : kGradWaves3))
+// PX: columns per lane (2: packed arithmetic, 128-column strips; 1: 64-column strips, see the pixel-vector overloads above)
+template <int NCH, bool TGV, bool LOG, int J = 1, int NT = 0, int PX = 2>
+__global__ __launch_bounds__((J == 1 ? 256 : 64 * J), (PX == 1 ? (J == 1 && !LOG ? 6 : 2) : NCH == 1 ? kGradWaves1 : NCH == 2 ? 3 : kGradWaves3))
 void k_gradient(GradArgs a)
 {
         static_assert(J == 1 || NCH == 1, "channel-per-wavefront mode keeps one channel per wavefront");
-        __shared__ __attribute__((aligned(16))) v2f xchg[J == 1 ? 1 : 2 * J * 64 * 3];
+        static_assert(PX == 2 || NCH == 1, "one column per lane: one channel per wavefront");
+        typedef typename std::conditional<PX == 2, v2f, float>::type V;
+        constexpr int kCols = 64 * PX - 4;                      // output columns per strip: 2 halo columns on each side
+        __shared__ __attribute__((aligned(16))) V xchg[J == 1 ? 1 : 2 * J * 64 * 3];
         __shared__ double fold_buf[kFoldMaxRows];               // the norm tree of the launch's last wavefront
         const int lane = (int)threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // uniform: keeps row/strip arithmetic scalar
@@ -901,18 +975,24 @@ void k_gradient(GradArgs a)
         const int rows = (int)a.geo.rows, row0 = (int)a.geo.row0;
         const int t0 = (int)(bseg * a.geo.rpw);                // band-local target rows [t0, t1)
         const int t1 = t0 + (int)a.geo.rpw < rows ? t0 + (int)a.geo.rpw : rows;
-        // Strip i loads columns [124 i, 124 i + 128); lanes 0 and 63 are halo — except at the image's
-        // left and right edges, where the neighbour beyond the edge contributes nothing anyway, so the
-        // first strip also owns its lane 0 and the last strip its lane 63: n strips cover 124 n + 4
-        // columns (33 strips for W = 4096).
-        const int xl = wcol * kStripCols + lane * 2;           // canvas column of .x (even; W is even too)
+        // Strip i loads columns [kCols i, kCols i + 64 PX); its two outermost columns on each side are halo — except
+        // at the image's left and right edges, where the neighbour beyond the edge contributes nothing anyway, so the
+        // first strip also owns its left halo lanes and the last strip its right ones: n strips cover kCols n + 4
+        // columns (two columns per lane: 124 n + 4, 33 strips for W = 4096).
+        const int xl = wcol * kCols + lane * PX;               // canvas column of the lane's first pixel (W is a multiple of 8)
 
-        const bool pair_in = xl >= 0 && xl < W;                // both columns in the image, or neither
-        const bool pair_own = pair_in && (lane >= 1 || wcol == 0) && (lane <= 62 || xl + 2 >= W);
+        const bool pair_in = xl >= 0 && xl < W;                // the lane's columns are in the image (both, or neither)
+        const bool pair_own = pair_in && (lane * PX >= 2 || wcol == 0) && (lane * PX + PX <= 64 * PX - 2 || wcol * kCols + 64 * PX >= W);
         // per-lane constant masks (1.f / 0.f), multiplied instead of selected: v*1 is exact, v*0 = +-0
         const float in_f = pair_in ? 1.f : 0.f;
-        const v2f m_gx = v2f{in_f, xl + 1 >= W - 1 ? 0.f : in_f};   // gx = 0 on the last column (compute.c:79)
-        const v2f m_hx = v2f{xl == 0 ? 0.f : in_f, in_f};           // gxx, gyx = 0 on the first column
+        V m_gx, m_hx;
+        if constexpr(PX == 2) {
+                m_gx = v2f{in_f, xl + 1 >= W - 1 ? 0.f : in_f};     // gx = 0 on the last column (compute.c:79)
+                m_hx = v2f{xl == 0 ? 0.f : in_f, in_f};             // gxx, gyx = 0 on the first column
+        } else {
+                m_gx = xl >= W - 1 ? 0.f : in_f;
+                m_hx = xl == 0 ? 0.f : in_f;
+        }
 
         // Rows are fetched kRing-1 loop trips before they are needed: `fetch_row` only issues the
         // loads of x_k / x_{k-1} (raw values stay in the ring), `make_y` turns them into the FISTA
@@ -920,13 +1000,13 @@ void k_gradient(GradArgs a)
         // lanes left/right of the image and rows above/below it read a clamped, valid address and
         // are zeroed by a mask afterwards — so the loop body is straight-line code and the compiler
         // can keep the younger loads in flight (counted s_waitcnt) instead of draining them.
-        const int xl_c = xl < 0 ? 0 : (xl > W - 2 ? W - 2 : xl);
-        const unsigned xoff = (unsigned)xl_c * 4u;             // byte offset of the lane's column pair within a row
+        const int xl_c = xl < 0 ? 0 : (xl > W - PX ? W - PX : xl);
+        const unsigned xoff = (unsigned)xl_c * 4u;             // byte offset of the lane's pixel vector within a row
         const int lr_lo = -(row0 < (int)kHalo ? row0 : (int)kHalo);                      // first readable band-local row
         const int lr_hi = rows - 1 + (H - row0 - rows < (int)kHalo ? H - row0 - rows : (int)kHalo);
         // FREE (a std::bool_constant, see `march` below): the strip is known to lie inside the image and the
         // band with room to spare, so the row clamps and every 0/1 mask are the identity and are left out
-        auto fetch_row = [&](auto free_tag, int lr, v2f (&rc)[NCH], v2f (&rp)[NCH]) {
+        auto fetch_row = [&](auto free_tag, int lr, V (&rc)[NCH], V (&rp)[NCH]) {
                 constexpr bool FREE = decltype(free_tag)::value;
                 // rows past the strip's last needed row (t1+1) re-read that row: a cache hit, not HBM traffic
                 int lm = lr > t1 + 1 ? t1 + 1 : lr;
@@ -942,13 +1022,13 @@ void k_gradient(GradArgs a)
                 const ptrdiff_t roff = (ptrdiff_t)lc * W;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
-                        J2P_CHK(a.ch[cbase + c], x_read[0], reinterpret_cast<const char *>(a.ch[cbase + c].xcur + roff) + xoff, 8, 101);
-                        J2P_CHK(a.ch[cbase + c], x_read[1], reinterpret_cast<const char *>(a.ch[cbase + c].xprev + roff) + xoff, 8, 102);
-                        rc[c] = *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(a.ch[cbase + c].xcur + roff) + xoff);
-                        rp[c] = *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(a.ch[cbase + c].xprev + roff) + xoff);
+                        J2P_CHK(a.ch[cbase + c], x_read[0], reinterpret_cast<const char *>(a.ch[cbase + c].xcur + roff) + xoff, 4 * PX, 101);
+                        J2P_CHK(a.ch[cbase + c], x_read[1], reinterpret_cast<const char *>(a.ch[cbase + c].xprev + roff) + xoff, 4 * PX, 102);
+                        rc[c] = *reinterpret_cast<const V *>(reinterpret_cast<const char *>(a.ch[cbase + c].xcur + roff) + xoff);
+                        rp[c] = *reinterpret_cast<const V *>(reinterpret_cast<const char *>(a.ch[cbase + c].xprev + roff) + xoff);
                 }
         };
-        auto make_y = [&](auto free_tag, int lr, const v2f (&rc)[NCH], const v2f (&rp)[NCH], v2f (&y)[NCH], unsigned &suspect) {
+        auto make_y = [&](auto free_tag, int lr, const V (&rc)[NCH], const V (&rp)[NCH], V (&y)[NCH], unsigned &suspect) {
                 constexpr bool FREE = decltype(free_tag)::value;
                 const int gr = row0 + lr;
                 const float m = gr >= 0 && gr < H ? in_f : 0.f;   // 0 outside the image
@@ -959,21 +1039,16 @@ void k_gradient(GradArgs a)
                 unsigned hi = 0u, lo = ~0u;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
-                        const v2f yy = rc[c] + a.factor * (rc[c] - rp[c]);   // compute.c:435
+                        const V yy = rc[c] + a.factor * (rc[c] - rp[c]);     // compute.c:435
                         y[c] = FREE ? yy : yy * m;
-                        // (bit-cast the VECTOR: hipcc 7.2 turns element-wise casts of .x and .y into two reads of .x)
-                        typedef unsigned v2u __attribute__((ext_vector_type(2)));
-                        const v2u u = __builtin_bit_cast(v2u, y[c]) & 0x7fffffffu;
-                        const v2u um = u - 1u;
-                        hi = max(hi, max(u.x, u.y));
-                        lo = min(lo, min(um.x, um.y));
+                        screen_update(hi, lo, y[c]);
                 }
                 constexpr unsigned kLo = 0x35800000u, kHi = 0x54000000u;      // bits of 2^-20 and 2^41
                 const unsigned long long out_of_range = __builtin_amdgcn_ballot_w64(hi >= kHi) | __builtin_amdgcn_ballot_w64(lo < kLo - 1u);
                 suspect = (unsigned)out_of_range | (unsigned)(out_of_range >> 32);   // wave-uniform, non-zero = suspect
         };
         // forward differences of row gr given rows gr and gr+1 (compute.c:79,81)
-        auto diffs = [&](auto free_tag, int gr, const v2f (&yc)[NCH], const v2f (&yn)[NCH], v2f (&gx)[NCH], v2f (&gy)[NCH]) {
+        auto diffs = [&](auto free_tag, int gr, const V (&yc)[NCH], const V (&yn)[NCH], V (&gx)[NCH], V (&gy)[NCH]) {
                 constexpr bool FREE = decltype(free_tag)::value;
                 const float m_gy = gr >= 0 && gr < H - 1 ? 1.f : 0.f;
 #pragma unroll
@@ -987,19 +1062,21 @@ void k_gradient(GradArgs a)
         // footprint).  Loaded unconditionally from a clamped address; `pmask` (per lane) and the row
         // test at the point of use decide whether it contributes.  A channel with pweight == 0 has an
         // all-zero state buffer, so it needs no special case.
-        v2f p_scale[NCH];
-        int p_col[NCH][2];
+        V p_scale[NCH];
+        int p_col[NCH][PX];
 #pragma unroll
         for(int c = 0; c < NCH; c++) {
                 const ChanDev &k = a.ch[cbase + c];
                 const bool on = k.prob_on && pair_own && (unsigned)xl < k.cw * k.ws;
-                p_scale[c] = on ? v2f{k.p_alpha, k.p_alpha} : v2f{0.f, 0.f};
+                p_scale[c] = splat<V>(on ? k.p_alpha : 0.f);
                 const unsigned cmax = k.cw - 1;
-                const unsigned c0 = (unsigned)xl_c / k.ws, c1 = (unsigned)(xl_c + 1) / k.ws;
-                p_col[c][0] = (int)(c0 > cmax ? cmax : c0) * 4;   // byte offsets within a coefficient row
-                p_col[c][1] = (int)(c1 > cmax ? cmax : c1) * 4;
+#pragma unroll
+                for(int e = 0; e < PX; e++) {
+                        const unsigned ce = (unsigned)(xl_c + e) / k.ws;
+                        p_col[c][e] = (int)(ce > cmax ? cmax : ce) * 4;   // byte offsets within a coefficient row
+                }
         }
-        auto load_p = [&](auto free_tag, int lt, v2f (&pv)[NCH]) {
+        auto load_p = [&](auto free_tag, int lt, V (&pv)[NCH]) {
                 constexpr bool FREE = decltype(free_tag)::value;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
@@ -1013,9 +1090,9 @@ void k_gradient(GradArgs a)
 #endif
                         if constexpr(decltype(free_tag)::unit) {
                                 const float *prow = k.pg + (size_t)((unsigned)gt - k.crow0) * k.cw;
-                                J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + xoff, 8, 103);
-                                if constexpr(NT >= 2) { pv[c] = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(prow) + xoff)); }
-                                else { pv[c] = *reinterpret_cast<const v2f *>(reinterpret_cast<const char *>(prow) + xoff); }
+                                J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + xoff, 4 * PX, 103);
+                                if constexpr(NT >= 2) { pv[c] = __builtin_nontemporal_load(reinterpret_cast<const V *>(reinterpret_cast<const char *>(prow) + xoff)); }
+                                else { pv[c] = *reinterpret_cast<const V *>(reinterpret_cast<const char *>(prow) + xoff); }
                                 continue;
                         }
                         unsigned cr;
@@ -1027,9 +1104,13 @@ void k_gradient(GradArgs a)
                         }
                         const float *prow = k.pg + (size_t)(cr - k.crow0) * k.cw;
                         J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][0], 4, 104);
-                        J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][1], 4, 105);
-                        pv[c] = v2f{*reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][0]),
-                                    *reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][1])};   // two dword loads whatever the sampling: no branch
+                        if constexpr(PX == 2) {
+                                J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][1], 4, 105);
+                                pv[c] = v2f{*reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][0]),
+                                            *reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][1])};   // two dword loads whatever the sampling: no branch
+                        } else {
+                                pv[c] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][0]);
+                        }
                 }
         };
 
@@ -1048,12 +1129,12 @@ void k_gradient(GradArgs a)
         auto march = [&](auto free_tag) {
                 constexpr bool FREE = decltype(free_tag)::value;
                 // rings of kRing row slots, slot = (row - (t0-1)) mod kRing = phase of the trip that owns the row
-                v2f RC[R][NCH], RP[R][NCH], Y[R][NCH], GX[R][NCH], GY[R][NCH], PV[R][NCH];
+                V RC[R][NCH], RP[R][NCH], Y[R][NCH], GX[R][NCH], GY[R][NCH], PV[R][NCH];
                 unsigned bad1, bad2;   // screen results (non-zero = suspect) of the last two rows made; plain scalars
-                SourceTerms<NCH, TGV> S[R];
+                SourceTerms<NCH, TGV, V> S[R];
                 {
                         // rows t0-2, t0-1, t0 are needed at once; rows up to t0+R-2 are put in flight
-                        v2f mc[NCH], mp[NCH], ym[NCH];
+                        V mc[NCH], mp[NCH], ym[NCH];
                         unsigned bm;
                         fetch_row(free_tag, t0 - 2, mc, mp);
                         fetch_row(free_tag, t0 - 1, RC[0], RP[0]);
@@ -1085,18 +1166,18 @@ void k_gradient(GradArgs a)
                         const unsigned badmask = bad2 | bad1 | bnew;        // rows r-1, r, r+1
                         bad2 = bad1;
                         bad1 = bnew;
-                        SourceTerms<NCH, TGV> &s = S[P];
+                        SourceTerms<NCH, TGV, V> &s = S[P];
                         diffs(free_tag, gr, Y[P], Y[P1], GX[P], GY[P]);
                         {
                                 // A row above or below the image needs no special case: its y is 0, m_gy zeroes
                                 // its gy, and hy = 0 zeroes its gxy/gyy, so every term comes out 0.
                                 const bool log_row = LOG && pair_own && r >= t0 && r < t1 && cbase == 0;
                                 const float hy = gr <= 0 || gr >= H ? 0.f : in_f;  // gxy, gyy = 0 on the first row (compute.c:141-143)
-                                const v2f m_hy = v2f{hy, hy};
+                                const V m_hy = splat<V>(hy);
                                 // second differences and the sums under the two norms (the same on every path), then the
                                 // path: screened unless the rows involved hold a value outside the screen's range or one
                                 // of the norms may have an all-ones mantissa (see norm_and_reciprocal)
-                                SourcePrep<NCH, TGV> prep;
+                                SourcePrep<NCH, TGV, V> prep;
                                 if constexpr(J > 1) {
                                         const int parity = (r - t0 + 1) & 1;
                                         source_prepare_joint<J, TGV, !FREE>(cbase, lane, parity, xchg, GX[P][0], GY[P][0], GX[PM1][0], GY[PM1][0],
@@ -1114,12 +1195,12 @@ void k_gradient(GradArgs a)
                         // ---- target row t = r-1: rows t-1, t, t+1 live in slots PM2, PM1, P ----
                         const int t = r - 1;
                         if(t >= t0) {
-                                const SourceTerms<NCH, TGV> &up = S[PM2], &mid = S[PM1];
+                                const SourceTerms<NCH, TGV, V> &up = S[PM2], &mid = S[PM1];
                                 const int gt = row0 + t;
         #pragma unroll
                                 for(int c = 0; c < NCH; c++) {
                                         const ChanDev &k = a.ch[cbase + c];
-                                        v2f g = v2f{0.f, 0.f};
+                                        V g = splat<V>(0.f);
                                         if(FREE || (unsigned)gt < k.ch * k.hs) { g += p_scale[c] * PV[PM1][c]; }   // row t, fetched R-1 trips ago
                                         g += up.tvy[c];                  // TV from (x, t-1)
                                         g = add_left_of(g, mid.tvx[c]);  // TV from (x-1, t)
@@ -1135,16 +1216,14 @@ void k_gradient(GradArgs a)
                                         }
                                         if(pair_own) {
 #ifdef J2P_EXP_NOTRAFFIC
-                                                v2f *gdst = reinterpret_cast<v2f *>(reinterpret_cast<char *>(k.grad + (size_t)(t & 63) * W) + (unsigned)xl * 4u);
+                                                V *gdst = reinterpret_cast<V *>(reinterpret_cast<char *>(k.grad + (size_t)(t & 63) * W) + (unsigned)xl * 4u);
 #else
-                                                v2f *gdst = reinterpret_cast<v2f *>(reinterpret_cast<char *>(k.grad + (size_t)t * W) + (unsigned)xl * 4u);
+                                                V *gdst = reinterpret_cast<V *>(reinterpret_cast<char *>(k.grad + (size_t)t * W) + (unsigned)xl * 4u);
 #endif
-                                                J2P_CHK(k, grad, gdst, 8, 106);
+                                                J2P_CHK(k, grad, gdst, 4 * PX, 106);
                                                 if constexpr(NT >= 1) { __builtin_nontemporal_store(g, gdst); }
                                                 else { *gdst = g; }
-                                                const v2f sq = g * g;
-                                                g2[c] += (double)sq.x;   // compute.c:203
-                                                g2[c] += (double)sq.y;
+                                                add_elements(g2[c], g * g);      // compute.c:203
                                         }
                                 }
                         }
@@ -1172,7 +1251,7 @@ void k_gradient(GradArgs a)
                 }
         };
         {
-                bool seg_free = wcol > 0 && wcol * kStripCols + 128 <= W - 1 &&          // no lane on the first / last column
+                bool seg_free = wcol > 0 && wcol * kCols + 64 * PX <= W - 1 &&           // no lane on the first / last column
                                 row0 + t0 - 2 >= 0 && row0 + t1 + 1 < H &&                // rows t0-2 .. t1+1 inside the image
                                 t0 - 2 >= lr_lo && t1 + 1 <= lr_hi;                       // ... and readable in this band
 #pragma unroll
@@ -1184,7 +1263,7 @@ void k_gradient(GradArgs a)
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
                         const ChanDev &k = a.ch[cbase + c];
-                        unit = unit && k.ws == 1 && k.hs == 1 && (unsigned)(wcol * kStripCols + 128) <= k.cw;
+                        unit = unit && k.ws == 1 && k.hs == 1 && (unsigned)(wcol * kCols + 64 * PX) <= k.cw;
                 }
                 if(__builtin_amdgcn_readfirstlane(unit ? 1 : 0)) { march(MarchTag<true, true>{}); }
                 else if(__builtin_amdgcn_readfirstlane(seg_free ? 1 : 0)) { march(MarchTag<true, false>{}); }

@@ -111,6 +111,7 @@ struct j2p_solver {
         bool norm_by_project = false;   // ... or left level-1 row sums that k_project reduces itself
         unsigned *tickets = nullptr;     // device: [ntr_local] per-tile-row arrival counters + [1] finished-rows counter
         unsigned rpw = 16;
+        unsigned px = 2;                // columns per lane of the gradient strips (2: 128-column strips, 1: 64-column strips)
         bool interior_done = false;
         bool rowsums_pending = false;
         unsigned ntx = 0, nseg = 0, ntr_local = 0, ntr_global = 0, first_tr = 0;   // strips per row, row segments
@@ -289,6 +290,12 @@ struct Carver {
 constexpr size_t kNtWorkingSet = (size_t)260 << 20;      // see nt_policy in j2p_solver_create
 constexpr size_t kNormInProjectPixels = (size_t)5 << 19; // whole canvases up to this size (2.5 Mpixel) reduce ||g|| without a launch of its own
 constexpr size_t kMixedProjectPixels = (size_t)1 << 20;  // canvases up to this size project all channels in one launch
+// fewer gradient wavefronts than this (128-column, 16-row strips) -> 64-column strips.  0 = never: measured on canvases from
+// 0.26 to 16.8 Mpixel (profiles/r03_px_rpw_sweep.jsonl) the one-column-per-lane form is nowhere faster than the packed one
+// with the same rows per strip (512x512 4:2:0 29.2 vs 27.5 us per iteration, 1080p Y 31.1 vs 28.7, 2048^2 45.5 vs 44.4):
+// twice the wavefronts do not shorten the launch, because each still walks as many rows, one row trip at a time
+constexpr unsigned long long kPx1Waves = 0;
+constexpr unsigned long long kShortStripWaves = 2048;     // fewer than this: 8- or 4-row strips (half the chip's 4096 wavefront slots)
 
 unsigned gcd_u(unsigned a, unsigned b) { return b ? gcd_u(b, a % b) : a; }
 unsigned lcm_u(unsigned a, unsigned b) { return a / gcd_u(a, b) * b; }
@@ -378,14 +385,14 @@ Geo geo_of(const j2p_solver *s)
         return g;
 }
 
-template <int NCH, int J>
+template <int NCH, int J, int PX = 2>
 void launch_gradient_n(const GradArgs &a, unsigned ntx, unsigned nseg, hipStream_t st, bool tgv, bool log, int nt)
 {
         // J == 1: 4 strips per 256-thread workgroup; J > 1: one strip per workgroup of J wavefronts
         constexpr unsigned wpb = 4;     // strips per workgroup
         const dim3 grid = J == 1 ? dim3((ntx + wpb - 1) / wpb, nseg) : dim3(ntx, nseg);
         const dim3 block = J == 1 ? dim3(64 * wpb) : dim3(64 * J);
-        if constexpr(NCH == 1) {
+        if constexpr(NCH == 1 && PX == 2) {
                 // non-temporal g / prob state (see nt_policy): the one-channel-per-wavefront kernels without logging
                 if(nt >= 1 && !log) {
                         if(nt >= 2) {
@@ -398,12 +405,13 @@ void launch_gradient_n(const GradArgs &a, unsigned ntx, unsigned nseg, hipStream
                         return;
                 }
         }
+        // (one column per lane is for canvases that leave wavefront slots empty: they fit the caches, no hint)
         if(tgv) {
-                if(log) { hipLaunchKernelGGL((k_gradient<NCH, true, true, J>), grid, block, 0, st, a); }
-                else { hipLaunchKernelGGL((k_gradient<NCH, true, false, J>), grid, block, 0, st, a); }
+                if(log) { hipLaunchKernelGGL((k_gradient<NCH, true, true, J, 0, PX>), grid, block, 0, st, a); }
+                else { hipLaunchKernelGGL((k_gradient<NCH, true, false, J, 0, PX>), grid, block, 0, st, a); }
         } else {
-                if(log) { hipLaunchKernelGGL((k_gradient<NCH, false, true, J>), grid, block, 0, st, a); }
-                else { hipLaunchKernelGGL((k_gradient<NCH, false, false, J>), grid, block, 0, st, a); }
+                if(log) { hipLaunchKernelGGL((k_gradient<NCH, false, true, J, 0, PX>), grid, block, 0, st, a); }
+                else { hipLaunchKernelGGL((k_gradient<NCH, false, false, J, 0, PX>), grid, block, 0, st, a); }
         }
 }
 
@@ -515,13 +523,18 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         // selects the in-wavefront kernel (kept: it is the same arithmetic in another schedule, and tested).
         const bool inwave = s->joint_inwave;
         switch(s->nch) {
-        case 1: launch_gradient_n<1, 1>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); break;
+        case 1:
+                if(s->px == 1) { launch_gradient_n<1, 1, 1>(a, s->ntx, nseg_launch, st, tgv, log, 0); }
+                else { launch_gradient_n<1, 1>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); }
+                break;
         case 2:
                 if(inwave) { launch_gradient_n<2, 1>(a, s->ntx, nseg_launch, st, tgv, log, 0); }
+                else if(s->px == 1) { launch_gradient_n<1, 2, 1>(a, s->ntx, nseg_launch, st, tgv, log, 0); }
                 else { launch_gradient_n<1, 2>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); }
                 break;
         default:
                 if(inwave) { launch_gradient_n<3, 1>(a, s->ntx, nseg_launch, st, tgv, log, 0); }
+                else if(s->px == 1) { launch_gradient_n<1, 3, 1>(a, s->ntx, nseg_launch, st, tgv, log, 0); }
                 else { launch_gradient_n<1, 3>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); }
                 break;
         }
@@ -898,26 +911,34 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 }
         }
         // reductions: tile rows are counted on the canvas, the band owns a contiguous range
-        s->ntx = W <= 4 ? 1 : (W - 4 + kStripCols - 1) / kStripCols;   // n strips cover 124 n + 4 columns
-        // Rows per gradient strip = rows per norm partial ("tile row").  16 on canvases that fill the chip (32/48/64
-        // measured no faster).  A small canvas is latency-bound INSIDE k_gradient — 512x512 4:2:0: 480
-        // wavefronts of 18 dependent row trips each on a chip with 4096 wavefront slots, 21 us; launch gaps are ~0
-        // (profiles/r02_small_planes.md) — so it gets more and shorter strips: 8 or 4 rows while the canvas has fewer
-        // than 2048 strips.  A function of the CANVAS only (never of the band), so that every band of a tiled run —
-        // and the whole-canvas solver — reduce ||g|| over the same partials in the same order.
+        // Gradient strips: columns per lane (px) and rows per strip = rows per norm partial ("tile row", rpw).
+        // A canvas that fills the chip: 128-column strips (two columns per lane, packed arithmetic) of 16 rows (32 / 48 / 64
+        // measured no faster).  A smaller canvas leaves wavefront slots empty and is bound by how long ONE
+        // wavefront takes to walk its rows (wave timelines, profiles/r03_wave_trace.jsonl: ~0.9 us per row trip whatever
+        // the SIMD's load), so it gets shorter strips (8 or 4 rows: fewer trips per wavefront).  64-column strips (one
+        // column per lane: the same kernel instantiated on float instead of float2) exist behind J2P_PX=1 and do not
+        // pay (kPx1Waves).  Functions of the CANVAS only (never of the band), so that every band of a tiled run — and
+        // the whole-canvas solver — reduce ||g|| over the same partials in the same order.
         {
-                const unsigned per_strip_row = s->ntx * nchannel;       // one wavefront per channel and strip
-                unsigned g = kTY;
-                // (2048: half the chip's 4096 wavefront slots.  Measured: 1080p Y 34.2 -> 31.2 us per iteration with 8-row
-                // strips, three such planes on three streams 124.5 -> 131.3 Gpx-it/s, 1024^2 22.5 -> 21.4 us; 2048^2 and
-                // larger keep 16 rows and their times.  A limit of 4096 costs the 512^2 image 5 %.)
-                while(g > 4 && (unsigned long long)per_strip_row * ((H + g - 1) / g) < 2048ull) { g >>= 1; }
-                // (timing experiments: J2P_RPW = 4 / 8 / 16 / 32 / 64 for every solver of the process; whole canvases only above 16)
+                auto strips = [&](unsigned px) { return W <= 4 ? 1u : (W - 4 + (64 * px - 4) - 1) / (64 * px - 4); };
+                auto waves = [&](unsigned px, unsigned g) { return (unsigned long long)strips(px) * nchannel * ((H + g - 1) / g); };
+                unsigned px = 2, g = kTY;
+                // (limits measured, profiles/r03_px_rpw_sweep.jsonl)
+                if(waves(2, kTY) < kPx1Waves && !s->joint_inwave) { px = 1; }
+                while(g > 4 && waves(px, g) < kShortStripWaves) { g >>= 1; }
+                // (timing experiments: J2P_PX = 1 / 2, J2P_RPW = 4 / 8 / 16 / 32 / 64 for every solver of the process;
+                // rows above 16 on whole canvases only)
+                if(const char *env = getenv("J2P_PX")) {
+                        const int v = atoi(env);
+                        if((v == 1 && !s->joint_inwave) || v == 2) { px = (unsigned)v; }
+                }
                 if(const char *env = getenv("J2P_RPW")) {
                         const int v = atoi(env);
                         if(v == 4 || v == 8 || v == 16 || v == 32 || v == 64) { g = (unsigned)v; }
                 }
+                s->px = px;
                 s->rpw = g;
+                s->ntx = strips(px);
         }
         s->nseg = (s->rows + s->rpw - 1) / s->rpw;
         s->ntr_local = s->nseg;
@@ -1073,7 +1094,10 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
                 if(s->rowsum_alternate && !value) { return fail(J2P_ESTATE, "alternating row sums need the folded norm reduction"); }
                 s->fold = value != 0;
                 break;
-        case J2P_OPT_JOINT_INWAVE: s->joint_inwave = value != 0; break;
+        case J2P_OPT_JOINT_INWAVE:
+                if(value && s->px == 1) { return fail(J2P_ESTATE, "the in-wavefront joint kernel has no one-column-per-lane form (set J2P_JOINT_INWAVE=1 before the solver is created)"); }
+                s->joint_inwave = value != 0;
+                break;
         case J2P_OPT_NORM_IN_PROJECT: s->norm_in_project = value != 0; break;
         case J2P_OPT_NT_GRADIENT:
                 s->nt_forced = value >= 0;                 // negative: back to the policy

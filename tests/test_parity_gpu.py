@@ -562,10 +562,11 @@ def test_both_joint_modes_agree(lib, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("shape", [(520, 136, "420", False), (1000, 96, "444", True), (264, 200, "422", False)])
-def test_every_schedule_switch_leaves_the_bits_alone(lib, oracle, shape):
+def test_every_schedule_switch_leaves_the_bits_alone(lib, oracle, shape, monkeypatch):
     """the J2P_OPT_* switches select schedules of the same arithmetic (where the norm is reduced, whether g is
-    streamed non-temporally, one projection launch or one per sampling class): every combination the solver can
-    pick by itself — the choice depends on the canvas size — must give the bits of the reference on ONE canvas"""
+    streamed non-temporally, one projection launch or one per sampling class), J2P_PX / J2P_RPW the geometry of the
+    gradient strips (one or two columns per lane, rows per strip): every combination the solver can pick by itself —
+    the choice depends on the canvas size — must give the bits of the reference on ONE canvas"""
     import jpeg2png_amd as j
     w, h, sub, yonly = shape
     planes = make_case(w, h, sub, 10, seed=91, y_only=yonly)
@@ -582,15 +583,38 @@ def test_every_schedule_switch_leaves_the_bits_alone(lib, oracle, shape):
         {j.J2P_OPT_NT_GRADIENT: 3},
         {j.J2P_OPT_NT_GRADIENT: 3, j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 0},
         {j.J2P_OPT_MIXED_PROJECT: 0},                                               # what a > 1 Mpixel canvas gets
-        {j.J2P_OPT_MIXED_PROJECT: 0, j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 0, j.J2P_OPT_JOINT_INWAVE: 1},
+        {j.J2P_OPT_MIXED_PROJECT: 0, j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 0, "J2P_JOINT_INWAVE": "1"},
     ]
-    for opts in settings:
-        with j.Solver(planes, 0.3, [0.001] * n, its) as s:
-            for k, v in opts.items():
-                s.debug_option(k, v)
-            s.run(its)
+    for px in ("2", "1"):
+        monkeypatch.setenv("J2P_PX", px)
+        for opts in settings:
+            if "J2P_JOINT_INWAVE" in opts:
+                if px == "1":
+                    continue                    # the in-wavefront joint kernel exists with two columns per lane only
+                monkeypatch.setenv("J2P_JOINT_INWAVE", "1")
+            with j.Solver(planes, 0.3, [0.001] * n, its) as s:
+                for k, v in opts.items():
+                    if not isinstance(k, str):
+                        s.debug_option(k, v)
+                s.run(its)
+                for c in range(n):
+                    assert bit_equal(s.download(c), want[c]), f"px {px} options {opts} channel {c}"
+            monkeypatch.delenv("J2P_JOINT_INWAVE", raising=False)
+    # rows per strip (what canvases of other sizes get) with both strip widths, whole canvas and bands
+    for px in ("2", "1"):
+        for rpw in ("4", "8", "16"):
+            monkeypatch.setenv("J2P_PX", px)
+            monkeypatch.setenv("J2P_RPW", rpw)
+            got = copy.deepcopy(planes)
+            rows = j.compute(got, 0.3, [0.001] * n, its, log=True)
             for c in range(n):
-                assert bit_equal(s.download(c), want[c]), f"options {opts} channel {c}"
+                assert bit_equal(got[c].fdata, want[c]), f"px {px} rpw {rpw} channel {c}"
+            assert np.isfinite(rows).all()
+            if h >= 128:
+                with j.TiledSolver(planes, 0.3, [0.001] * n, its, devices=[0, 0]) as t:
+                    t.run(its)
+                    for c in range(n):
+                        assert bit_equal(t.download(c), want[c]), f"px {px} rpw {rpw}, two bands: channel {c}"
 
 
 def test_concurrent_calls_are_independent(lib, oracle):

@@ -75,7 +75,8 @@ names = {}
 for m in re.finditer(r"^(_ZN3j2p10k_gradient\w+):", text, re.M):
     dem = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
     names[dem] = m.group(1)
-for want, trips in (("k_gradient<1, true, false, 1, 1>", 4), ("k_gradient<1, true, false, 1, 0>", 4), ("k_gradient<1, true, false, 3, 0>", 3)):
+for want, trips in (("k_gradient<1, true, false, 1, 1, 2>", 4), ("k_gradient<1, true, false, 1, 0, 1>", 4), ("k_gradient<1, true, false, 3, 0, 2>", 4),
+                    ("k_gradient<1, true, false, 3, 0, 1>", 4)):
     kern = next((v for k, v in names.items() if want in k), None)
     if not kern:
         continue
