@@ -21,6 +21,11 @@ HIP_FLAGS = [
     "-fno-fast-math",
     "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-fno-gpu-flush-denormals-to-zero",
+    # the kernels say themselves which float operations are packed (float2 arithmetic); left to the SLP pass, pairs of scalar
+    # operations — the DCT butterflies of k_project above all — are packed too, with v_mov / v_pk_mov to line the operands
+    # up, and a packed f32 operation costs two plain ones on gfx950 anyway (profiles/r03_valu_rates.json).  Same bits;
+    # measured 4096^2 136.8 -> 140.6 Gpx-it/s (k_project 65.4 -> 62.0 us), 16384x2048 141.9 -> 146.3
+    "-fno-slp-vectorize",
     "-Wall", "-Wno-unused-function",
 ]
 
