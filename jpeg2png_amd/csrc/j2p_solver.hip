@@ -295,7 +295,13 @@ constexpr size_t kMixedProjectPixels = (size_t)1 << 20;  // canvases up to this 
 // with the same rows per strip (512x512 4:2:0 29.2 vs 27.5 us per iteration, 1080p Y 31.1 vs 28.7, 2048^2 45.5 vs 44.4):
 // twice the wavefronts do not shorten the launch, because each still walks as many rows, one row trip at a time
 constexpr unsigned long long kPx1Waves = 0;
-constexpr unsigned long long kShortStripWaves = 2048;     // fewer than this: 8- or 4-row strips (half the chip's 4096 wavefront slots)
+// rows per gradient strip: 16; 8, then 4, while the strips make fewer wavefronts than half the chip's 4096 slots (the
+// launch is then one generation whose length is the busiest SIMD's: shorter strips balance it, at 25 / 50 instead of 12.5 %
+// redundant rows).  A limit of 4096 for the first step was measured too (profiles/r03_px_rpw_sweep.jsonl,
+// r03_rpw_concurrency.json): a single 2048^2 Y plane or 1080p 4:2:0 image gains 2 %, eight concurrent 1080p 4:2:0 images —
+// the batch case, where the chip is full anyway — lose 5.7 %; not taken
+constexpr unsigned long long kHalfStripWaves = 2048;
+constexpr unsigned long long kShortStripWaves = 2048;
 
 unsigned gcd_u(unsigned a, unsigned b) { return b ? gcd_u(b, a % b) : a; }
 unsigned lcm_u(unsigned a, unsigned b) { return a / gcd_u(a, b) * b; }
@@ -925,7 +931,8 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 unsigned px = 2, g = kTY;
                 // (limits measured, profiles/r03_px_rpw_sweep.jsonl)
                 if(waves(2, kTY) < kPx1Waves && !s->joint_inwave) { px = 1; }
-                while(g > 4 && waves(px, g) < kShortStripWaves) { g >>= 1; }
+                if(waves(px, g) < kHalfStripWaves) { g = 8; }
+                if(g == 8 && waves(px, g) < kShortStripWaves) { g = 4; }
                 // (timing experiments: J2P_PX = 1 / 2, J2P_RPW = 4 / 8 / 16 / 32 / 64 for every solver of the process;
                 // rows above 16 on whole canvases only)
                 if(const char *env = getenv("J2P_PX")) {
