@@ -615,7 +615,10 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
                 bp = synth.Plane(bp.w, rows_per_gpu, 1, 1, bp.data, bp.quant_table)
                 r0, r1 = 0, rows_per_gpu
             engine = tiledmod.HipBandEngine([bp], WEIGHT, [PWEIGHT], its, (r0, r1), local_rank)
-            driver = tiledmod.RowTiledSolver(engine)
+            # (J2P_RCCL_OVERLAP=1: the split phases with the exchange on a side stream; default: one gradient and one
+            # projection launch per iteration like the C engine — on a band with a GPU to itself the split costs more than
+            # the exchange it hides, profiles/r03_band_alone.jsonl)
+            driver = tiledmod.RowTiledSolver(engine, overlap=os.environ.get("J2P_RCCL_OVERLAP", "0") == "1")
             _flush_c_stdio()
 
             def reset():

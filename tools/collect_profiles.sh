@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs"
+B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs"
 B2="python $R/bench.py --steps 1 --warmup 0 --iterations 50 --no-cpu-baseline --no-other-configs"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -- $B > "$OUT/${TAG}_bench_under_rocprof.log" 2>&1
 grep '^{' "$OUT/${TAG}_bench_under_rocprof.log" | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json"
