@@ -336,8 +336,9 @@ class Ranks:
         return box[0]
 
     def close(self):
-        if self.dist is not None and self.dist.is_initialized():
-            self.dist.destroy_process_group()
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
 
 
 def time_steps(ranks, reset, solve, sync, warmup, steps, eng, timing_every):
@@ -607,7 +608,6 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29541")
                 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-                ranks.dist = dist
             r0, r1 = rank * rows_per_gpu, (rank + 1) * rows_per_gpu
             bp = my_bands[rank]
             bp = synth.Plane(bp.w, H, 1, 1, bp.data, bp.quant_table)   # planes describe the whole image; arrays are band-local

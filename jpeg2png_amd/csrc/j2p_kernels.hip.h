@@ -928,7 +928,10 @@ __device__ __forceinline__ void fold_arrive(const GradArgs &a, unsigned tr, unsi
         if(lane == 0) { __hip_atomic_store(a.done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
-constexpr int kGradWaves1 = 4;    // waves per SIMD the 1-channel gradient kernel is register-limited to (5 needs <= 96 VGPRs: spills)
+#ifndef J2P_GRAD_WAVES
+#define J2P_GRAD_WAVES 4
+#endif
+constexpr int kGradWaves1 = J2P_GRAD_WAVES;    // waves per SIMD the 1-channel gradient kernel is register-limited to (5 needs <= 96 VGPRs: spills)
 constexpr int kGradWaves3 = 2;    // ... the three-channels-in-one-wavefront schedule
 // NCH channels are handled inside one wavefront (J == 1, workgroup = 4 strips), or — for a
 // jointly optimised image — J wavefronts of a workgroup take one channel each of the same strip
