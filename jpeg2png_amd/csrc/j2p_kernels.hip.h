@@ -419,7 +419,11 @@ __device__ __forceinline__ void add_elements(double &acc, v2f v)
         acc += (double)v.y;
 }
 __device__ __forceinline__ void add_elements(double &acc, float v) { acc += (double)v; }
-// the operand screen on bit patterns (see make_y in k_gradient): hi = largest |y|, lo = smallest non-zero |y| minus an ulp
+// The operand screen of the short division / sqrt sequences, on bit patterns and for a whole row at once (make_y in
+// k_gradient): a loaded pixel is outside the range for which the short paths are exact when 0 < |y| < 2^-20, |y| >= 2^41
+// or it is a NaN.  Flat regions whose pixels are rounding noise around 0 (1e-17 in the chroma of a grey area) do occur
+// in image data, so the lower bound has to hold all the way down to the subnormals.  hi = largest |y|, lo = smallest
+// NON-ZERO |y| minus one ulp (0 - 1 wraps to the top, so zeros drop out of the minimum)
 __device__ __forceinline__ void screen_update(unsigned &hi, unsigned &lo, v2f y)
 {
         // (bit-cast the VECTOR: hipcc 7.2 turns element-wise casts of .x and .y into two reads of .x)
@@ -487,21 +491,6 @@ __device__ __forceinline__ void div_shared_n(const V (&x)[N], V d, V r, V (&q)[N
         for(int i = 0; i < N; i++) { e1[i] = pk_fma(-d, q1[i], x[i]); }
 #pragma unroll
         for(int i = 0; i < N; i++) { q[i] = pk_fma(e1[i], r, q1[i]); }
-}
-
-// true when a loaded pixel is outside the range for which the fast paths are exact:
-// 0 < |y| < 2^-20, |y| >= 2^41, or NaN.  Flat regions whose pixels are rounding noise around 0
-// (1e-17 in the chroma of a grey area) do occur in image data, so the lower bound has to hold
-// all the way down to the subnormals.  (k_gradient applies the same test to a whole row at a
-// time on the bit patterns, see make_y; this per-value form is what it implements.)
-__device__ __forceinline__ bool in_fast_range(float v, float lo, float hi)
-{
-        const float av = __builtin_fabsf(v);
-        return (av >= lo && av < hi) || v == 0.f;
-}
-__device__ __forceinline__ bool y_suspect(v2f y)
-{
-        return !(in_fast_range(y.x, 0x1p-20f, 0x1p41f) && in_fast_range(y.y, 0x1p-20f, 0x1p41f));
 }
 
 // sqrtf for 0 or 2^-96 <= x < 2^126: v_sqrt_f32 is within 1 ulp; pick the correctly rounded
@@ -1035,7 +1024,7 @@ void k_gradient(GradArgs a)
                 constexpr bool FREE = decltype(free_tag)::value;
                 const int gr = row0 + lr;
                 const float m = gr >= 0 && gr < H ? in_f : 0.f;   // 0 outside the image
-                // the operand screen of the short division / sqrt sequences (see y_suspect) for the whole row at
+                // the operand screen of the short division / sqrt sequences (see screen_update) for the whole row at
                 // once, on the bit patterns: hi = largest |y|, lo = smallest NON-ZERO |y| minus one ulp (0 - 1
                 // wraps to the top, so zeros drop out of the minimum).  Two compares per row, each feeding a
                 // ballot directly, so the flag is born in scalar registers.
@@ -1578,13 +1567,9 @@ __device__ __forceinline__ float stepped(const ChanDev &k, ptrdiff_t off, float 
         return y;
 }
 
-// numerator screen of the short division: 0 < |x| < 2^-100, |x| >= 2^61, or NaN
-__device__ __forceinline__ bool num_suspect(v2f x)
-{
-        return !(in_fast_range(x.x, 0x1p-100f, 0x1p61f) && in_fast_range(x.y, 0x1p-100f, 0x1p61f));
-}
-// ... for a batch of values at once, on the bit patterns (as k_gradient's make_y does): hi = largest |x|, lo = smallest
-// NON-ZERO |x| minus one ulp (0 - 1 wraps to the top, so zeros drop out of the minimum); two compares at the end
+// numerator screen of phase B's short division — suspect: 0 < |x| < 2^-100, |x| >= 2^61, or NaN — for a batch of values at
+// once, on the bit patterns (as k_gradient's make_y does): hi = largest |x|, lo = smallest NON-ZERO |x| minus one ulp
+// (0 - 1 wraps to the top, so zeros drop out of the minimum); two compares at the end
 struct NumScreen {
         unsigned hi = 0u, lo = ~0u;
         __device__ __forceinline__ void add(v2f x)
