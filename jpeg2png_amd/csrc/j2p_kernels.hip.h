@@ -33,6 +33,7 @@
 //                     what the 1.15x over-fetch costs
 //   J2P_EXP_SHORTDIV  k_gradient WITHOUT the all-ones-mantissa test its short division needs (wrong once in ~1e6
 //                     pixels): what that test costs
+// (and one that stays correct: J2P_PROJECT_MAXWAVES=N caps k_project's wavefronts per SIMD through its LDS footprint)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -346,6 +347,58 @@ __device__ __forceinline__ double block_sum(double v, double *red /* >= 4 double
 // takes the plain `/` and sqrtf() path for the rows that pixel touches.
 // ---------------------------------------------------------------------------
 typedef float v2f __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------
+// Row accesses of the phase kernels as BUFFER instructions: a wave-uniform resource (the plane's base for this
+// wavefront's rows, in scalar registers), a loop-invariant 32-bit lane offset and a scalar row offset —
+// buffer_load_dword v, v_off, s[rsrc], s_row offen — so that no vector arithmetic goes into addresses.  As flat
+// pointers the same accesses cost one 64-bit vector addition each (v_lshl_add_u64, chained row to row: 24 of them in
+// front of k_project's 24 loads, 4.5 per row trip in k_gradient).  The resource covers "everything from the base on"
+// (no range checking intended: the kernels clamp their own addresses; J2P_DEBUG checks the equivalent pointers);
+// row offsets stay far below 4 GiB because the base is the wavefront's first row, not the plane's.
+// NT: the non-temporal hint of nt_policy (the `nt` bit of the instruction).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_from(const void *base)
+{
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)0xfffffffe, 0x00020000);
+}
+template <bool NT>
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned row_off)
+{
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)row_off, NT ? 2 : 0));
+}
+template <bool NT>
+__device__ __forceinline__ v2f buf_load2(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned row_off)
+{
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        const v2u raw = __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_off, (int)row_off, NT ? 2 : 0);
+        return __builtin_bit_cast(v2f, raw);
+}
+template <bool NT>
+__device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned row_off)
+{
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)lane_off, (int)row_off, NT ? 2 : 0);
+}
+template <bool NT>
+__device__ __forceinline__ void buf_store(v2f v, __amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned row_off)
+{
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, (int)lane_off, (int)row_off, NT ? 2 : 0);
+}
+template <bool NT>
+__device__ __forceinline__ void buf_store4(float a, float b, float c, float d, __amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned row_off)
+{
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        const v4u raw = v4u{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c),
+                            __builtin_bit_cast(unsigned, d)};
+        __builtin_amdgcn_raw_buffer_store_b128(raw, r, (int)lane_off, (int)row_off, NT ? 2 : 0);
+}
+template <bool NT, class V>
+__device__ __forceinline__ V buf_load(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned row_off)
+{
+        if constexpr(sizeof(V) == 8) { return buf_load2<NT>(r, lane_off, row_off); }
+        else { return buf_load1<NT>(r, lane_off, row_off); }
+}
 
 // Everything below is written once for a lane's PIXEL VECTOR V: v2f = two neighbouring columns per lane, the arithmetic
 // issuing as packed operations (128-column strips: what canvases that fill the chip use), or float = one column per
@@ -994,6 +1047,22 @@ void k_gradient(GradArgs a)
         // can keep the younger loads in flight (counted s_waitcnt) instead of draining them.
         const int xl_c = xl < 0 ? 0 : (xl > W - PX ? W - PX : xl);
         const unsigned xoff = (unsigned)xl_c * 4u;             // byte offset of the lane's pixel vector within a row
+        // (rows t0 - 2 ... t1 + 1 are what the segment touches; the x buffers have 2 halo rows above the band's row 0)
+#ifdef J2P_EXP_NOTRAFFIC
+        const int seg_base = 0, grad_base = 0;      // (every segment works on the plane's first 64 rows)
+#else
+        const int seg_base = t0 - 2, grad_base = t0;
+#endif
+        __amdgpu_buffer_rsrc_t res_cur[NCH], res_prev[NCH], res_grad[NCH], res_pg[NCH];
+#pragma unroll
+        for(int c = 0; c < NCH; c++) {
+                const ChanDev &k = a.ch[cbase + c];
+                res_cur[c] = rows_from(k.xcur + (ptrdiff_t)seg_base * W);
+                res_prev[c] = rows_from(k.xprev + (ptrdiff_t)seg_base * W);
+                res_grad[c] = rows_from(k.grad + (ptrdiff_t)grad_base * W);
+                // (the prob state of a unit-sampled channel, see load_p: coefficient row = canvas row)
+                res_pg[c] = rows_from(k.pg + (size_t)((unsigned)(row0 + grad_base) - k.crow0) * k.cw);
+        }
         const int lr_lo = -(row0 < (int)kHalo ? row0 : (int)kHalo);                      // first readable band-local row
         const int lr_hi = rows - 1 + (H - row0 - rows < (int)kHalo ? H - row0 - rows : (int)kHalo);
         // FREE (a std::bool_constant, see `march` below): the strip is known to lie inside the image and the
@@ -1009,15 +1078,17 @@ void k_gradient(GradArgs a)
 #ifdef J2P_EXP_NOTRAFFIC
                 lc = (lc < 0 ? 0 : lc) & 63;
 #endif
-                // uniform row pointer + loop-invariant 32-bit lane offset: scalar-base addressing, no
-                // 64-bit vector address arithmetic per row
-                const ptrdiff_t roff = (ptrdiff_t)lc * W;
+                // wave-uniform resource at the segment's first row + loop-invariant 32-bit lane offset + scalar row offset:
+                // no vector arithmetic in the address (see rows_from)
+                const ptrdiff_t roff = (ptrdiff_t)lc * W;              // (the pointer form: what J2P_DEBUG checks)
+                (void)roff;
+                const unsigned row_off = (unsigned)(lc - seg_base) * (unsigned)W * 4u;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
                         J2P_CHK(a.ch[cbase + c], x_read[0], reinterpret_cast<const char *>(a.ch[cbase + c].xcur + roff) + xoff, 4 * PX, 101);
                         J2P_CHK(a.ch[cbase + c], x_read[1], reinterpret_cast<const char *>(a.ch[cbase + c].xprev + roff) + xoff, 4 * PX, 102);
-                        rc[c] = *reinterpret_cast<const V *>(reinterpret_cast<const char *>(a.ch[cbase + c].xcur + roff) + xoff);
-                        rp[c] = *reinterpret_cast<const V *>(reinterpret_cast<const char *>(a.ch[cbase + c].xprev + roff) + xoff);
+                        rc[c] = buf_load<false, V>(res_cur[c], xoff, row_off);
+                        rp[c] = buf_load<false, V>(res_prev[c], xoff, row_off);
                 }
         };
         auto make_y = [&](auto free_tag, int lr, const V (&rc)[NCH], const V (&rp)[NCH], V (&y)[NCH], unsigned &suspect) {
@@ -1083,8 +1154,8 @@ void k_gradient(GradArgs a)
                         if constexpr(decltype(free_tag)::unit) {
                                 const float *prow = k.pg + (size_t)((unsigned)gt - k.crow0) * k.cw;
                                 J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + xoff, 4 * PX, 103);
-                                if constexpr(NT >= 2) { pv[c] = __builtin_nontemporal_load(reinterpret_cast<const V *>(reinterpret_cast<const char *>(prow) + xoff)); }
-                                else { pv[c] = *reinterpret_cast<const V *>(reinterpret_cast<const char *>(prow) + xoff); }
+                                (void)prow;
+                                pv[c] = buf_load<(NT >= 2), V>(res_pg[c], xoff, (unsigned)(gt - row0 - grad_base) * k.cw * 4u);
                                 continue;
                         }
                         unsigned cr;
@@ -1207,14 +1278,12 @@ void k_gradient(GradArgs a)
                                                 g += s.B[c];                     // (x,   t+1)
                                         }
                                         if(pair_own) {
+                                                J2P_CHK(k, grad, reinterpret_cast<char *>(k.grad + (size_t)t * W) + (unsigned)xl * 4u, 4 * PX, 106);
 #ifdef J2P_EXP_NOTRAFFIC
-                                                V *gdst = reinterpret_cast<V *>(reinterpret_cast<char *>(k.grad + (size_t)(t & 63) * W) + (unsigned)xl * 4u);
+                                                buf_store<(NT >= 1)>(g, res_grad[c], (unsigned)xl * 4u, (unsigned)(t & 63) * (unsigned)W * 4u);
 #else
-                                                V *gdst = reinterpret_cast<V *>(reinterpret_cast<char *>(k.grad + (size_t)t * W) + (unsigned)xl * 4u);
+                                                buf_store<(NT >= 1)>(g, res_grad[c], (unsigned)xl * 4u, (unsigned)(t - grad_base) * (unsigned)W * 4u);
 #endif
-                                                J2P_CHK(k, grad, gdst, 4 * PX, 106);
-                                                if constexpr(NT >= 1) { __builtin_nontemporal_store(g, gdst); }
-                                                else { *gdst = g; }
                                                 add_elements(g2[c], g * g);      // compute.c:203
                                         }
                                 }
@@ -1699,7 +1768,7 @@ struct __attribute__((aligned(16))) ProjShared {
         int q_fast;
 };
 
-template <bool LOG, int WS, int HS, int NT, bool NIP>
+template <bool LOG, int WS, int HS, int NT, bool NIP, bool PTR = false>
 __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
 {
         float *const tp = sh.tp;
@@ -1713,7 +1782,8 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
         const unsigned zi = blockIdx.z;
         const int c = (int)a.chan_of_z[zi];
         const ChanDev &k = a.ch[c];
-        const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+        const int lane = (int)threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // uniform: strip / row arithmetic and the row resources stay scalar
         const unsigned W = a.geo.W;
         const unsigned ws = k.ws, hs = k.hs;
         const unsigned strips_x = (W + 64 * ws - 1) / (64 * ws);      // strips across the canvas
@@ -1764,23 +1834,36 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
         // arithmetic instead of two.
         float gv[8], xcv[8], xpv[8];
         if(full) {
-                const size_t base = (size_t)ly0 * W + cx;
-                // (array by array: 0.5 % faster than row by row)
+                const size_t base = (size_t)ly0 * W + cx;             // (the pointer form: what J2P_DEBUG checks)
+                (void)base;
+                // wave-uniform resources at the strip's first row; lane = column, rows by scalar offset (see rows_from)
+                const __amdgpu_buffer_rsrc_t rc_ = rows_from(k.xcur + (size_t)ly0 * W), rp_ = rows_from(k.xprev + (size_t)ly0 * W),
+                                             rg_ = rows_from(k.grad + (size_t)ly0 * W);
+                const unsigned lane_off = cx * 4u;
+                // (array by array: 0.5 % faster than row by row.)  PTR: the same loads through flat pointers — what canvases
+                // whose rows lie >= 64 KiB apart take: there, and only there, the buffer form measures 5 % SLOWER
+                // (16384 x 2048: 116.7 -> 122.9 us; 8192 x 4096, same bytes: 116.4 -> 115.9; 4096^2 62.3 -> 61.2;
+                // 2048^2 22.4 -> 20.8), whatever the order of the 24 loads and at six or seven wavefronts per SIMD
+                // (profiles/r03_buffer_addressing.md)
 #pragma unroll
                 for(int r = 0; r < 8; r++) {
                         J2P_CHK(k, x_own[0], &k.xcur[base + (size_t)r * W], 4, 209);
-                        xcv[r] = k.xcur[base + (size_t)r * W];
+                        if constexpr(PTR) { xcv[r] = k.xcur[base + (size_t)r * W]; }
+                        else { xcv[r] = buf_load1<false>(rc_, lane_off, (unsigned)r * W * 4u); }
                 }
 #pragma unroll
                 for(int r = 0; r < 8; r++) {
                         J2P_CHK(k, x_own[1], &k.xprev[base + (size_t)r * W], 4, 210);
-                        xpv[r] = k.xprev[base + (size_t)r * W];
+                        if constexpr(PTR) { xpv[r] = k.xprev[base + (size_t)r * W]; }
+                        else { xpv[r] = buf_load1<false>(rp_, lane_off, (unsigned)r * W * 4u); }
                 }
 #pragma unroll
                 for(int r = 0; r < 8; r++) {
                         J2P_CHK(k, grad, &k.grad[base + (size_t)r * W], 4, 208);
-                        if constexpr(NT >= 1) { gv[r] = __builtin_nontemporal_load(&k.grad[base + (size_t)r * W]); }
-                        else { gv[r] = k.grad[base + (size_t)r * W]; }
+                        if constexpr(PTR) {
+                                if constexpr(NT >= 1) { gv[r] = __builtin_nontemporal_load(&k.grad[base + (size_t)r * W]); }
+                                else { gv[r] = k.grad[base + (size_t)r * W]; }
+                        } else { gv[r] = buf_load1<(NT >= 1)>(rg_, lane_off, (unsigned)r * W * 4u); }
                 }
         }
         if constexpr(NIP) { norm = norm_tree_reduce(tree); }
@@ -2041,15 +2124,24 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
 }
 
 // NIP: the norm comes from norm_tree_wave (ProjArgs::norm_rowsums) instead of ProjArgs::norm
-// (80 registers for the 1x1 form = six wavefronts per SIMD; forcing seven or eight spills: 66 -> 76 / 97 us)
+// (70 registers for the 1x1 form with buffer addressing = seven wavefronts per SIMD, 78 = six in the pointer form; capping
+// seven back to six — J2P_PROJECT_MAXWAVES=6 — changes nothing, forcing eight spills)
 #ifndef J2P_PROJECT_WAVES
 #define J2P_PROJECT_WAVES 0
 #endif
-template <bool LOG, int WS, int HS, int NT = 0, bool NIP = false>
+template <bool LOG, int WS, int HS, int NT = 0, bool NIP = false, bool PTR = false>
 __global__ __launch_bounds__(256, (J2P_PROJECT_WAVES && WS == 1 && HS == 1 && !LOG && !NIP ? J2P_PROJECT_WAVES : 1)) void k_project(ProjArgs a)
 {
         __shared__ ProjShared sh;
-        project_strip<LOG, WS, HS, NT, NIP>(a, sh);
+#ifdef J2P_PROJECT_MAXWAVES     // (experiment: cap the wavefronts per SIMD by the workgroup's LDS footprint instead of raising them)
+        __shared__ float occupancy_pad[(160 * 1024 / (J2P_PROJECT_MAXWAVES + 1) - sizeof(ProjShared)) / 4 + 64];
+        if(a.geo.W == 0xffffffffu) {            // (never: keeps the allocation alive)
+                occupancy_pad[threadIdx.x] = (float)a.geo.H;
+                __syncthreads();
+                if(occupancy_pad[threadIdx.x ^ 1] == 3.f) { __builtin_trap(); }
+        }
+#endif
+        project_strip<LOG, WS, HS, NT, NIP, PTR>(a, sh);
 }
 
 // Small canvases are bound by the number of dependent launches per iteration, not by bytes: there ALL channels

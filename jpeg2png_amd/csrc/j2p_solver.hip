@@ -689,10 +689,20 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
                 else if(s->norm_by_project) { hipLaunchKernelGGL((k_project<false, WS_, HS_, 0, true>), grid, dim3(256), 0, st, a); } \
                 else { hipLaunchKernelGGL((k_project<false, WS_, HS_>), grid, dim3(256), 0, st, a); }    \
         } while(0)
+                // (rows >= 64 KiB apart: the pointer form of the 24 loads, see project_strip)
+                const bool far_rows = (size_t)s->W * sizeof(float) >= 65536;
                 if(ws == 1 && hs == 1 && s->nt >= 1 && !inwave_nt_off && !log && !s->norm_by_project) {
-                        if(s->nt >= 3) { hipLaunchKernelGGL((k_project<false, 1, 1, 3>), grid, dim3(256), 0, st, a); }
+                        if(far_rows) {
+                                if(s->nt >= 3) { hipLaunchKernelGGL((k_project<false, 1, 1, 3, false, true>), grid, dim3(256), 0, st, a); }
+                                else if(s->nt == 2) { hipLaunchKernelGGL((k_project<false, 1, 1, 2, false, true>), grid, dim3(256), 0, st, a); }
+                                else { hipLaunchKernelGGL((k_project<false, 1, 1, 1, false, true>), grid, dim3(256), 0, st, a); }
+                        }
+                        else if(s->nt >= 3) { hipLaunchKernelGGL((k_project<false, 1, 1, 3>), grid, dim3(256), 0, st, a); }
                         else if(s->nt == 2) { hipLaunchKernelGGL((k_project<false, 1, 1, 2>), grid, dim3(256), 0, st, a); }
                         else { hipLaunchKernelGGL((k_project<false, 1, 1, 1>), grid, dim3(256), 0, st, a); }
+                }
+                else if(ws == 1 && hs == 1 && far_rows && !log && !s->norm_by_project) {
+                        hipLaunchKernelGGL((k_project<false, 1, 1, 0, false, true>), grid, dim3(256), 0, st, a);
                 }
                 else if(ws == 1 && hs == 1) { J2P_LAUNCH_PROJECT(1, 1); }
                 else if(ws == 2 && hs == 2) { J2P_LAUNCH_PROJECT(2, 2); }

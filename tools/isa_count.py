@@ -63,7 +63,7 @@ def count(body, trips):
     dpp = sum(n for k, n in c.items() if k.endswith("_dpp"))
     trans = sum(n for k, n in c.items() if k.startswith(("v_rcp", "v_rsq", "v_sqrt")))
     salu = sum(n for k, n in c.items() if k.startswith("s_") and k not in ("s_nop", "s_waitcnt"))
-    vmem = sum(n for k, n in c.items() if k.startswith("global"))
+    vmem = sum(n for k, n in c.items() if k.startswith(("global", "buffer_load", "buffer_store")))
     lds = sum(n for k, n in c.items() if k.startswith("ds_"))
     cyc = sum(n * cycles(k) for k, n in c.items())
     return (f"total {tot / trips:.1f} = VALU {valu / trips:.1f} (packed {pk / trips:.1f}, DPP {dpp / trips:.1f}, transcendental {trans / trips:.1f}) "
@@ -89,4 +89,6 @@ for want, trips in (("k_gradient<1, true, false, 1, 1, 2>", 4), ("k_gradient<1, 
     print(f"{want}: VGPRs {m.group(1) if m else '?'}, code {code.group(1) if code else '?'} bytes")
     for which, h in enumerate(hdr):
         body = L[h:hdr[which + 1]] if which + 1 < len(hdr) else L[h:]
+        if sum(1 for t in body if t.strip().startswith("v_pk_")) < 100:
+            continue                        # not a march (reduction / flush loops)
         print(f"   march {which}: per trip {count(body, trips)}")
