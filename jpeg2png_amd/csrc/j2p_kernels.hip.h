@@ -33,6 +33,8 @@
 //                     what the 1.15x over-fetch costs
 //   J2P_EXP_SHORTDIV  k_gradient WITHOUT the all-ones-mantissa test its short division needs (wrong once in ~1e6
 //                     pixels): what that test costs
+// -DJ2P_TRACE -DJ2P_TRACE_CLOCK: the trace record's middle stamp becomes the wavefront's life in CORE-clock ticks (s_memtime)
+// next to its life on the constant 100 MHz clock: the shader clock the kernels actually run at (tools/core_clock.py)
 // (and one that stays correct: J2P_PROJECT_MAXWAVES=N caps k_project's wavefronts per SIMD through its LDS footprint)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -1015,6 +1017,9 @@ void k_gradient(GradArgs a)
 #ifdef J2P_TRACE
         const unsigned long long tr_start = trace_now();
         unsigned long long tr_data = 0;
+#ifdef J2P_TRACE_CLOCK
+        const unsigned long long tr_core = clock64();
+#endif
 #endif
         const int W = (int)a.geo.W, H = (int)a.geo.H;
         const int rows = (int)a.geo.rows, row0 = (int)a.geo.row0;
@@ -1358,6 +1363,9 @@ void k_gradient(GradArgs a)
         }
 #ifdef J2P_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wavefront's stores have been acknowledged
+#ifdef J2P_TRACE_CLOCK
+        tr_data = clock64() - tr_core;                            // core-clock ticks of the wavefront's life (tools/core_clock.py)
+#endif
         trace_put(a.geo.trace, a.geo.trace_cap, a.geo.trace_base, 1u, a.geo.trace_seq, tr_start, tr_data, trace_now());
 #endif
 }
@@ -1777,6 +1785,9 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
 #ifdef J2P_TRACE
         const unsigned long long tr_start = trace_now();
         unsigned long long tr_data = 0;
+#ifdef J2P_TRACE_CLOCK
+        const unsigned long long tr_core = clock64();
+#endif
 #endif
 
         const unsigned zi = blockIdx.z;
@@ -2119,6 +2130,9 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
         }
 #ifdef J2P_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef J2P_TRACE_CLOCK
+        tr_data = clock64() - tr_core;
+#endif
         trace_put(a.geo.trace, a.geo.trace_cap, a.geo.trace_base, 2u, a.geo.trace_seq, tr_start, tr_data, trace_now());
 #endif
 }

@@ -943,15 +943,15 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 if(waves(2, kTY) < kPx1Waves && !s->joint_inwave) { px = 1; }
                 if(waves(px, g) < kHalfStripWaves) { g = 8; }
                 if(g == 8 && waves(px, g) < kShortStripWaves) { g = 4; }
-                // (timing experiments: J2P_PX = 1 / 2, J2P_RPW = 4 / 8 / 16 / 32 / 64 for every solver of the process;
-                // rows above 16 on whole canvases only)
+                // (timing experiments: J2P_PX = 1 / 2, J2P_RPW = 2 ... 64 for every solver of the process; band solvers take
+                // only the divisors of the band alignment, 16 — tools/rpw_fine.py sweeps the rest on whole canvases)
                 if(const char *env = getenv("J2P_PX")) {
                         const int v = atoi(env);
                         if((v == 1 && !s->joint_inwave) || v == 2) { px = (unsigned)v; }
                 }
                 if(const char *env = getenv("J2P_RPW")) {
                         const int v = atoi(env);
-                        if(v == 4 || v == 8 || v == 16 || v == 32 || v == 64) { g = (unsigned)v; }
+                        if(v >= 2 && v <= 64 && (s->whole || kTY % v == 0)) { g = (unsigned)v; }
                 }
                 s->px = px;
                 s->rpw = g;
