@@ -72,7 +72,7 @@ def parse():
     ap.add_argument("--height", type=int, default=0, help="override plane height (debug, single GPU)")
     ap.add_argument("--iterations", type=int, default=0, help="override iterations per solve (debug)")
     ap.add_argument("--batch", type=int, default=32, help="--config batch: images per step")
-    ap.add_argument("--slots", type=int, default=4, help="--config batch: images in flight per GPU")
+    ap.add_argument("--slots", type=int, default=8, help="--config batch: images in flight per GPU (measured 4 / 6 / 8 / 12: 188 / 197 / 203 / 193 images/s, profiles/r03_batch_slots.jsonl)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--timing-every", type=int, default=16, help="HIP-event sample stride (iterations)")
