@@ -409,7 +409,11 @@ def roofline_object(value_mpx, gpus_used, its, elapsed, steps, band_px, per_kern
             "event_samples": samples,
             "note": "per-kernel durations come from HIP events around every "
                     f"{timing_every}th iteration; the event records themselves cost time on those "
-                    "iterations, so the two durations can add up to more than iteration_ms"}
+                    "iterations, so the two durations can add up to more than iteration_ms",
+            "what_limits_it": "vector-ALU issue, not HBM: with every operand cache-resident k_gradient takes 57.6 of its 62.2 us "
+                              "and k_project 61.8 of 66.1 (profiles/r03_decomposition.jsonl); the SIMDs run at 1.96 / 2.07 GHz "
+                              "under these kernels (profiles/r03_core_clock.jsonl), at which their vector instructions fill "
+                              "about 90 % of the launch (DESIGN.md section 4); the HBM fraction is reported as the contract asks"}
 
 
 def single_gpu(a, j, synth, local_rank):

@@ -1,6 +1,6 @@
 """instruction count AND estimated issue cycles of k_gradient's marches per row trip, from the device assembly.
-One line per compiled march (in the order the compiler laid them out: interior strips with unit sampling, interior
-strips, general) of the 1-channel (non-temporal g: the 4096^2 headline) and the channel-per-wavefront kernel; blocks
+One line per compiled march (in the order the compiler laid them out — at present general, interior strips, interior
+strips with unit sampling = the hot one, whose count runs on into the strip's epilogue) of the 1-channel (non-temporal g: the 4096^2 headline) and the channel-per-wavefront kernel; blocks
 of the IEEE fallback (they contain v_div_scale / v_sqrt) are left out, the partial flush is counted although it runs
 once per strip.  Cycle weights: tools/ubench/valu_rates (profiles/r03_valu_rates.json, 8 wavefronts per SIMD):
 plain f32 2.7, packed f32 4.5-5.6, transcendental 8.1, f64 4.5-5.3, DPP 4.1, max / min / compare / select 4.3.
@@ -83,7 +83,9 @@ for want, trips in (("k_gradient<1, true, false, 1, 1, 2>", 4), ("k_gradient<1, 
     i = text.index(kern + ":")
     j = text.index("s_endpgm", i)
     L = text[i:j].split("\n")
-    hdr = [n for n, line in enumerate(L) if "Inner Loop Header" in line]
+    # marches are depth-1 loops; one that wraps a store in a waterfall loop (a row offset the compiler kept in a vector
+    # register) is a depth-1 header with inner loops, not an "Inner Loop Header": take both
+    hdr = [n for n, line in enumerate(L) if "Loop Header: Depth=1" in line]
     m = re.search(r"; NumVgprs: *(\d+)", text[j:j + 6000])
     code = re.search(r"codeLenInByte = (\d+)", text[j:j + 6000])
     print(f"{want}: VGPRs {m.group(1) if m else '?'}, code {code.group(1) if code else '?'} bytes")
