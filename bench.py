@@ -18,11 +18,13 @@ Workloads (BASELINE.json configs):
             c    : the C row tiling (j2p_tiled: one process drives all N GPUs with one host thread per band;
                    bands exchange edge rows and norm row sums by peer access over xGMI, ordered by HIP events)
                    — rank 0 drives it; the other ranks of the launch wait in a gloo (CPU) barrier, so that no
-                   RCCL barrier kernel spins on their GPUs while rank 0's band kernels run there; timed twice:
-                   its default schedule and the split-phase one (c_split, J2P_TILED_SPLIT=1);
+                   RCCL barrier kernel spins on their GPUs while rank 0's band kernels run there; timed three times:
+                   its default schedule, the split-phase one (c_split, J2P_TILED_SPLIT=1) and the default one with
+                   every band reducing ||g|| itself (c_allnorm, J2P_TILED_NORM=all: one cross-GPU hop less per
+                   iteration, N - 1 event waits per band instead of one);
             rccl : one process per GPU, RCCL send/recv of the halo rows + all-gather of the norm row sums
                    (jpeg2png_amd/tiled.py), the exchange north_star names.
-          `value` is the faster of the two (`config.parallelism` says which), the other one is in
+          `value` is the fastest of them (`config.parallelism` says which), the other one is in
           `other_configs`, next to the SAME canvas solved whole on ONE GPU (the strong-scaling denominator)
           and configs[4] — 256 x 1080p 4:2:0 Q50 -i 100 through the C batch engine over all N GPUs.
   --config batch : configs[4] slice — B x 1080p 4:2:0 Q=50 -i 100 through the C batch API
@@ -497,12 +499,13 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
     # ---- legs 1a / 1b: the C engine, driven by rank 0 — its default schedule (one gradient and one projection launch per
     # band and iteration, the halo rows pulled in front of the gradient) and the split one (J2P_TILED_SPLIT=1: interior /
     # edge parts, the halo exchange hidden behind the interior launches) ----
-    def c_leg(name, split):
+    def c_leg(name, split, norm="root"):
         ok = [True, ""]
         tsolver = eng = None
         if rank == 0:
             try:
                 os.environ["J2P_TILED_SPLIT"] = "1" if split else "0"          # read by j2p_tiled_create
+                os.environ["J2P_TILED_NORM"] = norm
                 devices = list(range(n_gpus)) if n_gpus > 1 and not one_device else [local_rank] * nband
                 tsolver = j.TiledSolver([whole_plane], WEIGHT, [PWEIGHT], its, devices=devices)
                 eng = tsolver.band_solver(0)
@@ -510,6 +513,7 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
                 ok = [False, f"{type(e).__name__}: {e}"]
             finally:
                 os.environ.pop("J2P_TILED_SPLIT", None)
+                os.environ.pop("J2P_TILED_NORM", None)
         ok = ranks.share(ok)
         if ok[0]:
             if rank == 0:
@@ -523,9 +527,11 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
             legs[name] = {"elapsed": elapsed, "g_ms": g_ms, "p_ms": p_ms, "samples": samples, "split": split,
                           "host_cpu_s": round(cpu_s, 3),
                           "parallelism": (f"row-tiled x{nband}: C engine (j2p_tiled), one process drives all GPUs, one host thread per "
-                                          "band; edge rows and norm row sums read over peer access, ordered by HIP events; one band "
-                                          "reduces ||g|| for all; " + ("split phases (halo exchange behind the interior launches)" if split
-                                                                      else "one gradient and one projection launch per iteration"))}
+                                          "band; edge rows and norm row sums read over peer access, ordered by HIP events; "
+                                          + ("one band reduces ||g|| for all; " if norm == "root" else
+                                             "every band reduces ||g|| itself from all bands' row sums (one cross-GPU hop less, N - 1 waits); ")
+                                          + ("split phases (halo exchange behind the interior launches)" if split
+                                             else "one gradient and one projection launch per iteration"))}
         elif rank == 0:
             print(f"bench: C row tiling ({name}) unavailable: {ok[1]}", file=sys.stderr, flush=True)
             legs[name + "_error"] = ok[1]
@@ -535,6 +541,7 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
         c_leg("c", False)
         if "c" in legs:
             c_leg("c_split", True)
+            c_leg("c_allnorm", False, "all")
 
     # ---- leg 2: one process per GPU over RCCL ----
     watchdog = None
