@@ -401,10 +401,14 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                 j2p_solver_halo_rows(bd->solver, 1, &bd->rows[1]);
                 // the two-part phases need an interior: three 16-row segments and three block rows of every channel
                 bd->split = t->want_split && nband > 1 && bd->row1 - bd->row0 >= 3 * align && bd->row1 - bd->row0 >= 3 * J2P_TILE_ROWS;
+                // (J2P_TILED_EVENT_FLAGS=<hex>: extra hipEventCreateWithFlags bits, a timing experiment — e.g. 0x20000000
+                // hipEventDisableSystemFence, 0x40000000 hipEventReleaseToDevice; NOT for bands on different GPUs)
+                unsigned evflags = hipEventDisableTiming;
+                if(const char *env = getenv("J2P_TILED_EVENT_FLAGS")) { evflags |= (unsigned)strtoul(env, nullptr, 16); }
                 for(int k = 0; k < 2 && rc == J2P_OK; k++) {
-                        if(hipEventCreateWithFlags(&bd->ev_grad[k], hipEventDisableTiming) != hipSuccess ||
-                           hipEventCreateWithFlags(&bd->ev_edge[k], hipEventDisableTiming) != hipSuccess ||
-                           hipEventCreateWithFlags(&bd->ev_norm[k], hipEventDisableTiming) != hipSuccess) {
+                        if(hipEventCreateWithFlags(&bd->ev_grad[k], evflags) != hipSuccess ||
+                           hipEventCreateWithFlags(&bd->ev_edge[k], evflags) != hipSuccess ||
+                           hipEventCreateWithFlags(&bd->ev_norm[k], evflags) != hipSuccess) {
                                 rc = j2p_fail(J2P_EDEVICE, "hipEventCreate failed");
                         }
                 }
