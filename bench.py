@@ -412,10 +412,11 @@ def roofline_object(value_mpx, gpus_used, its, elapsed, steps, band_px, per_kern
             "note": "per-kernel durations come from HIP events around every "
                     f"{timing_every}th iteration; the event records themselves cost time on those "
                     "iterations, so the two durations can add up to more than iteration_ms",
-            "what_limits_it": "vector-ALU issue, not HBM: with every operand cache-resident k_gradient takes 57.6 of its 62.2 us "
-                              "and k_project 61.8 of 66.1 (profiles/r03_decomposition.jsonl); the SIMDs run at 1.96 / 2.07 GHz "
-                              "under these kernels (profiles/r03_core_clock.jsonl), at which their vector instructions fill "
-                              "about 90 % of the launch (DESIGN.md section 4); the HBM fraction is reported as the contract asks"}
+            "what_limits_it": "both limits at once: k_project moves its bytes at about the achievable HBM rate of this part (6.29 TB/s "
+                              "float4 copy, MI355X_MICROARCH.md; peak above is the 8 TB/s spec the contract asks for); k_gradient moves "
+                              "its real traffic (1.15 x algorithmic: halo rows) at 0.9 of that rate while its vector ALUs are about "
+                              "90 % busy at the 1.96 GHz the SIMDs sustain under it (profiles/r03_core_clock.jsonl, r03_decomposition.jsonl; "
+                              "DESIGN.md sections 4-5)"}
 
 
 def single_gpu(a, j, synth, local_rank):

@@ -615,6 +615,20 @@ def test_every_schedule_switch_leaves_the_bits_alone(lib, oracle, shape, monkeyp
                     t.run(its)
                     for c in range(n):
                         assert bit_equal(t.download(c), want[c]), f"px {px} rpw {rpw}, two bands: channel {c}"
+    # strip heights that do not divide the band alignment (what tools/rpw_fine.py sweeps): whole canvases take them,
+    # band solvers keep their own choice — the bits are the reference's either way
+    monkeypatch.setenv("J2P_PX", "2")
+    for rpw in ("2", "6", "12", "24"):
+        monkeypatch.setenv("J2P_RPW", rpw)
+        got = copy.deepcopy(planes)
+        j.compute(got, 0.3, [0.001] * n, its)
+        for c in range(n):
+            assert bit_equal(got[c].fdata, want[c]), f"rpw {rpw} channel {c}"
+        if h >= 128:
+            with j.TiledSolver(planes, 0.3, [0.001] * n, its, devices=[0, 0]) as t:
+                t.run(its)
+                for c in range(n):
+                    assert bit_equal(t.download(c), want[c]), f"rpw {rpw} (ignored by band solvers), two bands: channel {c}"
 
 
 def test_concurrent_calls_are_independent(lib, oracle):
