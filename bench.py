@@ -500,13 +500,15 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
     # ---- legs 1a / 1b: the C engine, driven by rank 0 — its default schedule (one gradient and one projection launch per
     # band and iteration, the halo rows pulled in front of the gradient) and the split one (J2P_TILED_SPLIT=1: interior /
     # edge parts, the halo exchange hidden behind the interior launches) ----
-    def c_leg(name, split, norm="root"):
+    def c_leg(name, split, norm="root", event_flags=None, digest=False):
         ok = [True, ""]
         tsolver = eng = None
         if rank == 0:
             try:
                 os.environ["J2P_TILED_SPLIT"] = "1" if split else "0"          # read by j2p_tiled_create
                 os.environ["J2P_TILED_NORM"] = norm
+                if event_flags is not None:
+                    os.environ["J2P_TILED_EVENT_FLAGS"] = event_flags
                 devices = list(range(n_gpus)) if n_gpus > 1 and not one_device else [local_rank] * nband
                 tsolver = j.TiledSolver([whole_plane], WEIGHT, [PWEIGHT], its, devices=devices)
                 eng = tsolver.band_solver(0)
@@ -515,6 +517,7 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
             finally:
                 os.environ.pop("J2P_TILED_SPLIT", None)
                 os.environ.pop("J2P_TILED_NORM", None)
+                os.environ.pop("J2P_TILED_EVENT_FLAGS", None)
         ok = ranks.share(ok)
         if ok[0]:
             if rank == 0:
@@ -523,10 +526,14 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
                 reset = solve = sync = (lambda: None)
             elapsed, g_ms, p_ms, samples = time_steps(ranks, reset, solve, sync, a.warmup, a.steps, eng, a.timing_every)
             cpu_s = tsolver.host_cpu_seconds() if rank == 0 else 0.0
+            fingerprint = None
             if rank == 0:
+                if digest:          # the plane the last timed step left behind (every leg runs the same solve)
+                    import hashlib
+                    fingerprint = hashlib.blake2b(tsolver.download(0), digest_size=16).hexdigest()
                 tsolver.close()
             legs[name] = {"elapsed": elapsed, "g_ms": g_ms, "p_ms": p_ms, "samples": samples, "split": split,
-                          "host_cpu_s": round(cpu_s, 3),
+                          "host_cpu_s": round(cpu_s, 3), "digest": fingerprint, "experimental": event_flags is not None,
                           "parallelism": (f"row-tiled x{nband}: C engine (j2p_tiled), one process drives all GPUs, one host thread per "
                                           "band; edge rows and norm row sums read over peer access, ordered by HIP events; "
                                           + ("one band reduces ||g|| for all; " if norm == "root" else
@@ -539,10 +546,15 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
         ranks.barrier()
 
     if want_c:
-        c_leg("c", False)
+        c_leg("c", False, digest=True)
         if "c" in legs:
             c_leg("c_split", True)
             c_leg("c_allnorm", False, "all")
+            # an experiment the line reports but never scores: the tiling's events created with hipEventDisableSystemFence
+            # (4 us less per cross-stream dependency on one GPU, profiles/r03_tiled_event_flags.jsonl).  Without that fence
+            # HIP does not promise that a PEER GPU sees the rows an event covers; whether it does on this box shows in
+            # `bits_equal_to_the_default_schedule` (a hash of the resulting plane against leg c's)
+            c_leg("c_nofence_experiment", False, event_flags="20000000", digest=True)
 
     # ---- leg 2: one process per GPU over RCCL ----
     watchdog = None
@@ -561,7 +573,7 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
         """rank 0: assemble the JSON line from the legs measured so far"""
         if rank != 0:
             return
-        timed = {k: v for k, v in legs.items() if isinstance(v, dict) and "elapsed" in v}
+        timed = {k: v for k, v in legs.items() if isinstance(v, dict) and "elapsed" in v and not v.get("experimental")}
         if not timed and not strict:
             return
         if not timed:
@@ -583,6 +595,11 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
         for k, v in legs.items():
             if not isinstance(v, dict):
                 others.append({"config": f"engine {k}", "error": v})
+            elif v.get("experimental") and "elapsed" in v:
+                others.append({"config": f"experiment, not scored ({k}): the C row tiling with events created with hipEventDisableSystemFence",
+                               "Mpx_it_per_s": round(px * its * a.steps / v["elapsed"] / 1e6, 1),
+                               "ms_per_step": round(v["elapsed"] / a.steps * 1e3, 3),
+                               "bits_equal_to_the_default_schedule": (v.get("digest") is not None and v.get("digest") == legs.get("c", {}).get("digest"))})
         others += extra_other or []
         gpus_used = n_gpus if n_gpus > 1 else 1
         out = {
