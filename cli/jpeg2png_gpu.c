@@ -13,8 +13,9 @@
  *                  is a job of the library's batch engine, j2p_batch_*), instead of an OpenMP thread count;
  *                  default: the number of online cores, as OpenMP's default is (jpeg2png.c:246-257, :330)
  *   J2P_DEVICE / J2P_DEVICES environment: GPU index, or a comma list.  Files are spread over the listed GPUs; with
- *                  fewer files than GPUs every image is row-tiled over ALL of them instead (one band per GPU when
- *                  its canvas has at least 48 rows per GPU) — same pixels either way
+ *                  fewer files than GPUs the GPUs are shared out among the files and every image is row-tiled
+ *                  over its share (one band per GPU; the library uses fewer bands, or one GPU, for images too
+ *                  small to pay for the cross-band schedule: at least 2 Mpixel per band) — same pixels either way
  * Messages and exit codes follow the reference ("jpeg2png: <message>", EXIT_FAILURE).
  */
 #define _POSIX_C_SOURCE 200809L
@@ -199,7 +200,8 @@ struct options {
         float weights[3], pweights[3];
         unsigned png_bits;
         bool joint, quiet;
-        bool tile;              /* fewer files than GPUs: every image over all of them */
+        bool tile;              /* fewer files than GPUs: every image row-tiled over its share of them */
+        unsigned nfiles;
         FILE *csv;
         int ndev, devs[16];
 };
@@ -253,7 +255,7 @@ static void job_progress(void *user, unsigned n)
 /* decode_file (jpeg2png.c:120-172): the coefficients go to the library's batch engine, which decodes, solves
  * (one joint compute(3, ...) or three compute(1, ...), jpeg2png.c:141-152) and converts on a GPU slot of its own
  * while this thread's neighbours read their JPEGs and deflate their PNGs */
-static void decode_file(const char *infile, const char *outfile, const struct options *o)
+static void decode_file(const char *infile, const char *outfile, const struct options *o, unsigned index)
 {
         FILE *in = fopen(infile, "rb");
         if(!in) { die_perror("could not open input file `%s`", infile); }
@@ -279,6 +281,11 @@ static void decode_file(const char *infile, const char *outfile, const struct op
         }
         job.separate = !o->joint;
         job.tile = o->tile;
+        if(o->tile && o->nfiles > 1) {
+                /* several files, still fewer than GPUs: file i gets GPUs [i n / f, (i + 1) n / f) of the list */
+                job.tile_first = index * (unsigned)o->ndev / o->nfiles;
+                job.tile_count = (index + 1) * (unsigned)o->ndev / o->nfiles - job.tile_first;
+        }
         job.out_bits = o->png_bits;
         job.out_w = jp.w;
         job.out_h = jp.h;
@@ -319,7 +326,7 @@ static void *worker(void *arg)
                 unsigned i = w->next++;
                 pthread_mutex_unlock(&w->lock);
                 if(i >= w->nin) { break; }
-                decode_file(w->in[i], w->out[i], w->o);
+                decode_file(w->in[i], w->out[i], w->o, i);
         }
         return NULL;
 }
@@ -343,7 +350,7 @@ static void usage(void)
                "  -q, --quiet                  no progress bar\n"
                "  -h, --help    -V, --version\n"
                "environment: J2P_DEVICE=n or J2P_DEVICES=a,b,... selects the GPU(s); fewer files than GPUs:\n"
-               "             every image is row-tiled over all of them\n");
+               "             large images are row-tiled over their share of them\n");
         exit(EXIT_FAILURE);
 }
 
@@ -469,9 +476,10 @@ int main(int argc, char **argv)
         pthread_mutex_init(&w.lock, NULL);
         if(threads > nin) { threads = nin; }
         /* as many GPU slots as files in flight, spread over the devices of J2P_DEVICES; with fewer files than GPUs
-         * the library tiles every image over all of them (decode_file -> compute of one large image,
-         * jpeg2png.c:141-152) */
+         * the GPUs are shared out among the files and the library tiles every image over its share (decode_file ->
+         * compute of one large image, jpeg2png.c:141-152) when the image is large enough for that to pay */
         o.tile = o.ndev > 1 && nin < (unsigned)o.ndev;
+        o.nfiles = nin;
         batch_ndev = (unsigned)o.ndev;
         memcpy(batch_devs, o.devs, sizeof(batch_devs));
         batch_slots = (threads + batch_ndev - 1) / batch_ndev;

@@ -76,7 +76,9 @@ int j2p_device_count(int *count);
 
 /* aux_init (compute.c:278-310) on the device: uploads the planes (for a band:
  * only the coefficient rows the band covers; `planes` always describes the
- * WHOLE image, host arrays may be band-local when band_local_arrays != 0),
+ * WHOLE image, host arrays may be band-local when bit 0 of band_local_arrays is set;
+ * bit 1, J2P_BAND_EVEN_IF_WHOLE: a band covering every row is still driven with the
+ * phase calls and exchanges like any other band — one-band runs of the row tiling),
  * allocates x_k, x_{k-1}, gradient, prob state, and sets x_k = x_{k-1} =
  * replicate-upsample(fdata).  `iterations` fixes the step size
  * radius/sqrtf(1+iterations) (compute.c:443).  `stream` is a hipStream_t
@@ -86,6 +88,8 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream,
                       float weight, const float pweight[], unsigned iterations,
                       j2p_band band, int band_local_arrays);
 void j2p_solver_destroy(j2p_solver *s);
+#define J2P_BAND_LOCAL_ARRAYS  1
+#define J2P_BAND_EVEN_IF_WHOLE 2
 
 /* Device memory of destroyed solvers is cached per process and handed to the next solver on the same device
  * (hipMalloc / hipFree cost milliseconds and hipFree stalls every stream of the device, which matters when the
@@ -215,13 +219,43 @@ int j2p_solver_norm_ptr(j2p_solver *s, float **norm);              /* device add
 int j2p_solver_norm_external(j2p_solver *s);
 int j2p_solver_copy_rows(j2p_solver *s, unsigned n, float *const dst[], const float *const src[], size_t floats);
 
+/* Bands that can WRITE each other's memory (same GPU, or peer access): the two per-iteration exchanges without a
+ * kernel of their own.  After link_bands a band's projection phase stores its first / last J2P_HALO_ROWS rows of the
+ * new iterate ALSO into the neighbouring solvers' halo rows (no halo copy or send), and its gradient phase stores
+ * its level-1 sums of ||g||^2 into EVERY band's own copy of the global [tile row][channel] array (no reduction
+ * launch on a root band, no norm event); the projection phase then reduces ||g|| from its own copy inside k_project.
+ * A band iteration is two launches, and all traffic between GPUs is posted writes.
+ *   up_halo / down_halo : [x buffer 0 / 1][channel] — j2p_solver_halo_rows(neighbour above, buffer).recv_bottom /
+ *                         (neighbour below, buffer).recv_top; all NULL at the canvas's first / last band
+ *   push                : [iteration parity][band] — every band's j2p_solver_global_rowsums() arrays (this band's
+ *                         own included), npush of them
+ * The CALLER orders the streams: a band's gradient phase of iteration k behind its neighbours' projection of k - 1;
+ * its projection of k behind EVERY band's gradient phase of k — which is also what makes the stores into the
+ * neighbours' halo rows safe: they replace the halo of x_{k-1}, which the neighbours' gradient phase of k still read. */
+typedef struct j2p_band_links {
+        float *up_halo[2][J2P_MAX_CHANNELS];
+        float *down_halo[2][J2P_MAX_CHANNELS];
+        unsigned npush;
+        double *push[2][32];
+} j2p_band_links;
+int j2p_solver_global_rowsums(j2p_solver *s, double *arrays[2]);   /* band solvers: [global tile row][channel], even / odd iterations */
+int j2p_solver_link_bands(j2p_solver *s, const j2p_band_links *links);   /* NULL: back to halo rows of its own */
+
 /* One plane set row-tiled over several GPUs from one process: nband solvers, band i on devices[i] (ids may
  * repeat), one host thread per band.  cuts = nband + 1 row boundaries from 0 to the canvas height, aligned to
  * lcm(16, 8 * h_samp), or NULL for near-equal bands.  run / sync / download mirror the j2p_solver calls; the
  * planes are bit-identical to a whole-canvas solver's whatever the cut.  (Reference loop: compute.c:427-453.)
- * nband == 1 is a plain whole-canvas solver behind the same calls.  Per iteration one band reduces ||g|| for all
- * (environment J2P_TILED_NORM=all: every band for itself); J2P_TILED_SPLIT=1 selects the two-part phases that hide the
- * halo exchange behind the interior launches (measured slower on one GPU, j2p_tiled.hip; kept for A/B on xGMI).  host_cpu_seconds: user + system time the band
+ * nband == 1 is a plain whole-canvas solver behind the same calls.  How the bands exchange their row sums of g^2 and
+ * their edge rows is chosen at create time (j2p_tiled_exchange() names it; environment J2P_TILED_EXCHANGE forces one):
+ *   "direct" (default where every GPU can write every other's memory): both exchanges ride on the two phase kernels
+ *            as posted peer writes (j2p_solver_link_bands) — two launches and two event waits per band and iteration;
+ *   "copy"   round 3's schedule — a copy kernel pulls the neighbours' edge rows, one band reduces ||g|| for all
+ *            (J2P_TILED_NORM=all: every band for itself) — kept as the cross-check of "direct" and for canvases taller
+ *            than 16384 rows;
+ *   "rccl"   (default without peer access) ncclAllGather + grouped ncclSend / ncclRecv on the band's own stream, one
+ *            communicator per band from ncclCommInitAll, librccl loaded with dlopen (J2P_RCCL_LIBRARY names another
+ *            copy); needs one GPU per band.
+ * J2P_EDEVICE when none of them can work on the devices given.  host_cpu_seconds: user + system time the band
  * threads have spent issuing work so far. */
 typedef struct j2p_tiled j2p_tiled;
 int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const unsigned cuts[], unsigned nchannel,
@@ -234,6 +268,7 @@ int j2p_tiled_run(j2p_tiled *t, unsigned n, j2p_log_row *rows);   /* asynchronou
 int j2p_tiled_sync(j2p_tiled *t);
 int j2p_tiled_download(j2p_tiled *t, unsigned c, float *out);      /* W * H floats */
 int j2p_tiled_host_cpu_seconds(const j2p_tiled *t, double *seconds);
+int j2p_tiled_exchange(const j2p_tiled *t, const char **name);    /* "direct", "copy", "rccl"; "none" for one plain band */
 
 /* CSV logging for band solvers (the "+3 doubles when logging" of the norm exchange): with logging on, the
  * phase calls also leave the band's tv / tv2 / prob sums in j2p_exchange.log_local; the caller adds the bands'
@@ -316,11 +351,17 @@ typedef struct j2p_job {
         void (*on_rows)(void *user, unsigned channel, unsigned first, unsigned n, const j2p_log_row *rows);
         void (*on_progress)(void *user, unsigned n);
         void *user;
-        /* nonzero: ONE image over ALL the batch's devices — every solve of the job is row-tiled (j2p_tiled) with one
-         * band per device when the canvas has at least 48 rows per device, each band converting its own rows to
-         * RGB; for the case of fewer images than GPUs (decode_file -> compute of one large image,
-         * jpeg2png.c:141-152).  Same bits either way */
+        /* nonzero: ONE image over SEVERAL of the batch's devices — every solve of the job is row-tiled (j2p_tiled), one
+         * band per device, each band converting its own rows to RGB; for the case of fewer images than GPUs
+         * (decode_file -> compute of one large image, jpeg2png.c:141-152).  Same bits either way.  The devices are
+         * entries [tile_first, tile_first + tile_count) of the list given to j2p_batch_create (tile_count 0 = all of
+         * them), so that a few large images can each have a share of the GPUs.  How many bands there are is the
+         * library's decision: a band costs its GPU ~35 us per iteration of cross-band scheduling whatever its size
+         * (profiles/r03_band_alone.jsonl), so a band gets at least 2 Mpixel per channel (J2P_TILE_MIN_BAND_PIXELS
+         * overrides, tests) and at least 48 rows; an image too small for two such bands — and any image when the
+         * devices cannot be tiled over (no peer access and no RCCL) — is solved on ONE GPU instead */
         int tile;
+        unsigned tile_first, tile_count;
 } j2p_job;
 int j2p_batch_create(j2p_batch **out, unsigned ndev, const int devices[], unsigned slots_per_device);
 void j2p_batch_destroy(j2p_batch *b);                       /* finishes queued jobs first */

@@ -53,7 +53,8 @@ class _CJob(ctypes.Structure):
                 ("weight", ctypes.c_float * 3), ("pweight", ctypes.c_float * 3), ("iterations", ctypes.c_uint * 3),
                 ("out_bits", ctypes.c_uint), ("out_w", ctypes.c_uint), ("out_h", ctypes.c_uint),
                 ("out_rgb", ctypes.c_void_p), ("out_planes", ctypes.c_void_p * 3),
-                ("on_rows", _ROWS_CB), ("on_progress", _PROGRESS_CB), ("user", ctypes.c_void_p), ("tile", ctypes.c_int)]
+                ("on_rows", _ROWS_CB), ("on_progress", _PROGRESS_CB), ("user", ctypes.c_void_p), ("tile", ctypes.c_int),
+                ("tile_first", ctypes.c_uint), ("tile_count", ctypes.c_uint)]
 
 
 class _CExchange(ctypes.Structure):
@@ -79,6 +80,7 @@ C_ABI_SYMBOLS = [
     "j2p_solver_norm_from_bands", "j2p_solver_copy_rows", "j2p_solver_alternate_rowsums",
     "j2p_tiled_create", "j2p_tiled_destroy", "j2p_tiled_canvas", "j2p_tiled_band", "j2p_tiled_run", "j2p_tiled_reset", "j2p_tiled_sync",
     "j2p_tiled_download", "j2p_tiled_host_cpu_seconds", "j2p_solver_norm_ptr", "j2p_solver_norm_external",
+    "j2p_solver_global_rowsums", "j2p_solver_link_bands", "j2p_tiled_exchange",
     "j2p_batch_create", "j2p_batch_destroy", "j2p_batch_submit", "j2p_batch_wait",
     "compute", "j2p_compute", "j2p_compute_tiled",
     "j2p_debug_build", "j2p_solver_debug_violations", "j2p_solver_trace", "j2p_division_exhaustive",
@@ -450,6 +452,12 @@ class TiledSolver:
     def reset(self):
         _check(self._lib.j2p_tiled_reset(self._h))
 
+    def exchange(self):
+        """how the bands exchange row sums and edge rows: "direct", "copy", "rccl" ("none": one plain band)"""
+        name = ctypes.c_char_p()
+        _check(self._lib.j2p_tiled_exchange(self._h, ctypes.byref(name)))
+        return name.value.decode()
+
     def host_cpu_seconds(self):
         """user + system time the band threads have spent issuing work (they sleep while waiting for each other)"""
         v = ctypes.c_double()
@@ -499,12 +507,16 @@ class Batch:
         self._h = h
         self._pending = {}
 
-    def submit(self, planes, weight, pweight, iterations, separate=False, width=None, height=None, bits=0, tile=False):
-        """tile=True: the image is row-tiled over ALL the batch's devices instead of solved on one of them"""
+    def submit(self, planes, weight, pweight, iterations, separate=False, width=None, height=None, bits=0, tile=False,
+               tile_devices=None):
+        """tile=True: the image is row-tiled over the batch's devices instead of solved on one of them;
+        tile_devices=(first, count): over that slice of the batch's device list only"""
         n = len(planes)
         job = _CJob()
         job.nchannel = n
         job.tile = 1 if tile else 0
+        if tile_devices:
+            job.tile_first, job.tile_count = int(tile_devices[0]), int(tile_devices[1])
         cpl, keep = _c_planes(planes)
         for c in range(n):
             job.planes[c] = cpl[c]

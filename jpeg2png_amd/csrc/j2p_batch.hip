@@ -17,6 +17,8 @@
 #include <new>
 #include <thread>
 #include <vector>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "jpeg2png_amd.h"
@@ -58,31 +60,56 @@ constexpr unsigned kChunk = 32;         // iterations per round trip when a job 
 
 unsigned gcd_u(unsigned a, unsigned b) { return b ? gcd_u(b, a % b) : a; }
 
-// One image over all the batch's devices (j2p_job::tile): every solve of the job becomes a j2p_tiled with band b on
-// devices[b]; the solves of `-s` share their cuts so that band b of the three components meets on one GPU for the
-// colour conversion.  Returns J2P_OK with *handled = false when the canvas is too short to tile (the caller then
-// takes the single-solver path).
+// what both paths of a job check before they touch anything
+int validate_job(const j2p_job &d)
+{
+        if(d.nchannel == 0 || d.nchannel > J2P_MAX_CHANNELS) { return j2p_fail(J2P_EINVAL, "job: nchannel must be 1..3"); }
+        if(d.out_bits != 0 && d.out_bits != 8 && d.out_bits != 16) { return j2p_fail(J2P_EINVAL, "job: out_bits must be 0, 8 or 16"); }
+        if(d.out_bits && (!d.out_rgb || d.nchannel != 3)) { return j2p_fail(J2P_EINVAL, "job: RGB output needs three channels and out_rgb"); }
+        return J2P_OK;
+}
+
+// pixels per channel a band must at least have: the cross-band schedule costs every band ~35 us per iteration
+// whatever its size (profiles/r03_band_alone.jsonl: 276 vs 245 us for a 2048-row band of a 16384-wide plane), which
+// is more than a whole 1080p iteration takes on one GPU
+size_t tile_min_band_pixels()
+{
+        const char *env = getenv("J2P_TILE_MIN_BAND_PIXELS");       // (per job, not per iteration)
+        return env && *env ? (size_t)strtoull(env, nullptr, 10) : (size_t)2 << 20;
+}
+
+// One image over several of the batch's devices (j2p_job::tile): every solve of the job becomes a j2p_tiled with band
+// b on devices[b]; the solves of `-s` share their cuts so that band b of the three components meets on one GPU for
+// the colour conversion.  Returns J2P_OK with *handled = false when the image should be solved on one GPU after all:
+// too small for two bands (rows, or pixels per band), or the devices cannot be tiled over (the create phase failed:
+// no peer access and no RCCL, or no room for the band arenas) — the caller then takes the single-solver path.
+// Failures after the iterations have started stay failures.
 int run_job_tiled(const j2p_job &d, const std::vector<int> &devices, bool *handled)
 {
         *handled = false;
         const unsigned nsolve = d.separate ? d.nchannel : 1;
-        unsigned H[J2P_MAX_CHANNELS] = {0, 0, 0}, align = J2P_TILE_ROWS, hmin = ~0u;
+        unsigned H[J2P_MAX_CHANNELS] = {0, 0, 0}, Wc[J2P_MAX_CHANNELS] = {0, 0, 0}, align = J2P_TILE_ROWS, hmin = ~0u;
         for(unsigned c = 0; c < d.nchannel; c++) {
                 const j2p_plane &p = d.planes[c];
-                if(p.h_samp == 0 || p.h == 0) { return j2p_fail(J2P_EINVAL, "job: channel %u: empty plane", c); }
+                if(p.h_samp == 0 || p.h == 0 || p.w_samp == 0 || p.w == 0) { return j2p_fail(J2P_EINVAL, "job: channel %u: empty plane", c); }
                 align = align / gcd_u(align, 8 * p.h_samp) * (8 * p.h_samp);
                 const unsigned k = d.separate ? c : 0;
                 if(p.h * p.h_samp > H[k]) { H[k] = p.h * p.h_samp; }
+                if(p.w * p.w_samp > Wc[k]) { Wc[k] = p.w * p.w_samp; }
         }
-        for(unsigned k = 0; k < nsolve; k++) { if(H[k] < hmin) { hmin = H[k]; } }
-        // at least three 16-row gradient segments per band (an interior to hide the halo exchange behind)
+        size_t pixels_min = ~(size_t)0;
+        for(unsigned k = 0; k < nsolve; k++) {
+                if(H[k] < hmin) { hmin = H[k]; }
+                if((size_t)Wc[k] * H[k] < pixels_min) { pixels_min = (size_t)Wc[k] * H[k]; }
+        }
+        // at least three 16-row gradient segments per band
         unsigned per = 3 * J2P_TILE_ROWS;
         per = (per + align - 1) / align * align;
         unsigned nband = hmin / per;
+        if(tile_min_band_pixels() && pixels_min / tile_min_band_pixels() < nband) { nband = (unsigned)(pixels_min / tile_min_band_pixels()); }
         if(nband > devices.size()) { nband = (unsigned)devices.size(); }
         if(nband > 32) { nband = 32; }
         if(nband < 2) { return J2P_OK; }
-        *handled = true;
         // near-equal bands of the shortest canvas in units of the alignment; the last band ends where each canvas ends
         unsigned cuts[33];
         {
@@ -101,11 +128,20 @@ int run_job_tiled(const j2p_job &d, const std::vector<int> &devices, bool *handl
                 cuts[nband] = H[k];
                 its[k] = d.iterations[k];
                 if(d.separate) {
-                        JOB_TRY(j2p_tiled_create(&t[k], nband, devices.data(), cuts, 1, &d.planes[k], d.weight[k], &d.pweight[k], its[k]));
+                        rc = j2p_tiled_create(&t[k], nband, devices.data(), cuts, 1, &d.planes[k], d.weight[k], &d.pweight[k], its[k]);
                 } else {
-                        JOB_TRY(j2p_tiled_create(&t[k], nband, devices.data(), cuts, d.nchannel, d.planes, d.weight[0], d.pweight, its[k]));
+                        rc = j2p_tiled_create(&t[k], nband, devices.data(), cuts, d.nchannel, d.planes, d.weight[0], d.pweight, its[k]);
                 }
+                if(rc == J2P_EDEVICE || rc == J2P_ENOMEM) {
+                        // these GPUs cannot be tiled over (or have no room for it): the image is solved on one of them,
+                        // as it would have been without `tile`.  Nothing has run yet.
+                        fprintf(stderr, "jpeg2png_amd: not row-tiling this image over %u GPUs (%s); solving it on one\n", nband, j2p_last_error());
+                        rc = J2P_OK;
+                        goto out;
+                }
+                if(rc != J2P_OK) { goto out; }
         }
+        *handled = true;
         if(!chunked) {
                 for(unsigned k = 0; k < nsolve; k++) { JOB_TRY(j2p_tiled_run(t[k], its[k], nullptr)); }
         } else {
@@ -163,9 +199,6 @@ int run_job(const j2p_job &d, int device)
         int rc = J2P_OK;
         const j2p_band whole = {0, 0};
         const bool chunked = d.on_rows || d.on_progress;
-        if(d.nchannel == 0 || d.nchannel > J2P_MAX_CHANNELS) { return j2p_fail(J2P_EINVAL, "job: nchannel must be 1..3"); }
-        if(d.out_bits != 0 && d.out_bits != 8 && d.out_bits != 16) { return j2p_fail(J2P_EINVAL, "job: out_bits must be 0, 8 or 16"); }
-        if(d.out_bits && (!d.out_rgb || d.nchannel != 3)) { return j2p_fail(J2P_EINVAL, "job: RGB output needs three channels and out_rgb"); }
         if(d.separate) {
                 // jpeg2png.c:147-152: one compute(1, ...) per component, each with its own weight and iteration count
                 nsolver = d.nchannel;
@@ -227,9 +260,6 @@ out:
 
 void worker_main(j2p_batch *b, int device)
 {
-        // the distinct devices of the batch, in the order given (a tiled job puts one band on each)
-        std::vector<int> distinct_or_all = b->devices;
-
         (void)hipSetDevice(device);
         for(;;) {
                 Job *job = nullptr;
@@ -240,10 +270,25 @@ void worker_main(j2p_batch *b, int device)
                         job = b->queue.front();
                         b->queue.pop_front();
                 }
-                int rc = J2P_OK;
+                int rc = validate_job(job->desc);
                 bool tiled = false;
-                if(job->desc.tile && distinct_or_all.size() > 1) { rc = run_job_tiled(job->desc, distinct_or_all, &tiled); }
-                if(rc == J2P_OK && !tiled) { rc = run_job(job->desc, device); }
+                int single = device;
+                if(rc == J2P_OK && job->desc.tile) {
+                        // the job's share of the batch's devices, in the order given (a tiled job puts one band on each)
+                        const size_t first = job->desc.tile_first, nall = b->devices.size();
+                        const size_t count = job->desc.tile_count ? job->desc.tile_count : nall;
+                        if(first >= nall || count > nall - first) { rc = j2p_fail(J2P_EINVAL, "job: tile devices [%zu, %zu) of %zu", first, first + count, nall); }
+                        else {
+                                const std::vector<int> share(b->devices.begin() + (ptrdiff_t)first, b->devices.begin() + (ptrdiff_t)(first + count));
+                                if(job->desc.tile_count) { single = share[0]; }     // untiled after all: on a GPU of its share
+                                if(share.size() > 1) { rc = run_job_tiled(job->desc, share, &tiled); }
+                        }
+                }
+                if(rc == J2P_OK && !tiled) {
+                        if(single != device) { (void)hipSetDevice(single); }
+                        rc = run_job(job->desc, single);
+                        if(single != device) { (void)hipSetDevice(device); }
+                }
                 {
                         std::lock_guard<std::mutex> g(b->lock);
                         job->rc = rc;

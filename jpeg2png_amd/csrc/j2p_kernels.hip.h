@@ -256,6 +256,17 @@ struct Geo {
 #endif
 };
 
+// Row-tiled runs whose bands can write each other's memory (j2p_tiled, exchange "direct"): the level-1 sums of
+// ||g||^2 go straight into EVERY band's copy of the global [tile row][channel] array (the
+// band's own included), so that each band finishes the norm from memory of its own (norm_tree_wave in k_project, or
+// k_norm_finish) without a reduction launch on a root band and the event hop behind it
+constexpr int kMaxBands = 32;
+struct RowsumPush {
+        double *dst[kMaxBands];             // band b's global array of this iteration's parity
+        unsigned n;                         // 0 = no push
+        unsigned first_tr;                  // this band's first global tile row
+};
+
 struct GradArgs {
         ChanDev ch[kMaxCh];
         Geo geo;
@@ -273,6 +284,7 @@ struct GradArgs {
         unsigned nch_total;     // channels of the solver (partials per strip and tile row)
         unsigned fold_rows;     // tile rows this launch completes
         unsigned ntr_global;    // tile rows of the whole canvas (length of the tree's input)
+        RowsumPush push;        // (last: read by one wavefront per tile row only)
 };
 
 struct ProjArgs {
@@ -292,6 +304,14 @@ struct ProjArgs {
         // [tile row][channel] the gradient launch left behind (norm_tree_wave) — no reduction kernel between the phases
         const double *norm_rowsums;
         unsigned norm_rows, norm_nch;
+        // Row-tiled runs whose bands can write each other's memory (NIP == 2 instantiations only): the band's first /
+        // last kHalo rows of the new iterate ALSO go where the neighbouring bands' next gradient phase reads them — the
+        // lower halo rows of the band above, the upper halo rows of the band below, in the buffer that becomes x_{k+1}
+        // there too — instead of being copied or sent after the launch.  (Those rows hold the neighbour's halo of
+        // x_{k-1} until now, which its gradient launch of THIS iteration read: no projection starts before every
+        // band's gradient launch has finished, it needs ||g||.)  NULL = nobody to tell.
+        float *halo_up[kMaxCh];      // row 0 of the lower halo rows of the band above
+        float *halo_down[kMaxCh];    // row 0 of the upper halo rows of the band below
 };
 
 // rows per norm partial on canvases large enough to fill the chip: the granularity of the GPU-count invariant
@@ -904,6 +924,15 @@ __device__ __forceinline__ void fold_tile_row(const GradArgs &a, unsigned tr, si
         const double sum = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
         if(j == 0 && c < (int)nch) {
                 __hip_atomic_store(a.rowsum + (size_t)tr * nch + c, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // row-tiled, bands in each other's reach: the sum into every band's copy of the global array (all eight lanes
+        // of channel c's group hold it; lane j serves bands j, j + 8, ...).  System-scope stores: performed at the
+        // destination, visible to the peers' projection launches through the event recorded behind this launch.
+        if(a.push.n && c < (int)nch) {
+                const size_t slot = (size_t)(a.push.first_tr + tr) * nch + (unsigned)c;
+                for(unsigned b = (unsigned)j; b < a.push.n; b += 8) {
+                        __hip_atomic_store(a.push.dst[b] + slot, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
         }
 }
 
@@ -1545,7 +1574,6 @@ __device__ __forceinline__ float norm_tree_wave(const double *rowsum, unsigned n
 // Row-tiled runs inside one process (j2p_tiled): the two per-iteration exchanges as kernels that READ the other
 // bands' memory directly (peer access over xGMI, or plain device memory when bands share a GPU).
 // ---------------------------------------------------------------------------
-constexpr int kMaxBands = 32;
 struct BandRowsums {
         const double *rowsum[kMaxBands];   // band b's [tile row][channel] level-1 sums (GradArgs::rowsum)
         unsigned first[kMaxBands];         // its first global tile row
@@ -1743,9 +1771,12 @@ __device__ __forceinline__ void sub_load_step_mean(const ChanDev &k, size_t base
         }
 }
 
+// halo_up / halo_down: non-NULL when the strip is the band's first / last block row and a neighbouring band wants its
+// first / last kHalo rows too (ProjArgs::halo_up, halo_down), already offset to the lane's first column
 template <int WS, int HS>
 __device__ __forceinline__ void sub_store_residual(const ChanDev &k, size_t base, unsigned W, const SubTile<WS, HS> &t,
-                                                   const float (&mean_old)[8], const float (&mean_new)[8])
+                                                   const float (&mean_old)[8], const float (&mean_new)[8],
+                                                   float *halo_up = nullptr, float *halo_down = nullptr)
 {
         typedef float vws __attribute__((ext_vector_type(WS)));
 #pragma unroll
@@ -1760,6 +1791,10 @@ __device__ __forceinline__ void sub_store_residual(const ChanDev &k, size_t base
                         }
                         J2P_CHK(k, x_own[1], k.xprev + base + (size_t)(r * HS + sy) * W, 4 * WS, 207);
                         *reinterpret_cast<vws *>(k.xprev + base + (size_t)(r * HS + sy) * W) = o;
+                        // (the strip covers whole block rows of the band: its rows 0, 1 / 8 HS - 2, 8 HS - 1 are the band's)
+                        const int row = r * HS + sy;
+                        if(row < kHalo && halo_up) { *reinterpret_cast<vws *>(halo_up + (size_t)row * W) = o; }
+                        if(row >= 8 * HS - kHalo && halo_down) { *reinterpret_cast<vws *>(halo_down + (size_t)(row - (8 * HS - kHalo)) * W) = o; }
                 }
         }
 }
@@ -1774,9 +1809,16 @@ struct __attribute__((aligned(16))) ProjShared {
         float rqq[64];   // 1/(q*q), correctly rounded
         float rq[64];    // 1/q, correctly rounded   (log only)
         int q_fast;
+        float norm_ws;   // NIP == 2: ||g|| as the workgroup's first wavefront reduced it
 };
 
-template <bool LOG, int WS, int HS, int NT, bool NIP, bool PTR = false>
+// NIP: 0 = ||g|| is read from ProjArgs::norm; otherwise it is reduced here from the level-1 row sums the gradient launch
+// left behind (ProjArgs::norm_rowsums), so that no reduction launch stands between the phases — 1: by EVERY wavefront, its
+// loads in flight together with the strip's rows (small canvases: one memory round trip in front of the arithmetic);
+// 2: by the workgroup's FIRST wavefront, before anything else, and handed to the other three through LDS at the barrier
+// that publishes the quantisation tables anyway (bands of a row-tiled run: up to 1024 row sums, a quarter of the
+// loads and none of the registers of form 1 — the tree's values are dead before the row loads are issued)
+template <bool LOG, int WS, int HS, int NT, int NIP, bool PTR = false>
 __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
 {
         float *const tp = sh.tp;
@@ -1819,7 +1861,13 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
         // six wavefronts per SIMD, 1.3 us per launch at 4096^2, where it is not used)
         float norm;
         WaveTreeRows tree;
-        if constexpr(NIP) { norm_tree_load(a.norm_rowsums, a.norm_rows, a.norm_nch, (unsigned)c, lane, tree); }   // reduced below, behind the row loads
+        if constexpr(NIP == 1) { norm_tree_load(a.norm_rowsums, a.norm_rows, a.norm_nch, (unsigned)c, lane, tree); }   // reduced below, behind the row loads
+        else if constexpr(NIP == 2) {
+                if(wave == 0) {
+                        const float nrm = norm_tree_wave(a.norm_rowsums, a.norm_rows, a.norm_nch, (unsigned)c, lane);
+                        if(lane == 0) { sh.norm_ws = nrm; }
+                }
+        }
         else { norm = a.norm[c]; }
         const unsigned cx = sx * 64 + lane;                           // coefficient column of this lane
         const unsigned cy0 = (a.geo.row0 / hs) + by * 8;              // first coefficient row (global)
@@ -1839,6 +1887,20 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
         // wave-uniform: the whole 64 x 8 strip is inside the canvas and projected
         const bool full = active && WS == 1 && HS == 1 && unit && sx * 64 + 64 <= k.cw && sx * 64 + 64 <= W && cy0 < k.ch &&
                           ly0 + 8 <= a.geo.rows;
+        // band instantiations: strips of the band's first / last block row also store into the neighbours' halo rows
+        // (ProjArgs::halo_up / halo_down).  Wave-uniform pointers; NULL for every other strip.
+        constexpr bool PUSH = NIP == 2;
+        float *push_up = nullptr, *push_down = nullptr;
+        if constexpr(PUSH) {
+                if(ly0 < (unsigned)kHalo) { push_up = a.halo_up[c]; }
+                if(ly0 + 8 * hs + (unsigned)kHalo > a.geo.rows) { push_down = a.halo_down[c]; }
+        }
+        // where band-local canvas row ly of the new iterate goes besides the band's own plane (row start), or NULL
+        auto halo_copy_of = [&](unsigned ly) -> float * {
+                if(push_up && ly < (unsigned)kHalo) { return push_up + (size_t)ly * W; }
+                if(push_down && ly + (unsigned)kHalo >= a.geo.rows && ly < a.geo.rows) { return push_down + (size_t)(ly + kHalo - a.geo.rows) * W; }
+                return nullptr;
+        };
 
         // The common path puts its 24 loads in flight FIRST; the quantisation tables (one more dependent global load,
         // then LDS and a workgroup barrier) are set up while they fly: one memory round trip in front of the
@@ -1855,7 +1917,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                 // whose rows lie >= 64 KiB apart take: there, and only there, the buffer form measures 5 % SLOWER
                 // (16384 x 2048: 116.7 -> 122.9 us; 8192 x 4096, same bytes: 116.4 -> 115.9; 4096^2 62.3 -> 61.2;
                 // 2048^2 22.4 -> 20.8), whatever the order of the 24 loads and at six or seven wavefronts per SIMD
-                // (profiles/r03_buffer_addressing.md)
+                // (profiles/r03_ab_buffer_addressing.jsonl)
 #pragma unroll
                 for(int r = 0; r < 8; r++) {
                         J2P_CHK(k, x_own[0], &k.xcur[base + (size_t)r * W], 4, 209);
@@ -1877,7 +1939,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                         } else { gv[r] = buf_load1<(NT >= 1)>(rg_, lane_off, (unsigned)r * W * 4u); }
                 }
         }
-        if constexpr(NIP) { norm = norm_tree_reduce(tree); }
+        if constexpr(NIP == 1) { norm = norm_tree_reduce(tree); }
         if(threadIdx.x < 64) {
                 const float q = k.q[threadIdx.x];
                 qs[threadIdx.x] = q;
@@ -1889,6 +1951,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                 if(threadIdx.x == 0) { q_fast = all_ok == ~0ull; }
         }
         __syncthreads();
+        if constexpr(NIP == 2) { norm = sh.norm_ws; }
 
         if(!active) { return; }
 
@@ -1945,7 +2008,12 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                         if(inside && ly0 + r < a.geo.rows) {
                                 const ptrdiff_t off = (ptrdiff_t)(ly0 + r) * W + cx;
                                 v[r] = stepped(k, off, a.factor, a.step, norm);
-                                if(!covered) { k.xprev[off] = v[r]; }  // stepped but never projected (SURVEY §7 hard part 5); address checked by stepped()
+                                if(!covered) {
+                                        k.xprev[off] = v[r];           // stepped but never projected (SURVEY §7 hard part 5); address checked by stepped()
+                                        if constexpr(PUSH) {
+                                                if(float *h = halo_copy_of(ly0 + r)) { h[cx] = v[r]; }
+                                        }
+                                }
                         }
                 }
         } else {
@@ -1959,7 +2027,13 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                                         if(x < W && ly < a.geo.rows) {
                                                 const ptrdiff_t off = (ptrdiff_t)ly * W + x;
                                                 const float f = stepped(k, off, a.factor, a.step, norm);
-                                                if(covered) { mean += f; } else { k.xprev[off] = f; }
+                                                if(covered) { mean += f; }
+                                                else {
+                                                        k.xprev[off] = f;
+                                                        if constexpr(PUSH) {
+                                                                if(float *h = halo_copy_of(ly)) { h[x] = f; }
+                                                        }
+                                                }
                                         }
                                 }
                         }
@@ -2015,7 +2089,13 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                         const v2f lo = (df - 0.5f) * q, hi = (df + 0.5f) * q;
                         v2f x = v2f{v[2 * p], v[2 * p + 1]};
                         // x > hi ? hi : (x < lo ? lo : x)  (compute.c:327-329) as the median of the three: lo < hi, neither is
-                        // a zero (q >= 1, d integer), so whichever operand is returned carries the same bits
+                        // a zero (q >= 1, d integer), so whichever operand is returned carries the same bits.
+                        // PRECONDITION: x is not a NaN.  The reference's expression hands a NaN through (both compares are
+                        // false) and the image goes NaN from there; v_med3_f32 would return lo instead.  A NaN can only get
+                        // here from non-finite input planes (the iteration itself produces none from finite state: every
+                        // division is guarded by a norm != 0 test, compute.c:97,158,212), and what the reference makes of
+                        // such input — NaN everywhere after two iterations — is not a result worth reproducing; the parity
+                        // statements are for finite input.
                         x = v2f{__builtin_amdgcn_fmed3f(x.x, lo.x, hi.x), __builtin_amdgcn_fmed3f(x.y, lo.y, hi.y)};
                         v[2 * p] = x.x;
                         v[2 * p + 1] = x.y;
@@ -2069,19 +2149,32 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                         J2P_CHK(k, x_own[1], dst, 32, 212);
                         dst[0] = make_float4(v[0], v[1], v[2], v[3]);
                         dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+                        if constexpr(PUSH) {
+                                if(float *h = halo_copy_of(ly0 + rr)) {
+                                        float4 *hd = reinterpret_cast<float4 *>(h + bx * 8);
+                                        hd[0] = make_float4(v[0], v[1], v[2], v[3]);
+                                        hd[1] = make_float4(v[4], v[5], v[6], v[7]);
+                                }
+                        }
                 }
         } else {
                 // back to lane = coefficient column, then add the new mean onto the residual (compute.c:365,398)
                 transpose8(v, scratch, lane);
                 if(fullsub) {
-                        sub_store_residual<(kSub ? WS : 1), (kSub ? HS : 1)>(k, sub_base, W, tile, mean_old, v);
+                        sub_store_residual<(kSub ? WS : 1), (kSub ? HS : 1)>(k, sub_base, W, tile, mean_old, v,
+                                                                             push_up ? push_up + (size_t)cx * ws : nullptr,
+                                                                             push_down ? push_down + (size_t)cx * ws : nullptr);
                 } else if(full) {
                         // full && resample1: residual (x - mean) + new mean, lane = column again
                         const size_t base = (size_t)ly0 * W + cx;
 #pragma unroll
                         for(int r = 0; r < 8; r++) {
                                 J2P_CHK(k, x_own[1], &k.xprev[base + (size_t)r * W], 4, 213);
-                                k.xprev[base + (size_t)r * W] = (st1[r] - mean_old[r]) + v[r];
+                                const float o = (st1[r] - mean_old[r]) + v[r];
+                                k.xprev[base + (size_t)r * W] = o;
+                                if constexpr(PUSH) {
+                                        if(float *h = halo_copy_of(ly0 + r)) { h[cx] = o; }
+                                }
                         }
                 } else if(covered) {
 #pragma unroll 1
@@ -2093,6 +2186,9 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                                                 float f = stepped(k, off, a.factor, a.step, norm);
                                                 f = f - mean_old[r];
                                                 k.xprev[off] = f + v[r];
+                                                if constexpr(PUSH) {
+                                                        if(float *h = halo_copy_of(ly)) { h[x] = f + v[r]; }
+                                                }
                                         }
                                 }
                         }
@@ -2143,7 +2239,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
 #ifndef J2P_PROJECT_WAVES
 #define J2P_PROJECT_WAVES 0
 #endif
-template <bool LOG, int WS, int HS, int NT = 0, bool NIP = false, bool PTR = false>
+template <bool LOG, int WS, int HS, int NT = 0, int NIP = 0, bool PTR = false>
 __global__ __launch_bounds__(256, (J2P_PROJECT_WAVES && WS == 1 && HS == 1 && !LOG && !NIP ? J2P_PROJECT_WAVES : 1)) void k_project(ProjArgs a)
 {
         __shared__ ProjShared sh;
@@ -2167,9 +2263,9 @@ __global__ __launch_bounds__(256) void k_project_mixed(ProjArgs a)
 {
         __shared__ ProjShared sh;
         const ChanDev &k = a.ch[a.chan_of_z[blockIdx.z]];
-        if(k.ws == 1 && k.hs == 1) { project_strip<LOG, 1, 1, 0, NIP>(a, sh); }
-        else if(k.ws == 2 && k.hs == 2) { project_strip<LOG, 2, 2, 0, NIP>(a, sh); }
-        else { project_strip<LOG, 0, 0, 0, NIP>(a, sh); }
+        if(k.ws == 1 && k.hs == 1) { project_strip<LOG, 1, 1, 0, (NIP ? 1 : 0)>(a, sh); }
+        else if(k.ws == 2 && k.hs == 2) { project_strip<LOG, 2, 2, 0, (NIP ? 1 : 0)>(a, sh); }
+        else { project_strip<LOG, 0, 0, 0, (NIP ? 1 : 0)>(a, sh); }
 }
 
 // ---------------------------------------------------------------------------

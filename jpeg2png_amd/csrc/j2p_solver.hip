@@ -120,6 +120,10 @@ struct j2p_solver {
         bool rowsum_alternate = false;
         double *rowsum_local = nullptr;  // [ntr_local][c]
         double *rowsum_all = nullptr;    // [ntr_global][c]  (== rowsum_local when whole)
+        double *rowsum_all_odd = nullptr;   // band solvers: the global array of odd iterations once the bands are linked
+        bool linked = false;                // j2p_solver_link_bands: neighbours' rows read in place, row sums pushed
+        j2p_band_links links;
+        bool band_nip = true;               // band solvers: ||g|| from the global row sums inside k_project (NIP 2) instead of k_norm_finish
         float *norm = nullptr;           // [c]
         // logging
         double *part_tv = nullptr;       // [ntiles][2]
@@ -517,6 +521,13 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         a.row_ticket = s->fold ? s->tickets : nullptr;
         a.done_ticket = s->tickets + s->ntr_local;
         a.rowsum = (s->rowsum_alternate && (s->iter & 1)) ? s->rowsum_odd : s->rowsum_local;
+        a.push.n = 0;
+        a.push.first_tr = s->first_tr;
+        if(s->linked) {
+                if(part != 0) { return fail(J2P_ESTATE, "linked bands run whole phases (there is no exchange to hide)"); }
+                a.push.n = s->links.npush;
+                for(unsigned b = 0; b < s->links.npush; b++) { a.push.dst[b] = s->links.push[s->iter & 1][b]; }
+        }
         a.norm_out = fold_norm ? s->norm : nullptr;
         a.nch_total = s->nch;
         a.fold_rows = s->ntr_local;
@@ -591,6 +602,44 @@ int do_rowsums(j2p_solver *s)
         return J2P_OK;
 }
 
+// the instantiations of k_project by what the launch needs: NT = non-temporal level (nt_policy), NIP = who reduces
+// ||g|| (0: read from memory, 1: every wavefront, 2: the workgroup's first wavefront — bands), PTR = pointer form of the
+// row loads (rows >= 64 KiB apart)
+template <int NT, int NIP>
+void launch_project_unit_nt(bool ptr, dim3 grid, hipStream_t st, const ProjArgs &a)
+{
+        if(ptr) { hipLaunchKernelGGL((k_project<false, 1, 1, NT, NIP, true>), grid, dim3(256), 0, st, a); }
+        else { hipLaunchKernelGGL((k_project<false, 1, 1, NT, NIP, false>), grid, dim3(256), 0, st, a); }
+}
+void launch_project_unit(int nt, int nip, bool ptr, dim3 grid, hipStream_t st, const ProjArgs &a)
+{
+        if(nip == 2) {
+                switch(nt) {
+                case 0: launch_project_unit_nt<0, 2>(ptr, grid, st, a); break;
+                case 1: launch_project_unit_nt<1, 2>(ptr, grid, st, a); break;
+                case 2: launch_project_unit_nt<2, 2>(ptr, grid, st, a); break;
+                default: launch_project_unit_nt<3, 2>(ptr, grid, st, a); break;
+                }
+        } else {
+                switch(nt) {
+                case 0: launch_project_unit_nt<0, 0>(ptr, grid, st, a); break;
+                case 1: launch_project_unit_nt<1, 0>(ptr, grid, st, a); break;
+                case 2: launch_project_unit_nt<2, 0>(ptr, grid, st, a); break;
+                default: launch_project_unit_nt<3, 0>(ptr, grid, st, a); break;
+                }
+        }
+}
+// every other case by sampling class: logging, subsampled channels, the per-wavefront tree of small canvases
+template <bool LOG, int NIP>
+void launch_project_sampled(unsigned ws, unsigned hs, dim3 grid, hipStream_t st, const ProjArgs &a)
+{
+        if(ws == 1 && hs == 1) { hipLaunchKernelGGL((k_project<LOG, 1, 1, 0, NIP>), grid, dim3(256), 0, st, a); }
+        else if(ws == 2 && hs == 2) { hipLaunchKernelGGL((k_project<LOG, 2, 2, 0, NIP>), grid, dim3(256), 0, st, a); }
+        else if(ws == 2 && hs == 1) { hipLaunchKernelGGL((k_project<LOG, 2, 1, 0, NIP>), grid, dim3(256), 0, st, a); }
+        else if(ws == 1 && hs == 2) { hipLaunchKernelGGL((k_project<LOG, 1, 2, 0, NIP>), grid, dim3(256), 0, st, a); }
+        else { hipLaunchKernelGGL((k_project<LOG, 0, 0, 0, NIP>), grid, dim3(256), 0, st, a); }
+}
+
 // part: 0 = whole phase; J2P_PROJECT_BOUNDARY (1) = norm + the band's first and last block row of every
 // channel (they hold the rows the neighbours need); J2P_PROJECT_INTERIOR (2) = the rest, ends the iteration
 int do_phase_project(j2p_solver *s, bool log, int part = 0)
@@ -604,12 +653,19 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
         if(part != 2 && s->proj_boundary_done) { return fail(J2P_ESTATE, "boundary part of phase_project issued twice"); }
         unsigned P = 1;
         while(P < s->ntr_global) { P <<= 1; }
+        // the global [tile row][channel] sums a band solver finishes ||g|| from: gathered by the caller, or — linked
+        // bands — stored there by every band's gradient launch, even and odd iterations in two arrays
+        const double *global_rows = (s->linked && (s->iter & 1)) ? s->rowsum_all_odd : s->rowsum_all;
+        bool nip2 = false;
         if(part == 2 || s->norm_ready || s->norm_by_project) {
                 // the norm is already there, or every wavefront of k_project reduces the row sums itself
+        } else if(!s->whole && s->band_nip && part == 0 && s->ntr_global <= kWaveTreeMax) {
+                // band solvers: the first wavefront of every workgroup of k_project runs the tree (NIP 2) — no launch
+                nip2 = true;
         } else if(s->fold) {
                 // level 1 came with the gradient launch (band solvers: the caller has gathered all bands' row sums)
                 hipLaunchKernelGGL(k_norm_finish, dim3(s->nch), dim3(256), P * sizeof(double), st,
-                                   (const double *)s->rowsum_all, s->ntr_global, s->nch, s->norm);
+                                   global_rows, s->ntr_global, s->nch, s->norm);
         } else if(s->whole) {
                 // stage as many of the partials at once as the CU's LDS holds (P <= 4096)
                 unsigned stage = 0;                                  // narrow canvases: direct form (4.6 vs 5.4 us at 4096^2)
@@ -621,7 +677,7 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
                                    (const double *)s->part_g2, s->ntx, s->ntr_local, s->nch, s->norm, stage);
         } else {
                 hipLaunchKernelGGL(k_norm_finish, dim3(s->nch), dim3(256), P * sizeof(double), st,
-                                   (const double *)s->rowsum_all, s->ntr_global, s->nch, s->norm);
+                                   global_rows, s->ntr_global, s->nch, s->norm);
         }
         ProjArgs a;
         for(unsigned c = 0; c < s->nch; c++) { a.ch[c] = chan_dev(s, c); }
@@ -632,9 +688,20 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
         a.norm = s->norm;
         a.part_prob = s->part_prob;
         a.strips_per_chan = s->strips_stride;
-        a.norm_rowsums = s->norm_by_project ? s->rowsum_local : nullptr;
+        a.norm_rowsums = nip2 ? global_rows : (s->norm_by_project ? s->rowsum_local : nullptr);
         a.norm_rows = s->ntr_global;
         a.norm_nch = s->nch;
+        const int nip = nip2 ? 2 : (s->norm_by_project ? 1 : 0);
+        for(unsigned c = 0; c < kMaxCh; c++) { a.halo_up[c] = a.halo_down[c] = nullptr; }
+        if(s->linked) {
+                // the band's edge rows of x_{k+1} also go into the neighbours' halo rows of the buffer being written
+                // (only the NIP 2 instantiations store them: a linked band always takes those)
+                if(!nip2) { return fail(J2P_ESTATE, "linked bands: ||g|| must be reduced inside k_project (whole phases, at most %u tile rows, J2P_BAND_NIP not 0)", kWaveTreeMax); }
+                for(unsigned c = 0; c < s->nch; c++) {
+                        a.halo_up[c] = s->links.up_halo[s->cur ^ 1][c];
+                        a.halo_down[c] = s->links.down_halo[s->cur ^ 1][c];
+                }
+        }
         if(part != 1) { mark(s); }
         const bool inwave_nt_off = s->nch > 1 && s->joint_inwave;      // those gradient kernels have no non-temporal form
         auto block_rows = [&](unsigned hs, unsigned z) -> unsigned {
@@ -646,7 +713,7 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
         };
         bool mixed = false;
         for(unsigned c = 1; c < s->nch; c++) { mixed = mixed || s->ch[c].ws != s->ch[0].ws || s->ch[c].hs != s->ch[0].hs; }
-        if(mixed && s->mixed_project && (size_t)s->W * s->rows <= kMixedProjectPixels) {
+        if(mixed && s->mixed_project && nip != 2 && (size_t)s->W * s->rows <= kMixedProjectPixels) {
                 // small canvas, several samplings: one launch for all channels (k_project_mixed)
                 unsigned max_strips = 0;
                 for(unsigned c = 0; c < s->nch; c++) {
@@ -658,7 +725,7 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
                 if(max_strips) {
                         const dim3 grid((max_strips + 3) / 4, 1, s->nch);
                         if(log) { hipLaunchKernelGGL((k_project_mixed<true, false>), grid, dim3(256), 0, st, a); }
-                        else if(s->norm_by_project) { hipLaunchKernelGGL((k_project_mixed<false, true>), grid, dim3(256), 0, st, a); }
+                        else if(nip == 1) { hipLaunchKernelGGL((k_project_mixed<false, true>), grid, dim3(256), 0, st, a); }
                         else { hipLaunchKernelGGL((k_project_mixed<false, false>), grid, dim3(256), 0, st, a); }
 #ifdef J2P_TRACE
                         if(s->trace_on) { s->trace_used += grid.x * grid.z * 4; }
@@ -681,41 +748,25 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
                 if(a.nby[0] == 0) { continue; }
                 const unsigned strips = ((s->W + 64 * ws - 1) / (64 * ws)) * a.nby[0];
                 dim3 grid((strips + 3) / 4, 1, nz);
-        // (g is read non-temporally exactly when the gradient launch wrote it that way; only the 1x1 instantiation
-        // has the register-resident path that carries the hint)
-#define J2P_LAUNCH_PROJECT(WS_, HS_)                                                               \
-        do {                                                                                       \
-                if(log) { hipLaunchKernelGGL((k_project<true, WS_, HS_>), grid, dim3(256), 0, st, a); }  \
-                else if(s->norm_by_project) { hipLaunchKernelGGL((k_project<false, WS_, HS_, 0, true>), grid, dim3(256), 0, st, a); } \
-                else { hipLaunchKernelGGL((k_project<false, WS_, HS_>), grid, dim3(256), 0, st, a); }    \
-        } while(0)
-                // (rows >= 64 KiB apart: the pointer form of the 24 loads, see project_strip)
-                const bool far_rows = (size_t)s->W * sizeof(float) >= 65536;
-                if(ws == 1 && hs == 1 && s->nt >= 1 && !inwave_nt_off && !log && !s->norm_by_project) {
-                        if(far_rows) {
-                                if(s->nt >= 3) { hipLaunchKernelGGL((k_project<false, 1, 1, 3, false, true>), grid, dim3(256), 0, st, a); }
-                                else if(s->nt == 2) { hipLaunchKernelGGL((k_project<false, 1, 1, 2, false, true>), grid, dim3(256), 0, st, a); }
-                                else { hipLaunchKernelGGL((k_project<false, 1, 1, 1, false, true>), grid, dim3(256), 0, st, a); }
-                        }
-                        else if(s->nt >= 3) { hipLaunchKernelGGL((k_project<false, 1, 1, 3>), grid, dim3(256), 0, st, a); }
-                        else if(s->nt == 2) { hipLaunchKernelGGL((k_project<false, 1, 1, 2>), grid, dim3(256), 0, st, a); }
-                        else { hipLaunchKernelGGL((k_project<false, 1, 1, 1>), grid, dim3(256), 0, st, a); }
+                if(ws == 1 && hs == 1 && !log && nip != 1) {
+                        // the 1x1 instantiations: g is read non-temporally exactly when the gradient launch wrote it that
+                        // way (nt levels, nt_policy); rows >= 64 KiB apart take the pointer form of the 24 loads (see
+                        // project_strip); bands reduce ||g|| themselves (NIP 2)
+                        const bool far_rows = (size_t)s->W * sizeof(float) >= 65536;
+                        const int nt = inwave_nt_off ? 0 : s->nt;
+                        launch_project_unit(nt, nip, far_rows, grid, st, a);
                 }
-                else if(ws == 1 && hs == 1 && far_rows && !log && !s->norm_by_project) {
-                        hipLaunchKernelGGL((k_project<false, 1, 1, 0, false, true>), grid, dim3(256), 0, st, a);
-                }
-                else if(ws == 1 && hs == 1) { J2P_LAUNCH_PROJECT(1, 1); }
-                else if(ws == 2 && hs == 2) { J2P_LAUNCH_PROJECT(2, 2); }
-                else if(ws == 2 && hs == 1) { J2P_LAUNCH_PROJECT(2, 1); }
-                else if(ws == 1 && hs == 2) { J2P_LAUNCH_PROJECT(1, 2); }
-                else { J2P_LAUNCH_PROJECT(0, 0); }
+                else if(log && nip == 2) { launch_project_sampled<true, 2>(ws, hs, grid, st, a); }
+                else if(log) { launch_project_sampled<true, 0>(ws, hs, grid, st, a); }
+                else if(nip == 2) { launch_project_sampled<false, 2>(ws, hs, grid, st, a); }
+                else if(nip == 1) { launch_project_sampled<false, 1>(ws, hs, grid, st, a); }
+                else { launch_project_sampled<false, 0>(ws, hs, grid, st, a); }
 #ifdef J2P_TRACE
                 if(s->trace_on) {
                         s->trace_used += grid.x * grid.z * 4;
                         a.geo.trace_base = s->trace_used;       // the next sampling class's launch
                 }
 #endif
-#undef J2P_LAUNCH_PROJECT
         }
         }
         if(part != 1) { mark(s); }
@@ -823,6 +874,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         }
         if(H > (unsigned)kMaxTileRows * kTY) { return fail(J2P_EINVAL, "canvas height %u exceeds %u", H, kMaxTileRows * kTY); }   // (shorter tile rows: only far below)
         bool whole = band.row_begin == 0 && (band.row_end == 0 || band.row_end >= H);
+        if(whole && (band_local_arrays & J2P_BAND_EVEN_IF_WHOLE) && band.row_end >= H) { whole = false; band.row_end = H; }
         unsigned row0 = whole ? 0 : band.row_begin, row1 = whole ? H : band.row_end;
         if(!whole) {
                 if(row0 >= row1 || row1 > H) { return fail(J2P_EINVAL, "bad band [%u,%u) for canvas height %u", row0, row1, H); }
@@ -865,7 +917,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 s->fold = true;
                 s->norm_in_project = true;
         }
-        s->band_local = !whole && band_local_arrays != 0;
+        s->band_local = !whole && (band_local_arrays & J2P_BAND_LOCAL_ARRAYS) != 0;
         s->weight = weight;
         s->iterations = iterations;
         {
@@ -876,6 +928,9 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 // ... and: one projection launch per sampling class also on small canvases (J2P_OPT_MIXED_PROJECT)
                 env = getenv("J2P_MIXED_PROJECT");
                 if(env) { s->mixed_project = atoi(env) != 0; }
+                // ... and (A/B timing): band solvers finish ||g|| with a k_norm_finish launch instead of inside k_project
+                env = getenv("J2P_BAND_NIP");
+                if(env) { s->band_nip = atoi(env) != 0; }
         }
         int rc = J2P_OK;
 #define CREATE_TRY(expr)                                                                           \
@@ -1005,6 +1060,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 if(whole) { s->rowsum_all = s->rowsum_local; }
                 else {
                         carve.take(s->rowsum_all, (size_t)s->ntr_global * nchannel);
+                        carve.take(s->rowsum_all_odd, (size_t)s->ntr_global * nchannel);
                         carve.take(s->rowsum_odd, (size_t)s->ntr_local * nchannel);
                 }
                 carve.take(s->norm, kMaxCh);
@@ -1108,7 +1164,7 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
         if(s->grad_done || s->interior_done) { return fail(J2P_ESTATE, "options change between iterations only"); }
         switch(option) {
         case J2P_OPT_NORM_FOLD:
-                if(s->rowsum_alternate && !value) { return fail(J2P_ESTATE, "alternating row sums need the folded norm reduction"); }
+                if((s->rowsum_alternate || s->linked) && !value) { return fail(J2P_ESTATE, "alternating / pushed row sums need the folded norm reduction"); }
                 s->fold = value != 0;
                 break;
         case J2P_OPT_JOINT_INWAVE:
@@ -1409,9 +1465,54 @@ int j2p_solver_alternate_rowsums(j2p_solver *s, const double *buffers[2])
         if(!s || !buffers) { return fail(J2P_EINVAL, "NULL argument"); }
         if(s->whole || !s->rowsum_odd) { return fail(J2P_ESTATE, "alternating row sums are for band solvers"); }
         if(!s->fold) { return fail(J2P_ESTATE, "alternating row sums need the folded norm reduction"); }
+        if(s->linked) { return fail(J2P_ESTATE, "alternating row sums: this solver's bands are linked (its sums go to the global arrays)"); }
         s->rowsum_alternate = true;
         buffers[0] = s->rowsum_local;
         buffers[1] = s->rowsum_odd;
+        return J2P_OK;
+}
+
+int j2p_solver_global_rowsums(j2p_solver *s, double *arrays[2])
+{
+        if(!s || !arrays) { return fail(J2P_EINVAL, "NULL argument"); }
+        if(s->whole || !s->rowsum_all_odd) { return fail(J2P_ESTATE, "global row sums: band solvers only"); }
+        arrays[0] = s->rowsum_all;
+        arrays[1] = s->rowsum_all_odd;
+        return J2P_OK;
+}
+
+int j2p_solver_link_bands(j2p_solver *s, const j2p_band_links *links)
+{
+        if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        if(s->grad_done || s->interior_done) { return fail(J2P_ESTATE, "bands are linked between iterations only"); }
+        if(!links) {
+                s->linked = false;
+                return J2P_OK;
+        }
+        if(s->whole) { return fail(J2P_ESTATE, "link_bands: band solvers only"); }
+        if(!s->fold) { return fail(J2P_ESTATE, "link_bands needs the folded norm reduction (the row sums leave from inside k_gradient)"); }
+        if(s->rowsum_alternate) { return fail(J2P_ESTATE, "link_bands: this solver's row sums already alternate for norm_from_bands"); }
+        if(links->npush == 0 || links->npush > (unsigned)kMaxBands) { return fail(J2P_EINVAL, "link_bands: 1..%d bands to push to", kMaxBands); }
+        bool own[2] = {false, false};
+        for(int par = 0; par < 2; par++) {
+                for(unsigned b = 0; b < links->npush; b++) {
+                        if(!links->push[par][b]) { return fail(J2P_EINVAL, "link_bands: push target %u is NULL", b); }
+                        own[par] = own[par] || links->push[par][b] == (par ? s->rowsum_all_odd : s->rowsum_all);
+                }
+        }
+        if(!own[0] || !own[1]) { return fail(J2P_EINVAL, "link_bands: the push lists must contain this solver's own arrays"); }
+        for(unsigned c = 0; c < s->nch; c++) {
+                // a neighbour is given for both buffers or for neither; the band at the top / bottom of the canvas has none
+                const bool up = links->up_halo[0][c] != nullptr, down = links->down_halo[0][c] != nullptr;
+                if(up != (links->up_halo[1][c] != nullptr) || down != (links->down_halo[1][c] != nullptr)) {
+                        return fail(J2P_EINVAL, "link_bands: channel %u: a neighbour's rows are needed for both x buffers", c);
+                }
+                if(up != (s->row0 > 0) || down != (s->row0 + s->rows < s->H)) {
+                        return fail(J2P_EINVAL, "link_bands: channel %u: neighbours do not match the band's place in the canvas", c);
+                }
+        }
+        s->links = *links;
+        s->linked = true;
         return J2P_OK;
 }
 

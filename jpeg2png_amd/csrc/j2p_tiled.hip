@@ -4,30 +4,36 @@
 // DCT block and no gradient tile straddles two bands); band i is a j2p_solver on devices[i] — device ids may
 // repeat, several bands then share a GPU.  One host thread per band issues that band's launches, so the eight
 // GPUs of a node are fed in parallel and there is no interpreter in the iteration loop.  Per iteration the bands
-// meet twice (reference loop compute.c:427-453):
+// meet twice (reference loop compute.c:427-453): ||g|| (compute.c:200-207) needs every band's
+// gradient, and the next gradient reaches 2 rows into the neighbouring bands (TGV2, compute.c:137-143,165-183).
+// Three ways of carrying those two exchanges — same arithmetic, same bits, chosen at create time
+// (J2P_TILED_EXCHANGE=direct|copy|rccl; default: direct where every GPU can write every other's memory, else rccl):
 //
-//   1. ||g|| (compute.c:200-207) needs every band's gradient: each band records an event behind its gradient
-//      phase (whose last wavefronts have already reduced the band's 16-row tile rows).  ONE band — the root —
-//      waits for the other bands' events, reduces ALL bands' row sums — read in place over xGMI — with the same
-//      fixed tree over the same global array as the single-GPU solver, and stores the float norm into every band's
-//      own norm word; the other bands wait for that ONE event.  2 (N - 1) cross-device dependencies per iteration
-//      instead of N (N - 1), the same arithmetic: the result does not depend on the number of bands.
-//      (J2P_TILED_NORM=all: every band reduces for itself, as in round 2 — one hop less, N - 1 waits per band.)
-//   2. the next gradient reaches 2 rows into the neighbouring bands (TGV2, compute.c:137-143,165-183): a band
-//      records an event behind its projection and the neighbours pull its two edge rows into their halo rows in
-//      front of their next gradient phase (one small copy kernel).  A band's iteration is then four launches
-//      (copy, gradient, [norm,] projection).  The split schedule — the projection does the band's first and last
-//      block row first, the neighbours pull after the INTERIOR of their next gradient phase and run the two edge
-//      segments last, so that the copy and the cross-GPU wait hide behind compute — remains behind J2P_TILED_SPLIT=1:
-//      measured on a band that has a GPU to itself its three extra launches (a launch boundary and a nearly empty
-//      chip each) cost more than the wait they hide: 292 against 276 us per iteration, 245 for the same rows solved
-//      whole (profiles/r03_band_alone.jsonl).
+//   direct  The exchanges ride on the two phase kernels; a band's iteration is TWO launches and all traffic between
+//           GPUs is posted writes (j2p_solver_link_bands).  k_gradient's last-arriving wavefront of every 16-row tile
+//           row stores that row's sum of g^2 into EVERY band's copy of the global array; k_project reduces ||g|| from
+//           its own band's copy (the same fixed tree over the same global array as the single-GPU solver, so the
+//           result does not depend on the number of bands) and stores the band's first / last two rows of the new
+//           iterate also into the neighbours' halo rows.  Ordering by HIP events only: gradient(k) waits for the
+//           neighbours' projection(k - 1); projection(k) waits for EVERY band's gradient(k) — two cross-stream waits
+//           per band and iteration, at most two sequential cross-device hops.
+//   copy    Round 3's schedule, kept as the cross-check of `direct` on real multi-GPU hardware (bench.py --gpus N times
+//           both and compares their results): the neighbours' edge rows are PULLED by a small copy kernel in front of
+//           the gradient launch, and ONE band — the root — waits for the others' gradient events, reduces all bands'
+//           row sums (read in place) and stores the float norm into every band's norm word; the others wait for
+//           that event (J2P_TILED_NORM=all: every band reduces for itself).  Four launches per band and iteration, three
+//           sequential hops.  Also what canvases taller than 16384 rows use (k_project's in-kernel tree holds 1024 rows).
+//   rccl    GPUs without peer access, or on request: ncclAllGather of the bands' row sums between the phases and one
+//           ncclGroupStart/End of ncclSend/ncclRecv for the 2 + 2 edge rows behind the projection, on the band's own
+//           stream, one communicator per band (ncclCommInitAll); librccl is dlopen()ed, so the library loads and runs
+//           without it.  What north_star names.
 //
-// Ordering between GPUs is by HIP events only (kernel-boundary visibility); no flag is polled on a device.
 // Host side: a band thread that needs another band's event sleeps on a condition variable until that event has
 // been RECORDED (hipStreamWaitEvent on an event not yet recorded would be a no-op); it never waits for the GPU.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <sys/resource.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <atomic>
 #include <condition_variable>
@@ -44,22 +50,93 @@
 namespace {
 
 constexpr unsigned kLogCols = 2 + J2P_MAX_CHANNELS;
+constexpr unsigned kTreeRowsInProject = 1024;   // tile rows k_project's in-kernel tree handles (kWaveTreeMax)
+
+enum Exchange { kDirect = 0, kCopy = 1, kRccl = 2 };
+const char *const kExchangeName[3] = {"direct", "copy", "rccl"};
+
+// ---------------------------------------------------------------------------------------------------------------
+// librccl through dlopen: the C host reaches RCCL without linking against it (the library must load on hosts that
+// have none), and uses the copy the process already has (torch's bundled one under Python) when there is one.
+// Types as in rccl.h: ncclComm_t is a pointer, ncclResult_t 0 = success, ncclFloat32 = 7, ncclFloat64 = 8.
+// ---------------------------------------------------------------------------------------------------------------
+struct Rccl {
+        void *handle = nullptr;
+        int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+        int (*CommDestroy)(void *comm) = nullptr;
+        int (*AllGather)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t st) = nullptr;
+        int (*Broadcast)(const void *send, void *recv, size_t count, int dtype, int root, void *comm, hipStream_t st) = nullptr;
+        int (*Send)(const void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t st) = nullptr;
+        int (*Recv)(void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t st) = nullptr;
+        int (*GroupStart)() = nullptr;
+        int (*GroupEnd)() = nullptr;
+        const char *(*GetErrorString)(int) = nullptr;
+        char why[256] = "";
+};
+constexpr int kNcclFloat32 = 7, kNcclFloat64 = 8;
+
+Rccl *rccl_load()
+{
+        static std::mutex lock;
+        static Rccl *lib = nullptr;
+        static bool tried = false;
+        std::lock_guard<std::mutex> g(lock);
+        if(tried) { return lib; }
+        tried = true;
+        Rccl *r = new(std::nothrow) Rccl();
+        if(!r) { return nullptr; }
+        const char *env = getenv("J2P_RCCL_LIBRARY");
+        const char *names[] = {env && *env ? env : nullptr, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+        // a copy already in the process first (RTLD_NOLOAD), then by name
+        for(int pass = 0; pass < 2 && !r->handle; pass++) {
+                for(const char *n : names) {
+                        if(!n) { continue; }
+                        r->handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                        if(r->handle) { break; }
+                }
+        }
+        if(!r->handle) {
+                snprintf(r->why, sizeof(r->why), "librccl not found (%s)", dlerror() ? "dlopen failed; J2P_RCCL_LIBRARY names another" : "no such library");
+                lib = r;
+                return lib;
+        }
+#define RCCL_SYM(field, name)                                                                      \
+        do {                                                                                       \
+                *reinterpret_cast<void **>(&r->field) = dlsym(r->handle, name);                    \
+                if(!r->field && !r->why[0]) { snprintf(r->why, sizeof(r->why), "librccl lacks %s", name); } \
+        } while(0)
+        RCCL_SYM(CommInitAll, "ncclCommInitAll");
+        RCCL_SYM(CommDestroy, "ncclCommDestroy");
+        RCCL_SYM(AllGather, "ncclAllGather");
+        RCCL_SYM(Broadcast, "ncclBroadcast");
+        RCCL_SYM(Send, "ncclSend");
+        RCCL_SYM(Recv, "ncclRecv");
+        RCCL_SYM(GroupStart, "ncclGroupStart");
+        RCCL_SYM(GroupEnd, "ncclGroupEnd");
+        RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RCCL_SYM
+        lib = r;
+        return lib;
+}
+bool rccl_usable(const Rccl *r) { return r && r->handle && !r->why[0]; }
 
 struct Band {
         int device = 0;
         j2p_solver *solver = nullptr;
         hipStream_t stream = nullptr;
         unsigned row0 = 0, row1 = 0;
-        bool split = false;                    // long enough for the two-part phases
         hipEvent_t ev_grad[2] = {nullptr, nullptr};    // behind the gradient phase of iteration it (slot it & 1)
-        hipEvent_t ev_edge[2] = {nullptr, nullptr};    // behind the projection of the band's first/last block rows
-        hipEvent_t ev_norm[2] = {nullptr, nullptr};    // root band only: behind the norm of iteration it
+        hipEvent_t ev_edge[2] = {nullptr, nullptr};    // behind the projection of iteration it
+        hipEvent_t ev_norm[2] = {nullptr, nullptr};    // `copy`, root band only: behind the norm of iteration it
         // iterations whose event has been recorded (guarded by j2p_tiled::seq_lock)
         uint64_t grad_recorded = 0, edge_recorded = 0, norm_recorded = 0;
         j2p_exchange rows[2];                  // halo / edge row addresses of x buffer 0 and 1
-        const double *rowsum[2] = {nullptr, nullptr};   // level-1 sums of even / odd iterations
+        const double *rowsum[2] = {nullptr, nullptr};   // `copy`: level-1 sums of even / odd iterations
+        double *global_rows[2] = {nullptr, nullptr};    // the band's copies of the global [tile row][channel] array
+        double *rowsum_local = nullptr;        // `rccl`: what the band contributes to the all-gather
         float *norm = nullptr;                 // the band solver's norm word(s), [channel]
         unsigned first_tr = 0, ntr = 0;
+        void *comm = nullptr;                  // `rccl`: this band's communicator (rank = band index)
         double *log_dev = nullptr;             // the band's {tv, tv2, prob[3]} of the iteration just finished
         double *log_host = nullptr;            // pinned: [chunk][kLogCols]
         unsigned log_cap = 0;
@@ -79,9 +156,13 @@ struct j2p_tiled {
         double carried[J2P_MAX_CHANNELS] = {0., 0., 0.};
         bool carried_valid = true;             // false after iterations run without logging (their prob sums were not kept)
         bool logging = false;                  // the band solvers currently run their logging kernels
-        bool norm_by_root = true;              // one band reduces ||g|| for all (default); false: every band for itself
-        bool want_split = false;               // two-part phases (interior / edges) on bands tall enough (J2P_TILED_SPLIT=1)
+        Exchange exchange = kDirect;
+        bool threaded = false;                 // band threads exist (every run but the plain one-band one)
+        bool norm_by_root = true;              // `copy`: one band reduces ||g|| for all (default); false: every band for itself
+        bool self_neighbours = false;          // test hook (J2P_TILED_SELF_NEIGHBOURS=1, one band, rccl): the band exchanges with itself
+        bool equal_counts = true;              // `rccl`: every band has as many tile rows (one ncclAllGather; else grouped broadcasts)
         unsigned root = 0;
+        Rccl *rccl = nullptr;
         // command hand-over to the band threads
         std::mutex lock;
         std::condition_variable wake, done;
@@ -107,6 +188,11 @@ namespace {
         do {                                                                                       \
                 hipError_t e_ = (expr);                                                            \
                 if(e_ != hipSuccess) { return j2p_fail(J2P_EDEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); } \
+        } while(0)
+#define BAND_NCCL(t, expr)                                                                         \
+        do {                                                                                       \
+                int e_ = (expr);                                                                   \
+                if(e_ != 0) { return j2p_fail(J2P_EDEVICE, "%s failed: %s", #expr, (t)->rccl->GetErrorString(e_)); } \
         } while(0)
 
 enum Which { kGrad, kEdge, kNorm };
@@ -139,7 +225,7 @@ int wait_for(j2p_tiled *t, Band *me, Band *p, Which w, uint64_t it)
         return J2P_OK;
 }
 
-// the neighbours' edge rows of the iterate produced by iteration `it` into this band's halo rows
+// `copy`: the neighbours' edge rows of the iterate produced by iteration `it` into this band's halo rows
 int pull_halos(j2p_tiled *t, unsigned b, uint64_t it)
 {
         Band *me = t->bands[b];
@@ -158,11 +244,56 @@ int pull_halos(j2p_tiled *t, unsigned b, uint64_t it)
         return j2p_solver_copy_rows(me->solver, n, dst, src, me->rows[buf].halo_floats);
 }
 
+// `rccl`: every band's row sums of this iteration into every band's global array (between the two phases)
+int rccl_gather_rowsums(j2p_tiled *t, unsigned b)
+{
+        Band *me = t->bands[b];
+        const Rccl *r = t->rccl;
+        if(t->equal_counts) {
+                BAND_NCCL(t, r->AllGather(me->rowsum_local, me->global_rows[0], (size_t)me->ntr * t->nch, kNcclFloat64, me->comm, me->stream));
+                return J2P_OK;
+        }
+        // bands of different heights: one broadcast per band, grouped into one launch
+        BAND_NCCL(t, r->GroupStart());
+        for(unsigned p = 0; p < t->nband; p++) {
+                const Band *pb = t->bands[p];
+                BAND_NCCL(t, r->Broadcast(me->rowsum_local, me->global_rows[0] + (size_t)pb->first_tr * t->nch, (size_t)pb->ntr * t->nch,
+                                          kNcclFloat64, (int)p, me->comm, me->stream));
+        }
+        BAND_NCCL(t, r->GroupEnd());
+        return J2P_OK;
+}
+
+// `rccl`: the band's edge rows of the iterate produced by iteration `it` to the neighbours, theirs into its halo rows
+int rccl_exchange_halos(j2p_tiled *t, unsigned b, uint64_t it)
+{
+        Band *me = t->bands[b];
+        const Rccl *r = t->rccl;
+        int up = b > 0 ? (int)b - 1 : -1, down = b + 1 < t->nband ? (int)b + 1 : -1;
+        if(t->self_neighbours) { up = down = (int)b; }
+        if(up < 0 && down < 0) { return J2P_OK; }
+        const j2p_exchange &e = me->rows[(it + 1) & 1];
+        BAND_NCCL(t, r->GroupStart());
+        for(unsigned c = 0; c < t->nch; c++) {
+                if(up >= 0) {
+                        BAND_NCCL(t, r->Send(e.send_top[c], e.halo_floats, kNcclFloat32, up, me->comm, me->stream));
+                        BAND_NCCL(t, r->Recv(e.recv_top[c], e.halo_floats, kNcclFloat32, up, me->comm, me->stream));
+                }
+                if(down >= 0) {
+                        BAND_NCCL(t, r->Send(e.send_bottom[c], e.halo_floats, kNcclFloat32, down, me->comm, me->stream));
+                        BAND_NCCL(t, r->Recv(e.recv_bottom[c], e.halo_floats, kNcclFloat32, down, me->comm, me->stream));
+                }
+        }
+        BAND_NCCL(t, r->GroupEnd());
+        return J2P_OK;
+}
+
 int band_iterations(j2p_tiled *t, unsigned b, unsigned n, bool log)
 {
         Band *me = t->bands[b];
         BAND_HIP(hipSetDevice(me->device));
-        // a band may run ahead of the others by up to one gradient phase, so the row sums alternate between two
+        Band *up = b > 0 ? t->bands[b - 1] : nullptr, *down = b + 1 < t->nband ? t->bands[b + 1] : nullptr;
+        // `copy`: a band may run ahead of the others by up to one gradient phase, so the row sums alternate between two
         // buffers: iteration it + 2 overwrites those of iteration it only after every reader's norm(it) has run
         const double *rowsums[2][32];
         unsigned first[32], count[32];
@@ -178,43 +309,55 @@ int band_iterations(j2p_tiled *t, unsigned b, unsigned n, bool log)
         Band *root = t->bands[t->root];
         for(unsigned i = 0; i < n; i++) {
                 const uint64_t it = t->iter + i;
-                // ---- phase A.  Default: the neighbours' rows first, then ONE gradient launch.  Split schedule
-                // (J2P_TILED_SPLIT=1): the interior segments first, the rows and the two edge segments behind them ----
-                if(me->split) {
-                        BAND_TRY(j2p_solver_phase_gradient_part(me->solver, J2P_GRADIENT_INTERIOR, nullptr));
-                        if(it > 0) { BAND_TRY(pull_halos(t, b, it - 1)); }
-                        BAND_TRY(j2p_solver_phase_gradient_part(me->solver, J2P_GRADIENT_EDGES, nullptr));
-                        BAND_TRY(j2p_solver_phase_rowsums(me->solver));
-                } else {
-                        if(it > 0) { BAND_TRY(pull_halos(t, b, it - 1)); }
+                switch(t->exchange) {
+                case kDirect:
+                        // ---- phase A behind the neighbours' projection of the previous iteration (their edge rows are
+                        // in this band's halo rows when that launch has finished) ----
+                        if(it > 0) {
+                                if(up) { BAND_TRY(wait_for(t, me, up, kEdge, it - 1)); }
+                                if(down) { BAND_TRY(wait_for(t, me, down, kEdge, it - 1)); }
+                        }
                         BAND_TRY(j2p_solver_phase_gradient(me->solver));
-                }
-                BAND_TRY(record(t, me, kGrad, it));
-                // ---- the global norm: every band's row sums, one fixed tree ----
-                if(!by_root) {
+                        BAND_TRY(record(t, me, kGrad, it));
+                        // ---- phase B behind EVERY band's gradient launch (their row sums are in this band's global
+                        // array; nobody still reads the halo rows this band's projection is about to overwrite) ----
                         for(unsigned p = 0; p < t->nband; p++) {
                                 if(p != b) { BAND_TRY(wait_for(t, me, t->bands[p], kGrad, it)); }
                         }
-                        BAND_TRY(j2p_solver_norm_from_bands(me->solver, t->nband, rowsums[it & 1], first, count, 0, nullptr));
-                } else if(me == root) {
-                        for(unsigned p = 0; p < t->nband; p++) {
-                                if(p != b) { BAND_TRY(wait_for(t, me, t->bands[p], kGrad, it)); }
-                        }
-                        // ... and the result goes into every band's own norm word (peer stores)
-                        BAND_TRY(j2p_solver_norm_from_bands(me->solver, t->nband, rowsums[it & 1], first, count, t->nband, norm_out));
-                        BAND_TRY(record(t, me, kNorm, it));
-                } else {
-                        BAND_TRY(wait_for(t, me, root, kNorm, it));
-                        BAND_TRY(j2p_solver_norm_external(me->solver));
-                }
-                // ---- phase B (split schedule: the edge block rows, which the neighbours pull, first) ----
-                if(me->split) {
-                        BAND_TRY(j2p_solver_phase_project_part(me->solver, J2P_PROJECT_BOUNDARY));
-                        BAND_TRY(record(t, me, kEdge, it));
-                        BAND_TRY(j2p_solver_phase_project_part(me->solver, J2P_PROJECT_INTERIOR));
-                } else {
                         BAND_TRY(j2p_solver_phase_project(me->solver));
                         BAND_TRY(record(t, me, kEdge, it));
+                        break;
+                case kCopy:
+                        if(it > 0) { BAND_TRY(pull_halos(t, b, it - 1)); }
+                        BAND_TRY(j2p_solver_phase_gradient(me->solver));
+                        BAND_TRY(record(t, me, kGrad, it));
+                        // ---- the global norm: every band's row sums, one fixed tree ----
+                        if(!by_root) {
+                                for(unsigned p = 0; p < t->nband; p++) {
+                                        if(p != b) { BAND_TRY(wait_for(t, me, t->bands[p], kGrad, it)); }
+                                }
+                                BAND_TRY(j2p_solver_norm_from_bands(me->solver, t->nband, rowsums[it & 1], first, count, 0, nullptr));
+                        } else if(me == root) {
+                                for(unsigned p = 0; p < t->nband; p++) {
+                                        if(p != b) { BAND_TRY(wait_for(t, me, t->bands[p], kGrad, it)); }
+                                }
+                                // ... and the result goes into every band's own norm word (peer stores)
+                                BAND_TRY(j2p_solver_norm_from_bands(me->solver, t->nband, rowsums[it & 1], first, count, t->nband, norm_out));
+                                BAND_TRY(record(t, me, kNorm, it));
+                        } else {
+                                BAND_TRY(wait_for(t, me, root, kNorm, it));
+                                BAND_TRY(j2p_solver_norm_external(me->solver));
+                        }
+                        BAND_TRY(j2p_solver_phase_project(me->solver));
+                        BAND_TRY(record(t, me, kEdge, it));
+                        break;
+                case kRccl:
+                        // everything in the band's own stream: gradient, all-gather, projection, send/recv of the edge rows
+                        BAND_TRY(j2p_solver_phase_gradient(me->solver));
+                        BAND_TRY(rccl_gather_rowsums(t, b));
+                        BAND_TRY(j2p_solver_phase_project(me->solver));
+                        BAND_TRY(rccl_exchange_halos(t, b, it));
+                        break;
                 }
                 if(log) {
                         BAND_HIP(hipMemcpyAsync(me->log_host + (size_t)i * kLogCols, me->log_dev, kLogCols * sizeof(double),
@@ -267,6 +410,50 @@ void band_main(j2p_tiled *t, unsigned b)
 
 unsigned gcd_u(unsigned a, unsigned b) { return b ? gcd_u(b, a % b) : a; }
 
+// can every band's GPU write every other band's memory?  (same device: yes)
+bool peers_reachable(unsigned nband, const int devices[], char *why, size_t why_len)
+{
+        for(unsigned a = 0; a < nband; a++) {
+                for(unsigned b = 0; b < nband; b++) {
+                        if(devices[a] == devices[b]) { continue; }
+                        int can = 0;
+                        if(hipDeviceCanAccessPeer(&can, devices[a], devices[b]) != hipSuccess || !can) {
+                                (void)hipGetLastError();
+                                snprintf(why, why_len, "device %d cannot access device %d's memory (no peer access)", devices[a], devices[b]);
+                                return false;
+                        }
+                }
+        }
+        return true;
+}
+
+int enable_peer_access(unsigned nband, const int devices[])
+{
+        for(unsigned a = 0; a < nband; a++) {
+                for(unsigned b = 0; b < nband; b++) {
+                        const int da = devices[a], db = devices[b];
+                        if(da == db) { continue; }
+                        if(hipSetDevice(da) != hipSuccess) { return j2p_fail(J2P_EDEVICE, "hipSetDevice(%d) failed", da); }
+                        const hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+                        (void)hipGetLastError();
+                        if(e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                                return j2p_fail(J2P_EDEVICE, "hipDeviceEnablePeerAccess(%d -> %d): %s", da, db, hipGetErrorString(e));
+                        }
+                }
+        }
+        return J2P_OK;
+}
+
+bool devices_distinct(unsigned nband, const int devices[])
+{
+        for(unsigned a = 0; a < nband; a++) {
+                for(unsigned b = a + 1; b < nband; b++) {
+                        if(devices[a] == devices[b]) { return false; }
+                }
+        }
+        return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -284,6 +471,11 @@ void j2p_tiled_destroy(j2p_tiled *t)
         }
         int prev = -1;
         (void)hipGetDevice(&prev);
+        for(Band *b : t->bands) {
+                (void)hipSetDevice(b->device);
+                if(b->stream) { (void)hipStreamSynchronize(b->stream); }
+                if(b->comm && t->rccl) { (void)t->rccl->CommDestroy(b->comm); }
+        }
         for(Band *b : t->bands) {
                 (void)hipSetDevice(b->device);
                 if(b->solver) { j2p_solver_destroy(b->solver); }        // synchronises the band's stream first
@@ -341,36 +533,53 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
         t->H = H;
         t->weight = weight;
         for(unsigned c = 0; c < nchannel; c++) { t->pweight[c] = pweight[c]; }
-        {
-                // who reduces ||g||: the root band for all (default), or every band for itself (round 2's schedule)
-                const char *env = getenv("J2P_TILED_NORM");
-                t->norm_by_root = !(env && strcmp(env, "all") == 0);
-                t->root = 0;
-                env = getenv("J2P_TILED_SPLIT");
-                if(env) { t->want_split = atoi(env) != 0; }
-        }
         int prev = -1;
         (void)hipGetDevice(&prev);
         int rc = J2P_OK;
-        // every band reads every other band's row sums and its neighbours' edge rows in place: peer access first,
-        // so that every allocation the band solvers make below is mapped for the peers from the start
-        for(unsigned a = 0; a < nband && rc == J2P_OK; a++) {
-                for(unsigned b = 0; b < nband && rc == J2P_OK; b++) {
-                        const int da = devices[a], db = devices[b];
-                        if(da == db) { continue; }
-                        int can = 0;
-                        if(hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can) {
-                                rc = j2p_fail(J2P_EDEVICE, "device %d cannot access device %d's memory (no peer access)", da, db);
-                                break;
+        // ---- how the bands exchange (see the head of this file) ----
+        {
+                const char *env = getenv("J2P_TILED_NORM");
+                t->norm_by_root = !(env && strcmp(env, "all") == 0);
+                t->root = 0;
+                env = getenv("J2P_TILED_SELF_NEIGHBOURS");
+                t->self_neighbours = nband == 1 && env && atoi(env) != 0;
+                env = getenv("J2P_TILED_EXCHANGE");
+                int want = -1;
+                if(env && *env) {
+                        for(int k = 0; k < 3; k++) { if(strcmp(env, kExchangeName[k]) == 0) { want = k; } }
+                        if(want < 0) { rc = j2p_fail(J2P_EINVAL, "J2P_TILED_EXCHANGE=%s: direct, copy or rccl", env); }
+                }
+                char why[200] = "";
+                const bool reach = peers_reachable(nband, devices, why, sizeof(why));
+                const unsigned rows_of_tiles = (H + J2P_TILE_ROWS - 1) / J2P_TILE_ROWS;
+                if(rc == J2P_OK) {
+                        if(want == kRccl || (want < 0 && !reach)) {
+                                // one communicator per band: RCCL wants a GPU per rank
+                                Rccl *r = rccl_load();
+                                if(!rccl_usable(r)) {
+                                        rc = j2p_fail(J2P_EDEVICE, "%s%s%s", reach ? "" : why, reach ? "" : ", and RCCL is not available: ", r ? r->why : "out of memory");
+                                } else if(!devices_distinct(nband, devices)) {
+                                        rc = j2p_fail(J2P_EDEVICE, "the rccl exchange needs one GPU per band (a device is listed twice)");
+                                } else {
+                                        t->rccl = r;
+                                        t->exchange = kRccl;
+                                }
+                        } else if(!reach) {
+                                rc = j2p_fail(J2P_EDEVICE, "%s: J2P_TILED_EXCHANGE=%s needs it", why, kExchangeName[want]);
+                        } else if(want == kCopy || rows_of_tiles > kTreeRowsInProject) {
+                                t->exchange = kCopy;        // (also: canvases whose row sums k_project's in-kernel tree cannot hold)
+                        } else {
+                                t->exchange = kDirect;
                         }
-                        if(hipSetDevice(da) != hipSuccess) { rc = j2p_fail(J2P_EDEVICE, "hipSetDevice(%d) failed", da); break; }
-                        const hipError_t e = hipDeviceEnablePeerAccess(db, 0);
-                        if(e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
-                                rc = j2p_fail(J2P_EDEVICE, "hipDeviceEnablePeerAccess(%d -> %d): %s", da, db, hipGetErrorString(e));
-                        }
-                        (void)hipGetLastError();
                 }
         }
+        // a single band is a whole-canvas solver: j2p_tiled_run hands it to j2p_solver_run (no thread, no exchange) —
+        // unless the one-band RCCL self-test asks for the real machinery
+        const bool plain_single = nband == 1 && !(t->exchange == kRccl && t->self_neighbours);
+        t->threaded = !plain_single;
+        // direct / copy: every band writes (reads) other bands' memory: peer access first, so that every allocation the
+        // band solvers make below is mapped for the peers from the start
+        if(rc == J2P_OK && t->exchange != kRccl) { rc = enable_peer_access(nband, devices); }
         for(unsigned b = 0; b < nband && rc == J2P_OK; b++) {
                 Band *bd = new(std::nothrow) Band();
                 if(!bd) { rc = j2p_fail(J2P_ENOMEM, "host allocation failed"); break; }
@@ -380,7 +589,7 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                 bd->row1 = edge[b + 1];
                 const j2p_band band = {edge[b], edge[b + 1]};
                 rc = j2p_solver_create(&bd->solver, bd->device, nullptr, nchannel, planes, weight, pweight, iterations,
-                                       nband == 1 ? j2p_band{0, 0} : band, 0);
+                                       plain_single ? j2p_band{0, 0} : band, plain_single ? 0 : J2P_BAND_EVEN_IF_WHOLE);
                 if(rc != J2P_OK) { break; }
                 if(hipSetDevice(bd->device) != hipSuccess) { rc = j2p_fail(J2P_EDEVICE, "hipSetDevice(%d) failed", bd->device); break; }
                 void *st = nullptr;
@@ -389,22 +598,32 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                 j2p_exchange e;
                 j2p_solver_exchange_info(bd->solver, &e);
                 bd->rowsum[0] = bd->rowsum[1] = e.partials_local;
-                if(nband > 1) {
+                bd->rowsum_local = e.partials_local;
+                bd->global_rows[0] = bd->global_rows[1] = e.partials_all;
+                bd->first_tr = e.first_tile_row;
+                bd->ntr = e.local_tile_rows;
+                if(b > 0 && bd->ntr != t->bands[0]->ntr) { t->equal_counts = false; }
+                if(t->threaded && t->exchange == kCopy) {
                         rc = j2p_solver_alternate_rowsums(bd->solver, bd->rowsum);
                         if(rc != J2P_OK) { break; }
                 }
-                bd->first_tr = e.first_tile_row;
-                bd->ntr = e.local_tile_rows;
+                if(t->threaded && t->exchange == kDirect) {
+                        rc = j2p_solver_global_rowsums(bd->solver, bd->global_rows);
+                        if(rc != J2P_OK) { break; }
+                }
                 rc = j2p_solver_norm_ptr(bd->solver, &bd->norm);
                 if(rc != J2P_OK) { break; }
                 j2p_solver_halo_rows(bd->solver, 0, &bd->rows[0]);
                 j2p_solver_halo_rows(bd->solver, 1, &bd->rows[1]);
-                // the two-part phases need an interior: three 16-row segments and three block rows of every channel
-                bd->split = t->want_split && nband > 1 && bd->row1 - bd->row0 >= 3 * align && bd->row1 - bd->row0 >= 3 * J2P_TILE_ROWS;
                 // (J2P_TILED_EVENT_FLAGS=<hex>: extra hipEventCreateWithFlags bits, a timing experiment — e.g. 0x20000000
-                // hipEventDisableSystemFence, 0x40000000 hipEventReleaseToDevice; NOT for bands on different GPUs)
+                // hipEventDisableSystemFence.  Honoured ONLY when all bands share one GPU: between GPUs the system-scope
+                // release of the record is what makes a band's stores into its peers' memory visible to them)
                 unsigned evflags = hipEventDisableTiming;
-                if(const char *env = getenv("J2P_TILED_EVENT_FLAGS")) { evflags |= (unsigned)strtoul(env, nullptr, 16); }
+                if(const char *env = getenv("J2P_TILED_EVENT_FLAGS")) {
+                        bool one_device = true;
+                        for(unsigned k = 1; k < nband; k++) { one_device = one_device && devices[k] == devices[0]; }
+                        if(one_device) { evflags |= (unsigned)strtoul(env, nullptr, 16); }
+                }
                 for(int k = 0; k < 2 && rc == J2P_OK; k++) {
                         if(hipEventCreateWithFlags(&bd->ev_grad[k], evflags) != hipSuccess ||
                            hipEventCreateWithFlags(&bd->ev_edge[k], evflags) != hipSuccess ||
@@ -413,16 +632,55 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                         }
                 }
         }
+        // ---- direct: tell every band where its neighbours' halo rows and everybody's global arrays are ----
+        if(rc == J2P_OK && t->threaded && t->exchange == kDirect) {
+                for(unsigned b = 0; b < nband && rc == J2P_OK; b++) {
+                        Band *bd = t->bands[b];
+                        j2p_band_links l;
+                        memset(&l, 0, sizeof(l));
+                        for(int buf = 0; buf < 2; buf++) {
+                                for(unsigned c = 0; c < nchannel; c++) {
+                                        if(b > 0) { l.up_halo[buf][c] = t->bands[b - 1]->rows[buf].recv_bottom[c]; }
+                                        if(b + 1 < nband) { l.down_halo[buf][c] = t->bands[b + 1]->rows[buf].recv_top[c]; }
+                                }
+                                for(unsigned p = 0; p < nband; p++) { l.push[buf][p] = t->bands[p]->global_rows[buf]; }
+                        }
+                        l.npush = nband;
+                        rc = j2p_solver_link_bands(bd->solver, &l);
+                }
+        }
+        // ---- rccl: one communicator per band, all in this process ----
+        if(rc == J2P_OK && t->exchange == kRccl) {
+                std::vector<void *> comms(nband, nullptr);
+                const int e = t->rccl->CommInitAll(comms.data(), (int)nband, devices);
+                if(e != 0) { rc = j2p_fail(J2P_EDEVICE, "ncclCommInitAll over %u GPUs failed: %s", nband, t->rccl->GetErrorString(e)); }
+                else {
+                        for(unsigned b = 0; b < nband; b++) { t->bands[b]->comm = comms[b]; }
+                }
+        }
+        // every band's initial state (and, direct, nothing else) must be in place before any band's first phase reads
+        // or writes a neighbour: create is not a hot path, drain
+        for(unsigned b = 0; b < t->bands.size() && rc == J2P_OK; b++) { rc = j2p_solver_sync(t->bands[b]->solver); }
         if(prev >= 0) { (void)hipSetDevice(prev); }
         if(rc != J2P_OK) {
+                // (the error text survives the destroy: it is the calling thread's)
+                char keep[512];
+                strncpy(keep, j2p_last_error(), sizeof(keep) - 1);
+                keep[sizeof(keep) - 1] = 0;
                 j2p_tiled_destroy(t);
-                return rc;
+                return j2p_fail(rc, "%s", keep);
         }
-        // a single band is a whole-canvas solver: j2p_tiled_run hands it to j2p_solver_run (no thread, no exchange)
-        if(nband > 1) {
+        if(t->threaded) {
                 for(unsigned b = 0; b < nband; b++) { t->bands[b]->thread = std::thread(band_main, t, b); }
         }
         *out = t;
+        return J2P_OK;
+}
+
+int j2p_tiled_exchange(const j2p_tiled *t, const char **name)
+{
+        if(!t || !name) { return j2p_fail(J2P_EINVAL, "NULL argument"); }
+        *name = t->threaded ? kExchangeName[t->exchange] : "none";
         return J2P_OK;
 }
 
@@ -457,13 +715,15 @@ int j2p_tiled_reset(j2p_tiled *t)
 {
         if(!t) { return j2p_fail(J2P_EINVAL, "tiled solver is NULL"); }
         if(t->abort.load()) { return j2p_fail(J2P_ESTATE, "a band failed earlier; the tiled solver is unusable"); }
+        // a band's reset must neither overtake a neighbour still reading its edge rows nor be overtaken by one still
+        // writing into its halo rows: drain first, reset, drain again — this is not a hot path
+        BAND_TRY(j2p_tiled_sync(t));
         // the band threads are idle between run() calls; every band back to iteration 0 from its resident inputs
         for(Band *b : t->bands) { BAND_TRY(j2p_solver_reset(b->solver)); }
         {
                 std::lock_guard<std::mutex> g(t->seq_lock);
                 for(Band *b : t->bands) { b->grad_recorded = b->edge_recorded = b->norm_recorded = 0; }
         }
-        // a band's reset must not overtake a neighbour still pulling its edge rows: drain, this is not a hot path
         BAND_TRY(j2p_tiled_sync(t));
         t->iter = 0;
         for(unsigned c = 0; c < J2P_MAX_CHANNELS; c++) { t->carried[c] = 0.; }
@@ -476,7 +736,7 @@ int j2p_tiled_run(j2p_tiled *t, unsigned n, j2p_log_row *rows)
         if(!t) { return j2p_fail(J2P_EINVAL, "tiled solver is NULL"); }
         if(n == 0) { return J2P_OK; }
         if(t->abort.load()) { return j2p_fail(J2P_ESTATE, "a band failed earlier; the tiled solver is unusable"); }
-        if(t->nband == 1) {
+        if(!t->threaded) {
                 // one band = a whole-canvas solver: its own loop (its norm reduction is not the band solvers')
                 BAND_TRY(j2p_solver_run(t->bands[0]->solver, n, rows));
                 t->iter += n;

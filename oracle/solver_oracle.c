@@ -8,7 +8,7 @@
  * product library never links or calls it.
  *
  * Parity status: PINNED.  The reference has no golden vectors,
- * so the pin is the compiled reference itself: tests/test_oracle_vs_ref.py
+ * so the pin is the compiled reference itself: tests/test_oracle.py
  * checks that this restatement is BIT-IDENTICAL to oracle/_ref/libj2p_ref.so
  * (the untouched reference sources built by oracle/Makefile) for 1- and
  * 3-channel, subsampled and padded inputs, and tests/golden/ holds outputs of

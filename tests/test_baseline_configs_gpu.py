@@ -1,15 +1,18 @@
 """Parity at the parameters BASELINE.json's `configs` state, one test per configuration, against the UNMODIFIED
 reference (oracle/_ref: compute.c compiled from /root/reference) on identical `struct coef` inputs.
 
-Bar (north_star): per-plane PSNR >= 80 dB, peak 255 — asserted hard.  Expected, and asserted for everything
-below 4 Mpixel: BIT-IDENTICAL planes.  For the two large single planes (configs[2], configs[3]) a bit mismatch
-above 80 dB is reported as a warning instead of a failure: ||g|| is a double sum whose (fixed, GPU-count
-invariant) tree order differs from the reference's sequential order (compute.c:200-207), and the two can land
-on different sides of a float rounding boundary inside sqrtf((float)sum) with probability ~1e-5 per iteration
-at 16 Mpixel (SURVEY.md §7 hard part 2) — not observed so far.
+Bar (north_star): per-plane PSNR >= 80 dB, peak 255 — asserted hard.  Expected AND asserted, at every size:
+BIT-IDENTICAL planes.  The one place where that could fail without a defect: ||g|| is a double sum whose (fixed,
+GPU-count invariant) tree order differs from the reference's sequential order (compute.c:200-207), and the two can
+land on different sides of a float rounding boundary inside sqrtf((float)sum) with probability ~1e-5 per iteration
+at 16 Mpixel (SURVEY.md §7 hard part 2) — not observed so far.  Should it ever happen on the large single planes
+(configs[2], configs[3]) the test FAILS, so that the record and README.md cannot disagree; J2P_ALLOW_NORM_FLIP=1 in
+the environment turns that one failure (never the 80 dB bar) into a reported WARNING line.
 """
 import copy
+import os
 import threading
+import time
 import warnings
 
 import numpy as np
@@ -21,6 +24,8 @@ pytestmark = pytest.mark.gpu
 
 PSNR_BAR_DB = 80.0
 WEIGHT, PWEIGHT = 0.3, 0.001          # jpeg2png.c:22-23
+# large single planes: a bit mismatch above 80 dB fails the test unless this is set (see the module docstring)
+ALLOW_NORM_FLIP = os.environ.get("J2P_ALLOW_NORM_FLIP", "") == "1"
 
 
 def _need_ref(oracle):
@@ -113,7 +118,7 @@ def test_config2_4096x4096_y_q10_i500_the_bench_workload(lib, oracle):
     want, _, secs = oracle.ref_compute(planes, WEIGHT, [PWEIGHT], 500)
     got = copy.deepcopy(planes)
     j.compute(got, WEIGHT, [PWEIGHT], 500)
-    check_planes("configs[2]", [got[0].fdata], want, strict=False)
+    check_planes("configs[2]", [got[0].fdata], want, strict=not ALLOW_NORM_FLIP)
     print(f"configs[2]: reference {secs:.1f} s inside compute()")
 
 
@@ -165,70 +170,76 @@ def test_config4_1080p_420_q50_joint_i100(lib, oracle):
     check_log(got_log, want_log)
 
 
-def _config3_plane():
-    """the configs[3] plane: 16384x16384 Y-only Q10 (bench.py's seed), synthesised band by band on the host's cores"""
-    from jpeg2png_amd import synth
-    return synth.make_y_plane_banded(16384, 16384, 10, seed=1234 + 4, band_rows=1024, workers=16)
-
-
-def test_config3_full_size_8_bands_vs_whole_canvas_i100(lib):
-    """configs[3] at its stated size and iteration count (the loop compute.c:427-453 on the 16384x16384 geometry):
-    8 bands of 2048 rows through the C row tiling (j2p_tiled; the 8 bands share this box's one GPU) against the
-    whole-canvas solver on the same GPU, `-i 100`: planes and CSV rows, bitwise."""
+def test_config3_full_size_i100_vs_reference_whole_and_8_bands(lib, oracle, config3_reference):
+    """configs[3] AT ITS STATED PARAMETERS against the UNMODIFIED reference: 16384x16384 Y-only Q10, `-i 100` (the
+    iteration count enters the step size, compute.c:443, so no shorter run is the same solve).  The reference's
+    compute() on that plane takes ~5 minutes of one CPU core and ~9 GiB of host memory: it was started in a worker
+    thread when the session began (conftest.config3_reference; ctypes releases the GIL) and is joined here, the last
+    test of the run.  Compared with it, bitwise: (a) the whole-canvas solver through compute()'s path, (b) the C row
+    tiling, 8 bands of 2048 rows (j2p_tiled; the bands share this box's one GPU) — the loop compute.c:427-453 on the
+    16384x16384 geometry; (b) against (a) too, CSV rows included."""
+    _need_ref(oracle)
     import jpeg2png_amd as j
     its = 100
-    plane = _config3_plane()
+    plane, want, ref_seconds, waited = config3_reference()
     with j.Solver([plane], WEIGHT, [PWEIGHT], its) as s:
         whole_rows = s.run(its, log=True)
         whole = s.download(0)
+    check_planes("configs[3] 16384x16384 -i 100, whole canvas", [whole], want, strict=not ALLOW_NORM_FLIP)
     j.load_library().j2p_pool_trim()
     with j.TiledSolver([plane], WEIGHT, [PWEIGHT], its, devices=[0] * 8) as t:
         assert [b[1:] for b in t.bands()] == [(r, r + 2048) for r in range(0, 16384, 2048)]
         banded_rows = t.run(its, log=True)
         banded = t.download(0)
         cpu = t.host_cpu_seconds()
-    check_planes("configs[3] 16384x16384 -i 100, 8 x 2048-row bands", [banded], [whole], against="the whole-canvas solve")
+    check_planes("configs[3] 16384x16384 -i 100, 8 x 2048-row bands", [banded], want, strict=not ALLOW_NORM_FLIP)
+    assert bit_equal(banded, whole), "16384x16384 -i 100: 8 bands differ from the whole-canvas solve"
     np.testing.assert_allclose(banded_rows, whole_rows, rtol=1e-9, atol=1e-9)
     assert np.isfinite(banded_rows).all()
-    parity_note(f"configs[3] 16384x16384 -i 100: CSV rows of 8 bands == whole canvas; band threads used {cpu:.3f} s of host CPU")
+    parity_note(f"configs[3] 16384x16384 -i 100: 8 bands == whole canvas bitwise, CSV rows equal; band threads used {cpu:.3f} s of "
+                f"host CPU; the reference spent {ref_seconds:.0f} s inside compute() (in the background; this test waited {waited:.0f} s)")
 
 
-def test_config3_full_size_vs_reference_i4(lib, oracle):
-    """configs[3]'s canvas against the UNMODIFIED reference: 16384x16384 Y Q10 with the `-i 100` step size replaced
-    by `-i 4` (per-iteration cost is constant; ~12 s of one CPU core, ~9 GiB of host memory): 80 dB hard,
-    bit-identity reported."""
-    _need_ref(oracle)
-    import jpeg2png_amd as j
-    its = 4
-    plane = _config3_plane()
-    plane.fdata = j.decode_plane(plane)
-    want, _, secs = oracle.ref_compute([plane], WEIGHT, [PWEIGHT], its)
-    got = copy.copy(plane)
-    j.compute([got], WEIGHT, [PWEIGHT], its)
-    check_planes("configs[3] 16384x16384 -i 4", [got.fdata], want, strict=False)
-    print(f"configs[3] 16384x16384: reference {secs:.1f} s inside compute()")
-
-
-def test_config4_batch_of_32_images_first_and_last_vs_reference(lib, oracle):
-    """configs[4] as a batch: 32 x 1080p 4:2:0 Q50 `-i 100` joint through the C batch engine (j2p_batch: worker slots,
-    pooled arenas, overlapping upload / solve / download — the file loop jpeg2png.c:330-337); images 0 and 31 against
-    the reference's compute() on the same struct coef (float canvas planes out)."""
+def test_config4_batch_of_256_images_vs_reference(lib, oracle):
+    """configs[4] AS STATED: a batch of 256 x 1080p 4:2:0 Q50 `-i 100` joint through the C batch engine (j2p_batch: worker
+    slots, pooled arenas, overlapping upload / solve / download — the file loop jpeg2png.c:330-337), float canvas planes
+    out.  Images 0, 255 and one drawn at random against the reference's compute() on the same struct coef; every other
+    image against the first occurrence of its content (8 distinct images, cycled).  At most 32 results are held at a time."""
     _need_ref(oracle)
     import jpeg2png_amd as j
     from jpeg2png_amd import synth
-    n, its = 32, 100
-    distinct = [synth.make_planes(1920, 1080, "420", 50, seed=1234 + 5 + k) for k in range(4)]
-    images = [distinct[i % 4] for i in range(n)]
-    with j.Batch(devices=[0], slots_per_device=4) as b:
-        tickets = [b.submit(img, WEIGHT, [PWEIGHT] * 3, its) for img in images]
-        outs = [b.wait(t) for t in tickets]
-    for i in (0, n - 1):
-        planes = copy.deepcopy(images[i])
+    n, its, ndistinct, window = 256, 100, 8, 32
+    distinct = [synth.make_planes(1920, 1080, "420", 50, seed=1234 + 5 + k) for k in range(ndistinct)]
+    pick = int(np.random.default_rng(20260925).integers(1, n - 1))
+    against_ref = {0, n - 1, pick}
+    first = {}                      # content index -> planes of its first occurrence
+    kept = {}                       # image index -> planes, for the reference comparison
+    t0 = time.perf_counter()
+    with j.Batch(devices=[0], slots_per_device=8) as b:
+        tickets = {}
+
+        def collect(i):
+            out = b.wait(tickets.pop(i))
+            k = i % ndistinct
+            if k not in first:
+                first[k] = out
+            else:
+                for c in range(3):
+                    assert bit_equal(out[c], first[k][c]), f"image {i} channel {c} differs from image {k} (same content)"
+            if i in against_ref:
+                kept[i] = out
+        for i in range(n):
+            tickets[i] = b.submit(distinct[i % ndistinct], WEIGHT, [PWEIGHT] * 3, its)
+            if i >= window:
+                collect(i - window)
+        for i in range(n - window, n):
+            collect(i)
+    secs = time.perf_counter() - t0
+    for i in sorted(against_ref):
+        planes = copy.deepcopy(distinct[i % ndistinct])
         for p in planes:
             p.fdata = oracle.decode_plane(p)
         want, _, _ = oracle.ref_compute(planes, WEIGHT, [PWEIGHT] * 3, its)
-        check_planes(f"configs[4] batch of {n}, image {i}", outs[i], want)
-    # the same image submitted eight times gives the same bits eight times
-    for i in range(4, n):
-        for c in range(3):
-            assert bit_equal(outs[i][c], outs[i % 4][c]), f"image {i} channel {c} differs from image {i % 4}"
+        check_planes(f"configs[4] batch of {n}, image {i}", kept[i], want)
+    parity_note(f"configs[4] batch of {n} x 1080p 4:2:0 Q50 -i 100: every image bit-identical to the first occurrence of its "
+                f"content ({ndistinct} distinct); {n / secs:.0f} images/s host-to-host incl. the comparisons")

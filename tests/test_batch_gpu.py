@@ -99,10 +99,12 @@ def test_pool_recycles_arenas(lib):
 
 
 @pytest.mark.parametrize("separate", [False, True])
-def test_tiled_job_equals_single_solver_job(lib, separate):
+def test_tiled_job_equals_single_solver_job(lib, separate, monkeypatch):
     """j2p_job.tile: one image over all the batch's devices (here device 0 three times): float planes and RGB bytes
-    equal the untiled job's; a canvas too short to tile falls back to the single-solver path"""
+    equal the untiled job's; a canvas too short to tile falls back to the single-solver path.  (The library tiles only
+    images with at least 2 Mpixel per band; the gate is lowered here so that a small image exercises the path.)"""
     import jpeg2png_amd as j
+    monkeypatch.setenv("J2P_TILE_MIN_BAND_PIXELS", "0")
     planes = make_case(152, 296, "420", 10, seed=83)
     weights, its = ([0.3, 0.1, 0.0], [12, 7, 5]) if separate else (0.3, 12)
     with j.Batch(devices=[0, 0, 0], slots_per_device=1) as b:
@@ -120,3 +122,22 @@ def test_tiled_job_equals_single_solver_job(lib, separate):
         assert bit_equal(s_t[c], s_a[c])
     assert np.array_equal(t_rgb, a_rgb)
     assert np.array_equal(t_rgb16, a_rgb16)
+
+
+def test_tile_gate_and_device_shares(lib, monkeypatch):
+    """a job's share of the batch's devices (tile_first / tile_count: a few files, fewer than GPUs) and the pixel gate:
+    below 2 Mpixel per band the image is solved on one GPU of its share — same bits every way; a share outside the
+    batch's device list and a bad output description are rejected before anything runs"""
+    import jpeg2png_amd as j
+    planes = make_case(152, 296, "420", 10, seed=84)
+    with j.Batch(devices=[0, 0, 0, 0], slots_per_device=1) as b:
+        plain = b.wait(b.submit(planes, 0.3, [0.001] * 3, 6))
+        gated = b.wait(b.submit(planes, 0.3, [0.001] * 3, 6, tile=True, tile_devices=(2, 2)))       # too small: untiled
+        monkeypatch.setenv("J2P_TILE_MIN_BAND_PIXELS", "0")
+        share = b.wait(b.submit(planes, 0.3, [0.001] * 3, 6, tile=True, tile_devices=(1, 2)))       # two bands
+        with pytest.raises(j.J2PError, match="tile devices"):
+            b.wait(b.submit(planes, 0.3, [0.001] * 3, 6, tile=True, tile_devices=(3, 2)))
+        with pytest.raises(j.J2PError, match="out_bits"):
+            b.wait(b.submit(planes, 0.3, [0.001] * 3, 6, tile=True, width=150, height=290, bits=12))
+    for c in range(3):
+        assert bit_equal(gated[c], plain[c]) and bit_equal(share[c], plain[c])

@@ -278,7 +278,7 @@ def test_one_tall_image_is_row_tiled_over_every_listed_gpu(cli, tmp_path, case):
     ref_csv, gpu_csv = tmp_path / "ref.csv", tmp_path / "gpu.csv"
     r = run(REF_CLI, str(jpg), "-o", str(ref_png), "-q", "-c", str(ref_csv), "-t", "1", *flags)
     assert r.returncode == 0, r.stderr
-    env = dict(os.environ, J2P_DEVICES="0,0,0,0")
+    env = dict(os.environ, J2P_DEVICES="0,0,0,0", J2P_TILE_MIN_BAND_PIXELS="0")     # (small test images: lower the pixel gate)
     g = subprocess.run([cli, str(jpg), "-o", str(gpu_png), "-q", "-c", str(gpu_csv), *flags], capture_output=True, text=True, env=env)
     assert g.returncode == 0, g.stderr
     assert ref_png.read_bytes() == gpu_png.read_bytes()
@@ -288,6 +288,27 @@ def test_one_tall_image_is_row_tiled_over_every_listed_gpu(cli, tmp_path, case):
     gpu_rows = gpu_rows[np.lexsort((gpu_rows[:, 1], gpu_rows[:, 0]))]
     assert ref_rows.shape == gpu_rows.shape
     np.testing.assert_allclose(gpu_rows, ref_rows, rtol=0, atol=2e-6 * max(1.0, np.abs(ref_rows).max()))
+
+
+@pytest.mark.gpu
+def test_two_files_share_out_four_listed_gpus(cli, tmp_path):
+    """more than one file, still fewer than GPUs: file i is tiled over ITS share of J2P_DEVICES (two "GPUs" each here)
+    instead of every file over all of them; PNG bytes equal the reference program's"""
+    if not os.path.exists(REF_CLI):
+        pytest.skip("oracle/_ref/jpeg2png_ref not built (needs /root/reference)")
+    names = []
+    for i in range(2):
+        p = tmp_path / f"tall{i}.jpg"
+        make_jpeg(p, 72 + 8 * i, 200 + 56 * i, 12, 2, seed=70 + i)
+        names.append(str(p))
+    env = dict(os.environ, J2P_DEVICES="0,0,0,0", J2P_TILE_MIN_BAND_PIXELS="0")
+    g = subprocess.run([cli, *names, "-q", "-i", "7"], capture_output=True, text=True, env=env)
+    assert g.returncode == 0, g.stderr
+    for i in range(2):
+        ref = tmp_path / f"ref{i}.png"
+        r = run(REF_CLI, names[i], "-o", str(ref), "-q", "-i", "7", "-t", "1")
+        assert r.returncode == 0, r.stderr
+        assert (tmp_path / f"tall{i}.png").read_bytes() == ref.read_bytes()
 
 
 def test_threads_default_is_the_core_count_like_openmp(cli):

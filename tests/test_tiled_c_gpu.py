@@ -147,24 +147,75 @@ def test_unlogged_then_logged_runs_report_nan_for_the_unknown_distance(lib):
     np.testing.assert_allclose(rows[1:], want_rows[5:], rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("norm,split", [("root", "0"), ("all", "0"), ("root", "1"), ("all", "1")])
-def test_every_schedule_of_the_tiling_gives_the_same_bits(lib, norm, split, monkeypatch):
-    """one band reducing ||g|| for all (default) or every band for itself (J2P_TILED_NORM=all); one gradient and one
-    projection launch per band and iteration (default) or the split phases that hide the halo exchange behind the
-    interior launches (J2P_TILED_SPLIT=1): the same tree over the same array and the same kernels on the same rows,
-    so the same planes and the same CSV rows"""
+@pytest.mark.parametrize("exchange,norm", [("direct", "root"), ("copy", "root"), ("copy", "all")])
+def test_every_schedule_of_the_tiling_gives_the_same_bits(lib, exchange, norm, monkeypatch):
+    """the exchanges riding on the phase kernels as peer writes (direct: two launches per band and iteration, the
+    default) or round 3's copy kernel + one band reducing ||g|| for all / every band for itself (copy;
+    J2P_TILED_NORM=all): the same tree over the same array and the same kernels on the same rows, so the same planes
+    and the same CSV rows — joint 4:2:0 (subsampled and resampled projection paths push their edge rows too)"""
     import jpeg2png_amd as j
     planes = make_case(264, 410, "420", 10, seed=78)
     pws = [0.001] * 3
     want, want_rows = whole_canvas(planes, 0.3, pws, 10, log=True)
+    monkeypatch.setenv("J2P_TILED_EXCHANGE", exchange)
     monkeypatch.setenv("J2P_TILED_NORM", norm)
-    monkeypatch.setenv("J2P_TILED_SPLIT", split)
     with j.TiledSolver(planes, 0.3, pws, 10, devices=[0] * 5) as t:
+        assert t.exchange() == exchange
         t.run(10)
         for c in range(3):
-            assert bit_equal(t.download(c), want[c]), f"{norm}/{split}: channel {c}"
+            assert bit_equal(t.download(c), want[c]), f"{exchange}/{norm}: channel {c}"
         t.reset()
         rows = t.run(10, log=True)
         for c in range(3):
-            assert bit_equal(t.download(c), want[c]), f"{norm}/{split}, logged: channel {c}"
+            assert bit_equal(t.download(c), want[c]), f"{exchange}/{norm}, logged: channel {c}"
     np.testing.assert_allclose(rows, want_rows, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("sub,y_only,W,H", [("444", True, 200, 330), ("444", False, 136, 200), ("422", False, 152, 264),
+                                            ("440", False, 152, 264), ("420", False, 77, 301)])
+def test_direct_exchange_on_every_projection_path(lib, sub, y_only, W, H, monkeypatch):
+    """the edge rows a band's projection stores into its neighbours' halo rows, on every store path of k_project: 1x1
+    register path, 2x1 / 1x2 / 2x2 subsampled, ragged canvases (generic and uncovered pixels), iterations issued in
+    two run() calls"""
+    import jpeg2png_amd as j
+    planes = make_case(W, H, sub, 12, seed=79, y_only=y_only)
+    pws = [0.001] * len(planes)
+    want, _ = whole_canvas(planes, 0.3, pws, 8)
+    monkeypatch.setenv("J2P_TILED_EXCHANGE", "direct")
+    with j.TiledSolver(planes, 0.3, pws, 8, devices=[0] * 3) as t:
+        assert t.exchange() == "direct"
+        t.run(3)
+        t.run(5)
+        for c in range(len(planes)):
+            assert bit_equal(t.download(c), want[c]), f"channel {c}"
+
+
+def test_rccl_exchange_with_one_band_as_its_own_neighbour(lib, monkeypatch):
+    """the RCCL transport of the C engine on ONE GPU: one band (RCCL wants a GPU per rank), driven through the band
+    machinery — ncclCommInitAll, ncclAllGather of its row sums, grouped ncclSend / ncclRecv of its edge rows to
+    itself (they land above / below the image, where the kernels mask) — against the plain whole-canvas solver,
+    bitwise; two bands on one GPU are refused with the reason"""
+    import jpeg2png_amd as j
+    planes = make_case(264, 410, "420", 10, seed=80)
+    pws = [0.001] * 3
+    want, want_rows = whole_canvas(planes, 0.3, pws, 9, log=True)
+    monkeypatch.setenv("J2P_TILED_EXCHANGE", "rccl")
+    monkeypatch.setenv("J2P_TILED_SELF_NEIGHBOURS", "1")
+    try:
+        t = j.TiledSolver(planes, 0.3, pws, 9, devices=[0])
+    except j.J2PError as e:
+        if "librccl" in str(e) or "RCCL" in str(e):
+            pytest.skip(f"no usable librccl on this box: {e}")
+        raise
+    with t:
+        assert t.exchange() == "rccl"
+        rows = np.concatenate([t.run(4, log=True), t.run(5, log=True)])
+        for c in range(3):
+            assert bit_equal(t.download(c), want[c]), f"channel {c}"
+        t.reset()
+        t.run(9)
+        for c in range(3):
+            assert bit_equal(t.download(c), want[c]), f"after reset: channel {c}"
+    np.testing.assert_allclose(rows, want_rows, rtol=1e-9, atol=1e-12)
+    with pytest.raises(j.J2PError, match="one GPU per band"):
+        j.TiledSolver(planes, 0.3, pws, 9, devices=[0, 0])

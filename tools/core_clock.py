@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The shader clock the phase kernels actually run at (needs the -DJ2P_TRACE -DJ2P_TRACE_CLOCK build):
     python tools/build_variant.py traceclk -DJ2P_TRACE -DJ2P_TRACE_CLOCK
-    J2P_LIBRARY=variants/libj2p_traceclk.so python tools/core_clock.py [W H]
+    J2P_LIBRARY=ab/libj2p_traceclk.so python tools/core_clock.py [W H]
 Every wavefront records its life twice: on the constant 100 MHz clock (s_memrealtime) and in core-clock ticks (s_memtime);
 the ratio is the clock the SIMDs ran at while the kernel was executing — what the cycle counts of tools/isa_count.py
 and tools/ubench/valu_rates have to be priced at.  One JSON line."""

@@ -37,10 +37,10 @@ print(json.dumps({"plane":"$1x$2 Y-only Q10 -i 100","Mpx_it_per_s":d["value"],"u
 PY
 done | tee gpurun_out/${TAG}_size_sweep.jsonl
 for c in "512 512 420 rgb" "1920 1080 444 y" "2048 2048 444 y" "4096 4096 444 y"; do
-  ( J2P_LIBRARY=variants/libj2p_trace.so timeout 120 python tools/wave_trace.py $c ) 2>&1 | grep '^{'
+  ( J2P_LIBRARY=ab/libj2p_trace.so timeout 120 python tools/wave_trace.py $c ) 2>&1 | grep '^{'
 done | tee gpurun_out/${TAG}_wave_trace.jsonl
 # the shader clock the kernels run at, and the cost of a device-wide barrier against a launch boundary
 python tools/build_variant.py traceclk -DJ2P_TRACE -DJ2P_TRACE_CLOCK > /dev/null 2>&1
-for sz in "4096 4096" "2048 2048"; do J2P_LIBRARY=variants/libj2p_traceclk.so timeout 200 python tools/core_clock.py $sz; done | tee gpurun_out/${TAG}_core_clock.jsonl
+for sz in "4096 4096" "2048 2048"; do J2P_LIBRARY=ab/libj2p_traceclk.so timeout 200 python tools/core_clock.py $sz; done | tee gpurun_out/${TAG}_core_clock.jsonl
 [ -x tools/ubench/grid_sync ] || hipcc --offload-arch=gfx950 -O3 -o tools/ubench/grid_sync tools/ubench/grid_sync.hip
 timeout 120 tools/ubench/grid_sync 1000 | tee gpurun_out/${TAG}_grid_sync.json

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a launch of the phase kernels spends its time, wavefront by wavefront (needs the -DJ2P_TRACE build):
     python tools/build_variant.py trace -DJ2P_TRACE
-    J2P_LIBRARY=variants/libj2p_trace.so python tools/wave_trace.py W H [sub] [y|rgb] [iterations]
+    J2P_LIBRARY=ab/libj2p_trace.so python tools/wave_trace.py W H [sub] [y|rgb] [iterations]
 For each of the traced launches: span of the launch (first wavefront start -> last wavefront end), when the
 wavefronts start, how long the first rows / blocks take to arrive, how long a wavefront lives, how many wavefronts
 each CU got.  10 ns resolution (the constant 100 MHz clock)."""
