@@ -13,20 +13,22 @@ Workloads (BASELINE.json configs):
           `other_configs` carries configs[0], configs[1], a configs[4] slice and the 16384x2048 band that is
           the N = 1 point of the N > 1 workload below.
   N > 1 : configs[3]  16384-wide Y-only plane, Q=10, -i 100, row-tiled: 2048 rows per GPU
-          (N = 8 is exactly the 16384x16384 config); weak scaling (fixed rows per GPU).  BOTH engines are
-          timed, each with W warm-up and K timed steps between barriers:
-            c    : the C row tiling (j2p_tiled: one process drives all N GPUs with one host thread per band;
-                   bands exchange edge rows and norm row sums by peer access over xGMI, ordered by HIP events)
-                   — rank 0 drives it; the other ranks of the launch wait in a gloo (CPU) barrier, so that no
-                   RCCL barrier kernel spins on their GPUs while rank 0's band kernels run there; timed three times:
-                   its default schedule, the split-phase one (c_split, J2P_TILED_SPLIT=1) and the default one with
-                   every band reducing ||g|| itself (c_allnorm, J2P_TILED_NORM=all: one cross-GPU hop less per
-                   iteration, N - 1 event waits per band instead of one);
-            rccl : one process per GPU, RCCL send/recv of the halo rows + all-gather of the norm row sums
-                   (jpeg2png_amd/tiled.py), the exchange north_star names.
-          `value` is the fastest of them (`config.parallelism` says which), the other one is in
-          `other_configs`, next to the SAME canvas solved whole on ONE GPU (the strong-scaling denominator)
-          and configs[4] — 256 x 1080p 4:2:0 Q50 -i 100 through the C batch engine over all N GPUs.
+          (N = 8 is exactly the 16384x16384 config); weak scaling (fixed rows per GPU).  Every engine is
+          timed, each with W warm-up and K timed steps between barriers, and the plane each leaves is hashed:
+            c      : the C row tiling (j2p_tiled: one process drives all N GPUs with one host thread per band) in its
+                     default exchange — "direct": row sums of g^2 pushed from k_gradient and edge rows from k_project
+                     as posted peer writes over xGMI, ||g|| reduced inside k_project, two launches and two event waits
+                     per band and iteration — rank 0 drives it; the other ranks of the launch wait in a gloo (CPU)
+                     barrier, so that no RCCL barrier kernel spins on their GPUs while rank 0's band kernels run there;
+            c_copy : the same engine in round 3's exchange (copy kernel pulls the edge rows, one band reduces ||g|| for
+                     all): four launches and three hops per iteration — the cross-check of `c` on real hardware;
+            c_rccl : the same engine over RCCL (ncclAllGather + grouped ncclSend / ncclRecv on the band streams, the
+                     exchange north_star names), librccl dlopen()ed by the C library;
+            rccl   : one process per GPU, the Python harness over torch.distributed / librccl (jpeg2png_amd/tiled.py).
+          `value` is the fastest leg whose plane has the same hash as the SAME canvas solved whole on ONE GPU
+          (`other_configs` carries that solve — the strong-scaling denominator — and every other leg, each with
+          `bits_equal_to_the_whole_canvas_solve`), and configs[4] — 256 x 1080p 4:2:0 Q50 -i 100 through the C
+          batch engine over all N GPUs.
   --config batch : configs[4] slice — B x 1080p 4:2:0 Q=50 -i 100 through the C batch API
           (host buffers in, RGB out: PCIe inclusive), images/s and Mpx-it/s.
 
@@ -77,6 +79,7 @@ def parse():
     ap.add_argument("--slots", type=int, default=8, help="--config batch: images in flight per GPU (measured 4 / 6 / 8 / 12: 188 / 197 / 203 / 193 images/s, profiles/r03_batch_slots.jsonl)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-host-to-host", action="store_true")
     ap.add_argument("--timing-every", type=int, default=16, help="HIP-event sample stride (iterations)")
     ap.add_argument("--force-tiled", action="store_true", help="run the row-tiled path even with one rank (debug)")
     ap.add_argument("--bands", type=int, default=0, help="--force-tiled on one GPU: number of bands on device 0")
@@ -170,7 +173,12 @@ def _timed(fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
-def whole_canvas_on_one_gpu(j, plane, its, device=0, reps=2):
+def plane_digest(array):
+    import hashlib
+    return hashlib.blake2b(np.ascontiguousarray(array), digest_size=16).hexdigest()
+
+
+def whole_canvas_on_one_gpu(j, plane, its, device=0, reps=2, digest=False):
     """a Y plane solved whole on ONE GPU, resident (reset + run): Mpx-it/s and the iteration fraction"""
     s = j.Solver([plane], WEIGHT, [PWEIGHT], its, device=device)
 
@@ -179,12 +187,16 @@ def whole_canvas_on_one_gpu(j, plane, its, device=0, reps=2):
         s.run(its)
         s.sync()
     dt = _timed(run, reps)
+    fingerprint = plane_digest(s.download(0)) if digest else None
     s.close()
     j.load_library().j2p_pool_trim()
     px = plane.w * plane.h
-    return {"ms_per_solve": round(dt * 1e3, 3), "us_per_iteration": round(dt / its * 1e6, 2),
-            "Mpx_it_per_s": round(px * its / dt / 1e6, 1),
-            "iteration_frac": round(BYTES_ITERATION * px * its / dt / 1e9 / HBM_PEAK_GBS, 4)}
+    out = {"ms_per_solve": round(dt * 1e3, 3), "us_per_iteration": round(dt / its * 1e6, 2),
+           "Mpx_it_per_s": round(px * its / dt / 1e6, 1),
+           "iteration_frac": round(BYTES_ITERATION * px * its / dt / 1e9 / HBM_PEAK_GBS, 4)}
+    if digest:
+        out["digest"] = fingerprint
+    return out
 
 
 def batch_images_per_s(j, synth, devices, n_images, slots, its=100):
@@ -267,6 +279,29 @@ def other_configs(j, synth):
                    "2048 rows of the 16384-wide plane)")
     out.append(r)
     return out
+
+
+def host_to_host(j, planes, its, resident_ms, device=0, reps=3):
+    """SURVEY.md §8(d) "with and without H2D/D2H + aux_init": the C drop-in j2p_compute() — what compute() (compute.h:8)
+    is — called like the reference's decode_file() calls it: libc-allocated pageable planes in (int16 coefficients + the
+    decoded float plane), the float canvas plane back in newly allocated memory (compute.c:278-310, 455-461 are inside
+    the reference's compute() too).  Never `value`."""
+    for p in planes:
+        if p.fdata is None:
+            p.fdata = j.decode_plane(p, device=device)
+    _, secs = j.compute_c(planes, WEIGHT, [PWEIGHT] * len(planes), its, device=device, repeat=reps + 1)
+    ms = sorted(s * 1e3 for s in secs[1:])                    # (the first call creates the arena and the pinned slabs)
+    px = sum(p.w * p.w_samp * p.h * p.h_samp for p in planes[:1]) * len(planes)
+    up = sum(p.w * p.h * 6 for p in planes)
+    down = px * 4
+    med = ms[len(ms) // 2]
+    return {"ms_per_call": round(med, 3), "ms_per_call_all": [round(x, 3) for x in ms], "resident_ms_per_solve": round(resident_ms, 3),
+            "boundary_ms": round(med - resident_ms, 3), "upload_bytes": up, "download_bytes": down,
+            "Mpx_it_per_s": round(px * its / (med * 1e-3) / 1e6, 1),
+            "what": "j2p_compute() (the C drop-in behind compute(), compute.h:8) from libc-allocated pageable planes: upload of the "
+                    "int16 coefficients and the decoded float plane, aux_init, all iterations, download into a newly allocated "
+                    "plane; staged through pinned slabs by a few host threads (j2p_xfer.hip), the input planes freed and the "
+                    "output pages touched while the GPU iterates"}
 
 
 def bench_batch(a, j, synth):
@@ -449,6 +484,13 @@ def single_gpu(a, j, synth, local_rank):
         "roofline": roofline_object(value, 1, its, elapsed, a.steps, px, per_kernel, samples, a.timing_every, traffic, traffic_src),
     }
     solver.close()
+    if not a.no_host_to_host:
+        try:
+            planes = synth.make_planes(W, H, "444", 10, seed=seed, y_only=True)
+            out["host_to_host"] = host_to_host(j, planes, its, elapsed / a.steps * 1e3, device=local_rank)
+            del planes
+        except Exception as e:          # noqa: BLE001
+            out["host_to_host"] = {"error": f"{type(e).__name__}: {e}"}
     if not a.no_other_configs and not a.size:
         out["other_configs"] = other_configs(j, synth)
     if not a.no_cpu_baseline:
@@ -497,27 +539,35 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
     # (the RCCL harness needs one rank per GPU: not in the one-device rehearsal, and with a single rank only on request)
     want_rccl = (a.tiled_impl == "rccl" or (a.tiled_impl == "both" and world > 1)) and not (one_device and world > 1)
 
-    # ---- legs 1a / 1b: the C engine, driven by rank 0 — its default schedule (one gradient and one projection launch per
-    # band and iteration, the halo rows pulled in front of the gradient) and the split one (J2P_TILED_SPLIT=1: interior /
-    # edge parts, the halo exchange hidden behind the interior launches) ----
-    def c_leg(name, split, norm="root", event_flags=None, digest=False):
+    # ---- the truth every leg's plane is compared with: the SAME canvas solved whole on ONE GPU (also the strong-scaling
+    # denominator), by rank 0 ----
+    whole = None
+    if rank == 0 and not a.no_other_configs:
+        try:
+            whole = whole_canvas_on_one_gpu(j, whole_plane, its, device=local_rank, digest=True)
+        except Exception as e:          # noqa: BLE001
+            whole = {"error": f"{type(e).__name__}: {e}"}
+    ranks.barrier()
+
+    # ---- legs 1: the C engine, driven by rank 0, in each of its exchanges (j2p_tiled.hip) ----
+    def c_leg(name, exchange=None, norm="root"):
         ok = [True, ""]
         tsolver = eng = None
+        how = ""
         if rank == 0:
             try:
-                os.environ["J2P_TILED_SPLIT"] = "1" if split else "0"          # read by j2p_tiled_create
+                if exchange:
+                    os.environ["J2P_TILED_EXCHANGE"] = exchange      # read by j2p_tiled_create
                 os.environ["J2P_TILED_NORM"] = norm
-                if event_flags is not None:
-                    os.environ["J2P_TILED_EVENT_FLAGS"] = event_flags
                 devices = list(range(n_gpus)) if n_gpus > 1 and not one_device else [local_rank] * nband
                 tsolver = j.TiledSolver([whole_plane], WEIGHT, [PWEIGHT], its, devices=devices)
                 eng = tsolver.band_solver(0)
-            except Exception as e:      # noqa: BLE001  (no peer access between the GPUs, a device this process cannot open ...)
+                how = tsolver.exchange()
+            except Exception as e:      # noqa: BLE001  (no peer access between the GPUs, no librccl, a device this process cannot open ...)
                 ok = [False, f"{type(e).__name__}: {e}"]
             finally:
-                os.environ.pop("J2P_TILED_SPLIT", None)
+                os.environ.pop("J2P_TILED_EXCHANGE", None)
                 os.environ.pop("J2P_TILED_NORM", None)
-                os.environ.pop("J2P_TILED_EVENT_FLAGS", None)
         ok = ranks.share(ok)
         if ok[0]:
             if rank == 0:
@@ -528,33 +578,28 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
             cpu_s = tsolver.host_cpu_seconds() if rank == 0 else 0.0
             fingerprint = None
             if rank == 0:
-                if digest:          # the plane the last timed step left behind (every leg runs the same solve)
-                    import hashlib
-                    fingerprint = hashlib.blake2b(tsolver.download(0), digest_size=16).hexdigest()
+                fingerprint = plane_digest(tsolver.download(0))      # the plane the last timed step left behind
                 tsolver.close()
-            legs[name] = {"elapsed": elapsed, "g_ms": g_ms, "p_ms": p_ms, "samples": samples, "split": split,
-                          "host_cpu_s": round(cpu_s, 3), "digest": fingerprint, "experimental": event_flags is not None,
+            what = {"direct": "row sums of g^2 pushed from k_gradient and edge rows from k_project as posted peer writes, ||g|| "
+                              "reduced inside k_project: two launches and two event waits per band and iteration",
+                    "copy": "round 3's exchange: a copy kernel pulls the neighbours' edge rows, "
+                            + ("one band reduces ||g|| for all" if norm == "root" else "every band reduces ||g|| itself")
+                            + ": four launches per band and iteration",
+                    "rccl": "ncclAllGather of the row sums + grouped ncclSend / ncclRecv of the edge rows on the band streams "
+                            "(librccl dlopen()ed by the C library, one communicator per band)"}.get(how, how)
+            legs[name] = {"elapsed": elapsed, "g_ms": g_ms, "p_ms": p_ms, "samples": samples, "split": False,
+                          "host_cpu_s": round(cpu_s, 3), "digest": fingerprint, "exchange": how,
                           "parallelism": (f"row-tiled x{nband}: C engine (j2p_tiled), one process drives all GPUs, one host thread per "
-                                          "band; edge rows and norm row sums read over peer access, ordered by HIP events; "
-                                          + ("one band reduces ||g|| for all; " if norm == "root" else
-                                             "every band reduces ||g|| itself from all bands' row sums (one cross-GPU hop less, N - 1 waits); ")
-                                          + ("split phases (halo exchange behind the interior launches)" if split
-                                             else "one gradient and one projection launch per iteration"))}
+                                          f"band; exchange '{how}': {what}")}
         elif rank == 0:
             print(f"bench: C row tiling ({name}) unavailable: {ok[1]}", file=sys.stderr, flush=True)
             legs[name + "_error"] = ok[1]
         ranks.barrier()
 
     if want_c:
-        c_leg("c", False, digest=True)
-        if "c" in legs:
-            c_leg("c_split", True)
-            c_leg("c_allnorm", False, "all")
-            # an experiment the line reports but never scores: the tiling's events created with hipEventDisableSystemFence
-            # (4 us less per cross-stream dependency on one GPU, profiles/r03_tiled_event_flags.jsonl).  Without that fence
-            # HIP does not promise that a PEER GPU sees the rows an event covers; whether it does on this box shows in
-            # `bits_equal_to_the_default_schedule` (a hash of the resulting plane against leg c's)
-            c_leg("c_nofence_experiment", False, event_flags="20000000", digest=True)
+        c_leg("c")
+        c_leg("c_copy", "copy")
+        c_leg("c_rccl", "rccl")
 
     # ---- leg 2: one process per GPU over RCCL ----
     watchdog = None
@@ -573,12 +618,17 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
         """rank 0: assemble the JSON line from the legs measured so far"""
         if rank != 0:
             return
-        timed = {k: v for k, v in legs.items() if isinstance(v, dict) and "elapsed" in v and not v.get("experimental")}
+        timed = {k: v for k, v in legs.items() if isinstance(v, dict) and "elapsed" in v}
         if not timed and not strict:
             return
         if not timed:
             raise SystemExit("bench: no row-tiling engine could run: " + json.dumps({k: v for k, v in legs.items() if not isinstance(v, dict)}))
-        best = min(timed, key=lambda k: timed[k]["elapsed"])
+        # the truth: the whole-canvas solve's hash; without it (skipped / failed) the copy exchange's, round 3's engine
+        truth = (whole or {}).get("digest") or timed.get("c_copy", {}).get("digest")
+        for v in timed.values():
+            v["verified"] = None if (truth is None or v.get("digest") is None) else v["digest"] == truth
+        good = {k: v for k, v in timed.items() if v["verified"]} or {k: v for k, v in timed.items() if v["verified"] is None} or timed
+        best = min(good, key=lambda k: good[k]["elapsed"])
         L = timed[best]
         value = px * its * a.steps / L["elapsed"] / 1e6
         # pixels per TIMED launch: in the split schedules the events bracket the interior launches only
@@ -591,15 +641,11 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
                 continue
             others.append({"config": f"the same workload through the other engine ({k})", "parallelism": v["parallelism"],
                            "Mpx_it_per_s": round(px * its * a.steps / v["elapsed"] / 1e6, 1),
-                           "ms_per_step": round(v["elapsed"] / a.steps * 1e3, 3)})
+                           "ms_per_step": round(v["elapsed"] / a.steps * 1e3, 3),
+                           "bits_equal_to_the_whole_canvas_solve": v["verified"]})
         for k, v in legs.items():
             if not isinstance(v, dict):
                 others.append({"config": f"engine {k}", "error": v})
-            elif v.get("experimental") and "elapsed" in v:
-                others.append({"config": f"experiment, not scored ({k}): the C row tiling with events created with hipEventDisableSystemFence",
-                               "Mpx_it_per_s": round(px * its * a.steps / v["elapsed"] / 1e6, 1),
-                               "ms_per_step": round(v["elapsed"] / a.steps * 1e3, 3),
-                               "bits_equal_to_the_default_schedule": (v.get("digest") is not None and v.get("digest") == legs.get("c", {}).get("digest"))})
         others += extra_other or []
         gpus_used = n_gpus if n_gpus > 1 else 1
         out = {
@@ -610,7 +656,8 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
             "ms_per_step": round(L["elapsed"] / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "iterations_per_step": its, "weight": WEIGHT, "pweight": PWEIGHT,
-                       "parallelism": L["parallelism"], "engine": best, "band_threads_host_cpu_s": L.get("host_cpu_s")},
+                       "parallelism": L["parallelism"], "engine": best, "band_threads_host_cpu_s": L.get("host_cpu_s"),
+                       "bits_equal_to_the_whole_canvas_solve": L["verified"]},
             "roofline": roofline_object(value, gpus_used, its, L["elapsed"], a.steps, band_px, per_kernel, L["samples"], a.timing_every),
             "other_configs": others,
         }
@@ -674,15 +721,14 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
     # ---- the same canvas on ONE GPU, configs[4] over all GPUs, the CPU baseline (rank 0) ----
     if rank == 0 and state["out"] is not None and not a.no_other_configs:
         extra = []
-        try:
-            j.load_library().j2p_pool_trim()
-            r = whole_canvas_on_one_gpu(j, whole_plane, its, device=local_rank)
+        if whole is not None and "error" not in whole:
+            r = {k: v for k, v in whole.items() if k != "digest"}
             r["config"] = (f"strong-scaling denominator: the SAME {W}x{H} canvas solved whole on ONE GPU, -i {its} "
-                           "(value / this = speed-up of the tiling)")
+                           "(value / this = speed-up of the tiling; its plane's hash is what every leg is compared with)")
             r["speedup_of_the_tiled_run"] = round(state["out"]["value"] / r["Mpx_it_per_s"], 3)
             extra.append(r)
-        except Exception as e:          # noqa: BLE001
-            extra.append({"config": "strong-scaling denominator", "error": f"{type(e).__name__}: {e}"})
+        else:
+            extra.append({"config": "strong-scaling denominator", "error": (whole or {}).get("error", "not run")})
         try:
             devs = list(range(n_gpus)) if n_gpus > 1 and not one_device else [local_rank]
             r = batch_images_per_s(j, synth, devs, 256 if not a.size else 16, a.slots)

@@ -574,6 +574,61 @@ def log_rows_from_sums(nch, weight, pweight, sums):
     return np.array([[r.objective, r.prob_dist, r.tv, r.tv2] for r in rows[:n]], dtype=np.float64).reshape(n, 4)
 
 
+class _CCoef(ctypes.Structure):
+    """struct coef (jpeg2png.h:7-20, restated in include/jpeg2png_amd_compute.h)"""
+    _fields_ = [("h", ctypes.c_uint), ("w", ctypes.c_uint), ("h_samp", ctypes.c_uint), ("w_samp", ctypes.c_uint),
+                ("data", ctypes.c_void_p), ("fdata", ctypes.c_void_p), ("quant_table", ctypes.c_uint16 * 64)]
+
+
+def compute_c(planes, weight, pweight, iterations, device=0, repeat=1):
+    """The C drop-in itself — j2p_compute(), what compute() (compute.h:8) is behind its die() wrapper — called the way
+    the reference's decode_file() calls it (jpeg2png.c:141-152): planes that libc allocated (alloc_simd, utils.h:89-98),
+    the float plane freed and a new one handed back (compute.c:304-305, 455-461), no logger, no progress bar.
+    Returns (canvas planes of the last call, [seconds inside j2p_compute per call]): the host-to-host cost of the
+    boundary, pageable memory on both sides."""
+    import time
+    lib = load_library()
+    libc = ctypes.CDLL(None)
+    libc.aligned_alloc.restype = ctypes.c_void_p
+    libc.aligned_alloc.argtypes = [ctypes.c_size_t, ctypes.c_size_t]
+    libc.malloc.restype = ctypes.c_void_p
+    libc.malloc.argtypes = [ctypes.c_size_t]
+    libc.free.argtypes = [ctypes.c_void_p]
+    lib.j2p_compute.argtypes = [ctypes.c_int, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float,
+                                ctypes.c_void_p, ctypes.c_uint]
+    n = len(planes)
+    pw = (ctypes.c_float * n)(*[float(x) for x in pweight])
+    seconds, outs = [], None
+    for _ in range(repeat):
+        coefs = (_CCoef * n)()
+        for c, p in enumerate(planes):
+            if p.fdata is None:
+                raise J2PError("compute_c() expects decoded planes in fdata (jpeg.c:83-92); use decode_plane()")
+            d = np.ascontiguousarray(p.data, dtype=np.int16)
+            f = np.ascontiguousarray(p.fdata, dtype=np.float32)
+            coefs[c].w, coefs[c].h, coefs[c].w_samp, coefs[c].h_samp = p.w, p.h, p.w_samp, p.h_samp
+            coefs[c].data = libc.malloc(d.nbytes)
+            coefs[c].fdata = libc.aligned_alloc(16, (f.nbytes + 15) & ~15)
+            ctypes.memmove(coefs[c].data, d.ctypes.data, d.nbytes)
+            ctypes.memmove(coefs[c].fdata, f.ctypes.data, f.nbytes)
+            for k, q in enumerate(np.asarray(p.quant_table, dtype=np.uint16).reshape(64)):
+                coefs[c].quant_table[k] = int(q)
+        t0 = time.perf_counter()
+        rc = lib.j2p_compute(int(device), n, coefs, None, None, float(weight), pw, int(iterations))
+        seconds.append(time.perf_counter() - t0)
+        try:
+            _check(rc)
+            outs = []
+            for c in range(n):
+                a = np.ctypeslib.as_array(ctypes.cast(coefs[c].fdata, ctypes.POINTER(ctypes.c_float)), shape=(coefs[c].h, coefs[c].w))
+                outs.append(a.copy())
+        finally:
+            for c in range(n):
+                libc.free(coefs[c].fdata)              # free_simd, jpeg2png.c:169
+                libc.free(coefs[c].data)
+    return outs, seconds
+
+
 def compute(planes, weight, pweight, iterations, log=False, device=0):
     """Python twin of the reference's compute() (compute.h:8): same arguments and the same
     in/out convention — on return every plane's `fdata` is the W x H canvas plane and its

@@ -58,18 +58,32 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
                 rc = j2p_solver_create(&s, devices[0], NULL, nchannel, planes, weight, pweight, iterations, whole, 0);
         }
         if(rc != J2P_OK) { return rc; }
-        /* aux_init frees the input planes as soon as they are up-sampled (compute.c:304-305) */
-        for(unsigned c = 0; c < nchannel; c++) {
-                free(coefs[c].fdata);
-                coefs[c].fdata = NULL;
-        }
         const int want_log = log && log->f && logger_log;
         j2p_log_row rows[J2P_CHUNK];
+        float *outp[J2P_MAX_CHANNELS] = {NULL, NULL, NULL};
+        unsigned W = 0, H = 0;
+        if(t) { j2p_tiled_canvas(t, &W, &H, NULL); } else { j2p_solver_canvas(s, &W, &H); }
+        const size_t out_bytes = (sizeof(float) * (size_t)W * H + 15) & ~(size_t)15;
         unsigned done = 0;
+        int housekeeping = iterations == 0;    /* (no iterations: nothing to hide it behind, done below) */
         while(done < iterations) {
                 unsigned n = iterations - done;
                 if(n > J2P_CHUNK) { n = J2P_CHUNK; }
                 rc = t ? j2p_tiled_run(t, n, want_log ? rows : NULL) : j2p_solver_run(s, n, want_log ? rows : NULL);
+                if(rc == J2P_OK && !housekeeping) {
+                        /* While the GPU works on the first chunk (the run call only queues it unless log rows are wanted):
+                         * aux_init frees the input planes as soon as they are up-sampled (compute.c:304-305) — they are
+                         * on the device since create — and the planes compute() hands back (compute.c:455-461) are
+                         * allocated and their pages touched, so that the download at the end writes into mapped memory */
+                        housekeeping = 1;
+                        for(unsigned c = 0; c < nchannel; c++) {
+                                free(coefs[c].fdata);
+                                coefs[c].fdata = NULL;
+                                outp[c] = aligned_alloc(16, out_bytes);                /* alloc_simd, utils.h:89-98 */
+                                if(!outp[c]) { rc = J2P_ENOMEM; goto out; }
+                                for(size_t off = 0; off < out_bytes; off += 4096) { ((volatile char *)outp[c])[off] = 0; }
+                        }
+                }
                 if(rc == J2P_OK && !want_log && pb) { rc = t ? j2p_tiled_sync(t) : j2p_solver_sync(s); }
                 if(rc != J2P_OK) { goto out; }
                 for(unsigned i = 0; i < n; i++) {
@@ -83,19 +97,24 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
                 }
                 done += n;
         }
-        unsigned W = 0, H = 0;
-        if(t) { j2p_tiled_canvas(t, &W, &H, NULL); } else { j2p_solver_canvas(s, &W, &H); }
         for(unsigned c = 0; c < nchannel; c++) {
-                size_t bytes = sizeof(float) * (size_t)W * H;
-                float *plane = aligned_alloc(16, (bytes + 15) & ~(size_t)15);      /* alloc_simd, utils.h:89-98 */
-                if(!plane) { rc = J2P_ENOMEM; goto out; }
-                rc = t ? j2p_tiled_download(t, c, plane) : j2p_solver_download(s, c, plane);
-                if(rc != J2P_OK) { free(plane); goto out; }
-                coefs[c].fdata = plane;                                            /* compute.c:458 */
+                if(!outp[c]) {                                                     /* iterations == 0 */
+                        free(coefs[c].fdata);
+                        coefs[c].fdata = NULL;
+                        outp[c] = aligned_alloc(16, out_bytes);
+                        if(!outp[c]) { rc = J2P_ENOMEM; goto out; }
+                }
+                rc = t ? j2p_tiled_download(t, c, outp[c]) : j2p_solver_download(s, c, outp[c]);
+                if(rc != J2P_OK) { goto out; }
+        }
+        for(unsigned c = 0; c < nchannel; c++) {
+                coefs[c].fdata = outp[c];                                          /* compute.c:458 */
+                outp[c] = NULL;
                 coefs[c].w = W;                                                    /* compute.c:459-460 */
                 coefs[c].h = H;
         }
 out:
+        for(unsigned c = 0; c < nchannel; c++) { free(outp[c]); }
         if(t) { j2p_tiled_destroy(t); }
         if(s) { j2p_solver_destroy(s); }
         return rc;

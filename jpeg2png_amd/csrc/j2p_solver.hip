@@ -97,6 +97,7 @@ struct j2p_solver {
         bool fold = false;       // norm reduction folded into k_gradient (J2P_OPT_NORM_FOLD); default: band solvers only
         bool joint_inwave = false;   // J2P_OPT_JOINT_INWAVE
         bool norm_in_project = false;   // J2P_OPT_NORM_IN_PROJECT (with fold): level 2 of the norm inside k_project
+        int nip_form = 1;               // ... by every wavefront (1: small canvases) or by the workgroup's first (2), see project_strip
         int nt = 0;                     // 0..3: streams with the non-temporal hint (nt_policy; J2P_OPT_NT_GRADIENT)
         bool nt_forced = false;         // set through J2P_OPT_NT_GRADIENT: the policy no longer touches it
         bool live_registered = false;   // this solver's bytes are part of the device's live total (nt_policy)
@@ -691,7 +692,7 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
         a.norm_rowsums = nip2 ? global_rows : (s->norm_by_project ? s->rowsum_local : nullptr);
         a.norm_rows = s->ntr_global;
         a.norm_nch = s->nch;
-        const int nip = nip2 ? 2 : (s->norm_by_project ? 1 : 0);
+        const int nip = nip2 ? 2 : (s->norm_by_project ? s->nip_form : 0);
         for(unsigned c = 0; c < kMaxCh; c++) { a.halo_up[c] = a.halo_down[c] = nullptr; }
         if(s->linked) {
                 // the band's edge rows of x_{k+1} also go into the neighbours' halo rows of the buffer being written
@@ -714,6 +715,7 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
         bool mixed = false;
         for(unsigned c = 1; c < s->nch; c++) { mixed = mixed || s->ch[c].ws != s->ch[0].ws || s->ch[c].hs != s->ch[0].hs; }
         if(mixed && s->mixed_project && nip != 2 && (size_t)s->W * s->rows <= kMixedProjectPixels) {
+                // (k_project_mixed has the per-wavefront tree only; canvases this small take that form anyway)
                 // small canvas, several samplings: one launch for all channels (k_project_mixed)
                 unsigned max_strips = 0;
                 for(unsigned c = 0; c < s->nch; c++) {
@@ -849,7 +851,11 @@ void j2p_solver_destroy(j2p_solver *s)
         delete s;
 }
 
-void j2p_pool_trim(void) { pool_drop_all(); }
+void j2p_pool_trim(void)
+{
+        pool_drop_all();
+        j2p_xfer_trim();        // the pinned staging slabs of the large host copies too
+}
 
 int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchannel, const j2p_plane planes[],
                       float weight, const float pweight[], unsigned iterations, j2p_band band, int band_local_arrays)
@@ -1102,11 +1108,11 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 if(h.crows) {
                         // block-major: coefficient row r lives in block row r/8; rows are block aligned
                         const int16_t *src = p.data + (size_t)(h.crow0 - host_row0) * h.cw;
-                        CREATE_TRY(hipMemcpyAsync(h.d, src, (size_t)h.crows * h.cw * sizeof(int16_t), hipMemcpyHostToDevice, s->stream));
+                        CREATE_TRY(j2p_upload_plane(device, h.d, src, (size_t)h.crows * h.cw * sizeof(int16_t), s->stream));
                 }
                 if(p.fdata) {
                         const float *src = p.fdata + (size_t)(h.frow0 - host_row0) * h.cw;
-                        CREATE_TRY(hipMemcpyAsync(h.decoded, src, (size_t)h.frows * h.cw * sizeof(float), hipMemcpyHostToDevice, s->stream));
+                        CREATE_TRY(j2p_upload_plane(device, h.decoded, src, (size_t)h.frows * h.cw * sizeof(float), s->stream));
                 } else {
                         // decode on the device (jpeg.c:83-92 + box.c:5-19): whole block rows [b0, b1) of the input
                         // window.  Band rows are block aligned, so when the window has no halo rows (band_local, or
@@ -1127,7 +1133,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                                 }
                                 int16_t *dtmp = h.scratch_d ? h.scratch_d : reinterpret_cast<int16_t *>(h.xbuf[0]);
                                 const int16_t *src = p.data + (size_t)(b0 * 8 - host_row0) * h.cw;
-                                CREATE_TRY(hipMemcpyAsync(dtmp, src, (size_t)nb_rows * 8 * h.cw * sizeof(int16_t), hipMemcpyHostToDevice, s->stream));
+                                CREATE_TRY(j2p_upload_plane(device, dtmp, src, (size_t)nb_rows * 8 * h.cw * sizeof(int16_t), s->stream));
                                 dsrc = dtmp;
                         }
                         if(h.frow0 == b0 * 8 && h.frows == nb_rows * 8) {
@@ -1171,7 +1177,11 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
                 if(value && s->px == 1) { return fail(J2P_ESTATE, "the in-wavefront joint kernel has no one-column-per-lane form (set J2P_JOINT_INWAVE=1 before the solver is created)"); }
                 s->joint_inwave = value != 0;
                 break;
-        case J2P_OPT_NORM_IN_PROJECT: s->norm_in_project = value != 0; break;
+        case J2P_OPT_NORM_IN_PROJECT:
+                // 0: off; 1: the per-wavefront tree; 2: the per-workgroup tree; (needs NORM_FOLD)
+                s->norm_in_project = value != 0;
+                s->nip_form = value == 2 ? 2 : 1;
+                break;
         case J2P_OPT_NT_GRADIENT:
                 s->nt_forced = value >= 0;                 // negative: back to the policy
                 s->nt = value < 0 ? nt_policy(s) : (value > 3 ? 3 : value);
@@ -1615,8 +1625,7 @@ int j2p_solver_download(j2p_solver *s, unsigned c, float *out)
         if(s->grad_done) { return fail(J2P_ESTATE, "download between the two phases of an iteration"); }
         DeviceGuard guard(s->device);
         const float *src = s->ch[c].xbuf[s->cur] + (size_t)kHalo * s->W;
-        HIP_TRY(hipMemcpyAsync(out, src, (size_t)s->rows * s->W * sizeof(float), hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(j2p_download_plane(s->device, out, src, (size_t)s->rows * s->W * sizeof(float), s->stream));
         return J2P_OK;
 }
 

@@ -235,13 +235,17 @@ class RowTiledSolver:
             except Exception as ex:                       # noqa: BLE001 — any failure means "use torch's path"
                 import sys
                 print(f"jpeg2png_amd.tiled: direct RCCL unavailable ({ex}); using torch.distributed", file=sys.stderr)
+        # a CPU-only process group (gloo) under a GPU engine: both exchanges are staged through host memory — several
+        # processes on real kernels without RCCL (two ranks sharing one GPU in tests/test_tiled_multiprocess_gpu.py)
+        self.host_staged = dist.get_backend(group) == "gloo" and engine.partials_local.device.type != "cpu"
         counts = torch.zeros(self.world, dtype=torch.int64)
         counts[self.rank] = engine.local_tile_rows
-        counts = counts.to(engine.partials_local.device)
+        if not self.host_staged:
+            counts = counts.to(engine.partials_local.device)
         dist.all_reduce(counts, group=group)
         self.counts = [int(x) for x in counts.cpu()]
         self.equal = len(set(self.counts)) == 1
-        if not self.equal:
+        if not self.equal and not self.host_staged:
             self._stage = torch.zeros(self.world * max(self.counts) * engine.nch, dtype=torch.float64,
                                       device=engine.partials_local.device)
             self._pad = torch.zeros(max(self.counts) * engine.nch, dtype=torch.float64,
@@ -253,6 +257,15 @@ class RowTiledSolver:
         if self.world == 1 and not self.self_neighbours:
             if e.partials_all.data_ptr() != e.partials_local.data_ptr():
                 e.partials_all.copy_(e.partials_local)
+            return
+        if self.host_staged:
+            # device -> host (synchronises the solver's stream), gloo all-gather of equal-size padded pieces, host -> device
+            m = max(self.counts) * e.nch
+            mine = torch.zeros(m, dtype=torch.float64)
+            mine[: e.partials_local.numel()] = e.partials_local.cpu()
+            pieces = [torch.zeros(m, dtype=torch.float64) for _ in range(self.world)]
+            dist.all_gather(pieces, mine, group=self.group)
+            e.partials_all.copy_(torch.cat([pieces[r][: self.counts[r] * e.nch] for r in range(self.world)]))
             return
         if self.equal and self.direct is not None:
             self.direct.all_gather(e.partials_local.data_ptr(), e.partials_all.data_ptr(), e.partials_local.numel(),
@@ -281,7 +294,11 @@ class RowTiledSolver:
                 grown[: self._logged] = self._logbuf[: self._logged]
             self._logbuf = grown
         dst = self._logbuf[self._logged]
-        if self.world == 1 and not self.self_neighbours:
+        if self.host_staged:
+            pieces = [torch.zeros(k, dtype=torch.float64) for _ in range(self.world)]
+            dist.all_gather(pieces, e.log_local.cpu(), group=self.group)
+            dst.copy_(torch.stack(pieces))
+        elif self.world == 1 and not self.self_neighbours:
             dst[0].copy_(e.log_local)
         elif self.direct is not None:
             self.direct.all_gather(e.log_local.data_ptr(), dst.data_ptr(), k,
@@ -321,6 +338,20 @@ class RowTiledSolver:
             self._ops[key] = (ops, h)     # keep the views alive
         else:
             ops = ops[0]
+        if self.host_staged:
+            host_ops, landing = [], []
+            for op in ops:
+                if op.op is dist.isend:
+                    host_ops.append(dist.P2POp(dist.isend, op.tensor.cpu(), op.peer, self.group))
+                else:
+                    buf = torch.empty(op.tensor.numel(), dtype=op.tensor.dtype)
+                    landing.append((op.tensor, buf))
+                    host_ops.append(dist.P2POp(dist.irecv, buf, op.peer, self.group))
+            for w in dist.batch_isend_irecv(host_ops):
+                w.wait()
+            for dev, buf in landing:
+                dev.copy_(buf)
+            return
         if self.direct is not None:
             sends = [(op.tensor.data_ptr(), op.tensor.numel(), op.peer) for op in ops if op.op is dist.isend]
             recvs = [(op.tensor.data_ptr(), op.tensor.numel(), op.peer) for op in ops if op.op is dist.irecv]

@@ -577,7 +577,9 @@ def test_every_schedule_switch_leaves_the_bits_alone(lib, oracle, shape, monkeyp
         {},                                                                         # the solver's own choice
         {j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 0},                     # stand-alone norm kernel
         {j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 1},                     # both levels inside k_gradient
-        {j.J2P_OPT_NORM_FOLD: 1, j.J2P_OPT_NORM_IN_PROJECT: 1},                     # level 2 inside k_project
+        {j.J2P_OPT_NORM_FOLD: 1, j.J2P_OPT_NORM_IN_PROJECT: 1},                     # level 2 inside k_project, every wavefront
+        {j.J2P_OPT_NORM_FOLD: 1, j.J2P_OPT_NORM_IN_PROJECT: 2, j.J2P_OPT_MIXED_PROJECT: 0},   # ... the workgroup's first wavefront
+        {j.J2P_OPT_NORM_FOLD: 1, j.J2P_OPT_NORM_IN_PROJECT: 2, j.J2P_OPT_MIXED_PROJECT: 0, j.J2P_OPT_NT_GRADIENT: 3},
         {j.J2P_OPT_NT_GRADIENT: 1},                                                 # what working sets beyond the Infinity Cache get:
         {j.J2P_OPT_NT_GRADIENT: 2},                                                 # g / + prob state / + coefficients non-temporal
         {j.J2P_OPT_NT_GRADIENT: 3},

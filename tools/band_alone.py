@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""What the split phases of the C row tiling cost a band that has a GPU to itself — the figure that decides the
-multi-GPU efficiency, measurable on ONE GPU: a 2048-row band of the 16384-wide plane next to a 48-row band (which
-is idle almost all the time), against the same rows solved whole.  J2P_TILED_SIDE=0 puts the edge work back in line
-on the band's stream (round 2's schedule)."""
+"""What the cross-band schedule of the C row tiling costs a band that has a GPU to itself — the figure that decides
+the multi-GPU efficiency, measurable on ONE GPU: a 2048-row band of the 16384-wide plane next to a 48-row band (which
+is idle almost all the time), against the same rows solved whole.  J2P_TILED_EXCHANGE=direct|copy (and
+J2P_TILED_NORM=all with copy) select the schedule."""
 import json
 import os
 import sys
@@ -24,9 +24,9 @@ def timed(fn, reps=3):
     return (time.perf_counter() - t0) / reps
 
 
-res = {"split": os.environ.get("J2P_TILED_SPLIT", "default"), "side_stream": os.environ.get("J2P_TILED_SIDE", "default"),
-       "norm": os.environ.get("J2P_TILED_NORM", "default")}
+res = {"norm": os.environ.get("J2P_TILED_NORM", "default")}
 with j.TiledSolver([p], 0.3, [0.001], its, devices=[0, 0], cuts=[0, 2048, 2096]) as t:
+    res["exchange"] = t.exchange()
     def run():
         t.reset()
         t.run(its)
