@@ -300,8 +300,8 @@ def host_to_host(j, planes, its, resident_ms, device=0, reps=3):
             "Mpx_it_per_s": round(px * its / (med * 1e-3) / 1e6, 1),
             "what": "j2p_compute() (the C drop-in behind compute(), compute.h:8) from libc-allocated pageable planes: upload of the "
                     "int16 coefficients and the decoded float plane, aux_init, all iterations, download into a newly allocated "
-                    "plane; staged through pinned slabs by a few host threads (j2p_xfer.hip), the input planes freed and the "
-                    "output pages touched while the GPU iterates"}
+                    "plane; the whole iteration loop is queued at once and the input planes are freed / the output pages touched by a helper "
+                    "thread while the GPU iterates (compute_host.c)"}
 
 
 def bench_batch(a, j, synth):

@@ -37,7 +37,7 @@ def _newer(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-HIP_UNITS = ("j2p_solver.hip", "j2p_tiled.hip", "j2p_batch.hip", "j2p_xfer.hip")
+HIP_UNITS = ("j2p_solver.hip", "j2p_tiled.hip", "j2p_batch.hip")
 HEADERS = ("j2p_kernels.hip.h", "j2p_internal.h")
 
 

@@ -4,12 +4,14 @@
  * Plain C like the reference's host code; the device work is entirely behind
  * j2p_solver_* (include/jpeg2png_amd.h).
  */
+#define _POSIX_C_SOURCE 200809L        /* clock_gettime under -std=c11 */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
 #include <assert.h>
 #include <pthread.h>
+#include <time.h>
 
 #include "jpeg2png_amd.h"
 #include "jpeg2png_amd_compute.h"
@@ -31,6 +33,40 @@ extern void progressbar_inc(struct progressbar *pb) __attribute__((weak));
  * `jpeg2png: ` prefix goes out.  Used when the host has it, so that a failure in here reads like one of its own. */
 extern void die_message_start(void) __attribute__((weak));
 
+/* J2P_COMPUTE_TIMING=1: one line on stderr per call with where its wall time went (create = upload + aux_init issue,
+ * housekeeping = freeing the inputs and preparing the output planes while the GPU iterates, wait = until the last
+ * iteration has finished, download, destroy) — the host-to-host figure of bench.py taken apart */
+static double now_ms(void)
+{
+        struct timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+
+struct housekeeping {
+        unsigned nchannel;
+        struct coef *coefs;
+        size_t out_bytes;
+        float *out[J2P_MAX_CHANNELS];
+        int failed;
+        double ms;
+};
+
+static void *housekeeping_main(void *arg)
+{
+        struct housekeeping *h = arg;
+        const double t0 = now_ms();
+        for(unsigned c = 0; c < h->nchannel; c++) {
+                free(h->coefs[c].fdata);                                           /* compute.c:304-305 */
+                h->coefs[c].fdata = NULL;
+                h->out[c] = aligned_alloc(16, h->out_bytes);                       /* alloc_simd, utils.h:89-98 */
+                if(!h->out[c]) { h->failed = 1; continue; }
+                for(size_t off = 0; off < h->out_bytes; off += 4096) { ((volatile char *)h->out[c])[off] = 0; }
+        }
+        h->ms = now_ms() - t0;
+        return NULL;
+}
+
 /* The loop of compute.c:427-453 over either engine: one j2p_solver (whole canvas on one GPU) or one j2p_tiled
  * (row bands over several GPUs).  Same chunking, callbacks and hand-back either way. */
 static int compute_on(unsigned nband, const int devices[], unsigned nchannel, struct coef coefs[], struct logger *log,
@@ -51,6 +87,10 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
         j2p_solver *s = NULL;
         j2p_tiled *t = NULL;
         int rc;
+        const char *timing_env = getenv("J2P_COMPUTE_TIMING");
+        const int timing = timing_env && atoi(timing_env) != 0;
+        double t_mark[6] = {0., 0., 0., 0., 0., 0.}, t_house = 0.;
+        t_mark[0] = now_ms();
         if(nband > 1) {
                 rc = j2p_tiled_create(&t, nband, devices, NULL, nchannel, planes, weight, pweight, iterations);
         } else {
@@ -58,37 +98,37 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
                 rc = j2p_solver_create(&s, devices[0], NULL, nchannel, planes, weight, pweight, iterations, whole, 0);
         }
         if(rc != J2P_OK) { return rc; }
+        t_mark[1] = now_ms();
         const int want_log = log && log->f && logger_log;
         j2p_log_row rows[J2P_CHUNK];
-        float *outp[J2P_MAX_CHANNELS] = {NULL, NULL, NULL};
         unsigned W = 0, H = 0;
         if(t) { j2p_tiled_canvas(t, &W, &H, NULL); } else { j2p_solver_canvas(s, &W, &H); }
-        const size_t out_bytes = (sizeof(float) * (size_t)W * H + 15) & ~(size_t)15;
+        /* While the GPU iterates, a helper thread does what the host owes the caller: aux_init frees the input planes
+         * as soon as they are up-sampled (compute.c:304-305) — they are on the device since create — and the planes
+         * compute() hands back (compute.c:455-461) are allocated and their pages touched, so that the download at the
+         * end writes into mapped memory.  (In line, between two chunks of iterations, those ~12 ms for a 64 MiB plane
+         * left the GPU idle: it runs 32 iterations in 4.) */
+        struct housekeeping hk;
+        hk.nchannel = nchannel;
+        hk.coefs = coefs;
+        hk.out_bytes = (sizeof(float) * (size_t)W * H + 15) & ~(size_t)15;
+        hk.failed = 0;
+        hk.ms = 0.;
+        for(unsigned c = 0; c < J2P_MAX_CHANNELS; c++) { hk.out[c] = NULL; }
+        pthread_t hk_thread;
+        int hk_started = pthread_create(&hk_thread, NULL, housekeeping_main, &hk) == 0;
+        if(!hk_started) { housekeeping_main(&hk); }
         unsigned done = 0;
-        int housekeeping = iterations == 0;    /* (no iterations: nothing to hide it behind, done below) */
         while(done < iterations) {
                 unsigned n = iterations - done;
-                if(n > J2P_CHUNK) { n = J2P_CHUNK; }
+                /* nothing to report between chunks: the whole loop goes to the device queue at once */
+                if(n > J2P_CHUNK && (want_log || pb)) { n = J2P_CHUNK; }
                 rc = t ? j2p_tiled_run(t, n, want_log ? rows : NULL) : j2p_solver_run(s, n, want_log ? rows : NULL);
-                if(rc == J2P_OK && !housekeeping) {
-                        /* While the GPU works on the first chunk (the run call only queues it unless log rows are wanted):
-                         * aux_init frees the input planes as soon as they are up-sampled (compute.c:304-305) — they are
-                         * on the device since create — and the planes compute() hands back (compute.c:455-461) are
-                         * allocated and their pages touched, so that the download at the end writes into mapped memory */
-                        housekeeping = 1;
-                        for(unsigned c = 0; c < nchannel; c++) {
-                                free(coefs[c].fdata);
-                                coefs[c].fdata = NULL;
-                                outp[c] = aligned_alloc(16, out_bytes);                /* alloc_simd, utils.h:89-98 */
-                                if(!outp[c]) { rc = J2P_ENOMEM; goto out; }
-                                for(size_t off = 0; off < out_bytes; off += 4096) { ((volatile char *)outp[c])[off] = 0; }
-                        }
-                }
                 if(rc == J2P_OK && !want_log && pb) { rc = t ? j2p_tiled_sync(t) : j2p_solver_sync(s); }
-                if(rc != J2P_OK) { goto out; }
-                for(unsigned i = 0; i < n; i++) {
+                if(rc != J2P_OK) { break; }
+                for(unsigned i = 0; i < n && (log || pb); i++) {
                         if(log) { log->iteration = done + i; }                     /* compute.c:428 */
-                        if(want_log) { logger_log(log, rows[i].objective, rows[i].prob_dist, rows[i].tv, rows[i].tv2); }
+                        if(want_log) { logger_log(log, rows[i % J2P_CHUNK].objective, rows[i % J2P_CHUNK].prob_dist, rows[i % J2P_CHUNK].tv, rows[i % J2P_CHUNK].tv2); }
                         if(pb && progressbar_inc) {
                                 pthread_mutex_lock(&progress_lock);
                                 progressbar_inc(pb);                               /* compute.c:449-452 */
@@ -97,13 +137,15 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
                 }
                 done += n;
         }
+        if(hk_started) { pthread_join(hk_thread, NULL); }
+        t_house = hk.ms;
+        float **outp = hk.out;
+        if(rc == J2P_OK && hk.failed) { rc = J2P_ENOMEM; }
+        if(rc != J2P_OK) { goto out; }
+        t_mark[2] = now_ms();
+        if(timing) { rc = t ? j2p_tiled_sync(t) : j2p_solver_sync(s); if(rc != J2P_OK) { goto out; } }
+        t_mark[3] = now_ms();
         for(unsigned c = 0; c < nchannel; c++) {
-                if(!outp[c]) {                                                     /* iterations == 0 */
-                        free(coefs[c].fdata);
-                        coefs[c].fdata = NULL;
-                        outp[c] = aligned_alloc(16, out_bytes);
-                        if(!outp[c]) { rc = J2P_ENOMEM; goto out; }
-                }
                 rc = t ? j2p_tiled_download(t, c, outp[c]) : j2p_solver_download(s, c, outp[c]);
                 if(rc != J2P_OK) { goto out; }
         }
@@ -114,9 +156,16 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
                 coefs[c].h = H;
         }
 out:
-        for(unsigned c = 0; c < nchannel; c++) { free(outp[c]); }
+        t_mark[4] = now_ms();
+        for(unsigned c = 0; c < nchannel; c++) { free(hk.out[c]); }
         if(t) { j2p_tiled_destroy(t); }
         if(s) { j2p_solver_destroy(s); }
+        t_mark[5] = now_ms();
+        if(timing && rc == J2P_OK) {
+                fprintf(stderr, "j2p compute timing (ms): create %.2f, issue %.2f (beside it, on a helper thread: housekeeping %.2f), wait %.2f, download %.2f, destroy %.2f, total %.2f\n",
+                        t_mark[1] - t_mark[0], t_mark[2] - t_mark[1], t_house, t_mark[3] - t_mark[2], t_mark[4] - t_mark[3],
+                        t_mark[5] - t_mark[4], t_mark[5] - t_mark[0]);
+        }
         return rc;
 }
 

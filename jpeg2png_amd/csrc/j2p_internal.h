@@ -12,11 +12,3 @@ int j2p_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)
 void j2p_rows_from_sums_carry(unsigned nch, float weight, const float *pweight, unsigned n, const double *sums,
                               double *carried, bool carried_valid, j2p_log_row *rows);
 
-// large copies between the caller's (pageable) planes and device memory, staged by a few host threads through cached
-// pinned slabs (j2p_xfer.hip); small copies take hipMemcpyAsync on `stream`.  upload: the host array is consumed on
-// return (team path: and the bytes are on the device); download: after everything queued on `stream`, complete on return
-#ifdef __HIP__
-hipError_t j2p_upload_plane(int device, void *dev, const void *host, size_t bytes, hipStream_t stream);
-hipError_t j2p_download_plane(int device, void *host, const void *dev, size_t bytes, hipStream_t stream);
-#endif
-void j2p_xfer_trim(void);

@@ -851,11 +851,7 @@ void j2p_solver_destroy(j2p_solver *s)
         delete s;
 }
 
-void j2p_pool_trim(void)
-{
-        pool_drop_all();
-        j2p_xfer_trim();        // the pinned staging slabs of the large host copies too
-}
+void j2p_pool_trim(void) { pool_drop_all(); }
 
 int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchannel, const j2p_plane planes[],
                       float weight, const float pweight[], unsigned iterations, j2p_band band, int band_local_arrays)
@@ -1108,11 +1104,11 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 if(h.crows) {
                         // block-major: coefficient row r lives in block row r/8; rows are block aligned
                         const int16_t *src = p.data + (size_t)(h.crow0 - host_row0) * h.cw;
-                        CREATE_TRY(j2p_upload_plane(device, h.d, src, (size_t)h.crows * h.cw * sizeof(int16_t), s->stream));
+                        CREATE_TRY(hipMemcpyAsync(h.d, src, (size_t)h.crows * h.cw * sizeof(int16_t), hipMemcpyHostToDevice, s->stream));
                 }
                 if(p.fdata) {
                         const float *src = p.fdata + (size_t)(h.frow0 - host_row0) * h.cw;
-                        CREATE_TRY(j2p_upload_plane(device, h.decoded, src, (size_t)h.frows * h.cw * sizeof(float), s->stream));
+                        CREATE_TRY(hipMemcpyAsync(h.decoded, src, (size_t)h.frows * h.cw * sizeof(float), hipMemcpyHostToDevice, s->stream));
                 } else {
                         // decode on the device (jpeg.c:83-92 + box.c:5-19): whole block rows [b0, b1) of the input
                         // window.  Band rows are block aligned, so when the window has no halo rows (band_local, or
@@ -1133,7 +1129,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                                 }
                                 int16_t *dtmp = h.scratch_d ? h.scratch_d : reinterpret_cast<int16_t *>(h.xbuf[0]);
                                 const int16_t *src = p.data + (size_t)(b0 * 8 - host_row0) * h.cw;
-                                CREATE_TRY(j2p_upload_plane(device, dtmp, src, (size_t)nb_rows * 8 * h.cw * sizeof(int16_t), s->stream));
+                                CREATE_TRY(hipMemcpyAsync(dtmp, src, (size_t)nb_rows * 8 * h.cw * sizeof(int16_t), hipMemcpyHostToDevice, s->stream));
                                 dsrc = dtmp;
                         }
                         if(h.frow0 == b0 * 8 && h.frows == nb_rows * 8) {
@@ -1625,7 +1621,8 @@ int j2p_solver_download(j2p_solver *s, unsigned c, float *out)
         if(s->grad_done) { return fail(J2P_ESTATE, "download between the two phases of an iteration"); }
         DeviceGuard guard(s->device);
         const float *src = s->ch[c].xbuf[s->cur] + (size_t)kHalo * s->W;
-        HIP_TRY(j2p_download_plane(s->device, out, src, (size_t)s->rows * s->W * sizeof(float), s->stream));
+        HIP_TRY(hipMemcpyAsync(out, src, (size_t)s->rows * s->W * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
         return J2P_OK;
 }
 
