@@ -63,7 +63,8 @@ BYTES_GRADIENT = 16              # per canvas pixel per launch (SURVEY.md §8d, 
 BYTES_PROJECT = 22               # phase B
 BYTES_ITERATION = BYTES_GRADIENT + BYTES_PROJECT
 WEIGHT, PWEIGHT = 0.3, 0.001     # jpeg2png.c:22-23 defaults
-RCCL_LEG_TIMEOUT_S = 240         # watchdog of the second (RCCL) leg of an N > 1 run
+RCCL_LEG_TIMEOUT_S = 240         # watchdog of the Python RCCL harness leg of an N > 1 run
+C_LEG_TIMEOUT_S = 300            # ... and of each child process that runs one leg of the C row tiling
 
 
 def parse():
@@ -415,7 +416,7 @@ def per_kernel_roofline(px_gradient, px_project, g_ms, p_ms):
 def pmc_traffic():
     """HBM bytes per iteration from the rocprofv3 PMC passes of the N = 1 workload (profiles/, corrected as
     MI355X_MICROARCH.md prescribes)"""
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json")
         if not os.path.exists(pmc):
             continue
@@ -484,7 +485,7 @@ def single_gpu(a, j, synth, local_rank):
         "roofline": roofline_object(value, 1, its, elapsed, a.steps, px, per_kernel, samples, a.timing_every, traffic, traffic_src),
     }
     solver.close()
-    if not a.no_host_to_host:
+    if not a.no_host_to_host and not a.size:
         try:
             planes = synth.make_planes(W, H, "444", 10, seed=seed, y_only=True)
             out["host_to_host"] = host_to_host(j, planes, its, elapsed / a.steps * 1e3, device=local_rank)
@@ -549,57 +550,59 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
             whole = {"error": f"{type(e).__name__}: {e}"}
     ranks.barrier()
 
-    # ---- legs 1: the C engine, driven by rank 0, in each of its exchanges (j2p_tiled.hip) ----
+    # ---- legs 1: the C engine in each of its exchanges (j2p_tiled.hip).  Rank 0 runs every leg in a CHILD process (this
+    # file with --leg-child): none of the exchanges has met real multi-GPU hardware before the driver's run, and a leg
+    # that hangs or dies there must cost its own figure, not the line.  The other ranks have nothing to do in these
+    # legs (one process drives all GPUs) and wait in the CPU barrier; the child does its own W warm-up and K timed
+    # steps between device synchronisations. ----
+    plane_file = f"{tag}_whole.npy"
+    if rank == 0 and want_c:
+        np.save(plane_file, whole_plane.data)
+
     def c_leg(name, exchange=None, norm="root"):
-        ok = [True, ""]
-        tsolver = eng = None
-        how = ""
         if rank == 0:
+            devices = list(range(n_gpus)) if n_gpus > 1 and not one_device else [local_rank] * nband
+            spec = {"plane": plane_file, "W": W, "H": H, "quant": [int(q) for q in np.asarray(whole_plane.quant_table).reshape(-1)],
+                    "its": its, "devices": devices, "warmup": a.warmup, "steps": a.steps, "timing_every": a.timing_every}
+            env = dict(os.environ, J2P_TILED_NORM=norm)
+            env.pop("J2P_TILED_EXCHANGE", None)
+            if exchange:
+                env["J2P_TILED_EXCHANGE"] = exchange                  # read by j2p_tiled_create
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+                env.pop(k, None)
+            import subprocess
             try:
-                if exchange:
-                    os.environ["J2P_TILED_EXCHANGE"] = exchange      # read by j2p_tiled_create
-                os.environ["J2P_TILED_NORM"] = norm
-                devices = list(range(n_gpus)) if n_gpus > 1 and not one_device else [local_rank] * nband
-                tsolver = j.TiledSolver([whole_plane], WEIGHT, [PWEIGHT], its, devices=devices)
-                eng = tsolver.band_solver(0)
-                how = tsolver.exchange()
-            except Exception as e:      # noqa: BLE001  (no peer access between the GPUs, no librccl, a device this process cannot open ...)
-                ok = [False, f"{type(e).__name__}: {e}"]
-            finally:
-                os.environ.pop("J2P_TILED_EXCHANGE", None)
-                os.environ.pop("J2P_TILED_NORM", None)
-        ok = ranks.share(ok)
-        if ok[0]:
-            if rank == 0:
-                reset, solve, sync = tsolver.reset, (lambda: tsolver.run(its)), tsolver.sync
-            else:
-                reset = solve = sync = (lambda: None)
-            elapsed, g_ms, p_ms, samples = time_steps(ranks, reset, solve, sync, a.warmup, a.steps, eng, a.timing_every)
-            cpu_s = tsolver.host_cpu_seconds() if rank == 0 else 0.0
-            fingerprint = None
-            if rank == 0:
-                fingerprint = plane_digest(tsolver.download(0))      # the plane the last timed step left behind
-                tsolver.close()
-            what = {"direct": "row sums of g^2 pushed from k_gradient and edge rows from k_project as posted peer writes, ||g|| "
-                              "reduced inside k_project: two launches and two event waits per band and iteration",
-                    "copy": "round 3's exchange: a copy kernel pulls the neighbours' edge rows, "
-                            + ("one band reduces ||g|| for all" if norm == "root" else "every band reduces ||g|| itself")
-                            + ": four launches per band and iteration",
-                    "rccl": "ncclAllGather of the row sums + grouped ncclSend / ncclRecv of the edge rows on the band streams "
-                            "(librccl dlopen()ed by the C library, one communicator per band)"}.get(how, how)
-            legs[name] = {"elapsed": elapsed, "g_ms": g_ms, "p_ms": p_ms, "samples": samples, "split": False,
-                          "host_cpu_s": round(cpu_s, 3), "digest": fingerprint, "exchange": how,
-                          "parallelism": (f"row-tiled x{nband}: C engine (j2p_tiled), one process drives all GPUs, one host thread per "
-                                          f"band; exchange '{how}': {what}")}
-        elif rank == 0:
-            print(f"bench: C row tiling ({name}) unavailable: {ok[1]}", file=sys.stderr, flush=True)
-            legs[name + "_error"] = ok[1]
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg-child", json.dumps(spec)], env=env,
+                                   capture_output=True, text=True, timeout=C_LEG_TIMEOUT_S)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("LEG ")]
+                if r.returncode != 0 or not line:
+                    raise RuntimeError(f"exit code {r.returncode}: " + (r.stderr.strip().splitlines() or ["no output"])[-1][:300])
+                res = json.loads(line[-1][4:])
+                if "error" in res:
+                    raise RuntimeError(res["error"])
+                how = res["exchange"]
+                what = {"direct": "row sums of g^2 pushed from k_gradient and edge rows from k_project as posted peer writes, ||g|| "
+                                  "reduced inside k_project: two launches and two event waits per band and iteration",
+                        "copy": "round 3's exchange: a copy kernel pulls the neighbours' edge rows, "
+                                + ("one band reduces ||g|| for all" if norm == "root" else "every band reduces ||g|| itself")
+                                + ": four launches per band and iteration",
+                        "rccl": "ncclAllGather of the row sums + grouped ncclSend / ncclRecv of the edge rows on the band streams "
+                                "(librccl dlopen()ed by the C library, one communicator per band)"}.get(how, how)
+                legs[name] = {"elapsed": res["elapsed"], "g_ms": res["g_ms"], "p_ms": res["p_ms"], "samples": res["samples"], "split": False,
+                              "host_cpu_s": res["host_cpu_s"], "digest": res["digest"], "exchange": how,
+                              "parallelism": (f"row-tiled x{nband}: C engine (j2p_tiled), one process drives all GPUs, one host thread per "
+                                              f"band; exchange '{how}': {what}")}
+            except subprocess.TimeoutExpired:
+                legs[name + "_error"] = f"no result within {C_LEG_TIMEOUT_S} s (child process killed)"
+            except Exception as e:      # noqa: BLE001  (no peer access between the GPUs, no librccl, a fault on first contact ...)
+                legs[name + "_error"] = f"{type(e).__name__}: {e}"
+            if name + "_error" in legs:
+                print(f"bench: C row tiling ({name}) gave no figure: {legs[name + '_error']}", file=sys.stderr, flush=True)
         ranks.barrier()
 
     if want_c:
         c_leg("c")
         c_leg("c_copy", "copy")
-        c_leg("c_rccl", "rccl")
 
     # ---- leg 2: one process per GPU over RCCL ----
     watchdog = None
@@ -664,15 +667,30 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
         state["out"] = out
 
     finish(strict=False)
+
+    def bark(which):
+        # an RCCL leg hung (its first meeting with real multi-GPU hardware is the driver's run) or a rank failed inside
+        # it: rank 0 reports what the legs before it measured
+        if rank == 0:
+            if state["out"] is not None:
+                state["out"]["other_configs"].append({"config": f"engine {which}", "error": f"no result within {RCCL_LEG_TIMEOUT_S} s"})
+            emit()
+        os._exit(0 if (rank != 0 or state["printed"]) else 1)
+
+    # ---- leg 1c: the C engine over RCCL (librccl dlopen()ed by the library) ----
+    if want_c and n_gpus > 1 and not one_device:
+        c_leg("c_rccl", "rccl")
+        finish(strict=False)
+    elif want_c and rank == 0:
+        legs["c_rccl_error"] = "not run: the rccl exchange needs one GPU per band (this is a one-GPU run)"
+        finish(strict=False)
+    if rank == 0 and want_c:
+        try:
+            os.unlink(plane_file)
+        except OSError:
+            pass
     if want_rccl:
-        def bark():
-            # the RCCL leg hung or a rank failed inside it: rank 0 reports what the first leg measured
-            if rank == 0:
-                if state["out"] is not None:
-                    state["out"]["other_configs"].append({"config": "engine rccl", "error": f"no result within {RCCL_LEG_TIMEOUT_S} s"})
-                emit()
-            os._exit(0 if (rank != 0 or state["printed"]) else 1)
-        watchdog = threading.Timer(RCCL_LEG_TIMEOUT_S, bark)
+        watchdog = threading.Timer(RCCL_LEG_TIMEOUT_S, bark, args=("rccl",))
         watchdog.daemon = True
         watchdog.start()
         err = ""
@@ -746,7 +764,43 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
     ranks.close()
 
 
+def leg_child(spec_json):
+    """one leg of the C row tiling in a process of its own (see tiled()): create, W warm-up steps, K timed steps, the
+    hash of the plane left behind; prints `LEG {json}`"""
+    spec = json.loads(spec_json)
+    import jpeg2png_amd as j
+    from jpeg2png_amd import synth
+    out = {}
+    try:
+        plane = synth.Plane(spec["W"], spec["H"], 1, 1, np.load(spec["plane"]), np.array(spec["quant"], dtype=np.uint16))
+        its = spec["its"]
+        with j.TiledSolver([plane], WEIGHT, [PWEIGHT], its, devices=spec["devices"]) as t:
+            eng = t.band_solver(0)
+            for _ in range(spec["warmup"]):
+                t.reset()
+                t.run(its)
+            t.sync()
+            eng.enable_timing(spec["timing_every"])
+            t0 = time.perf_counter()
+            for _ in range(spec["steps"]):
+                t.reset()
+                t.run(its)
+            t.sync()
+            elapsed = time.perf_counter() - t0
+            g_ms, p_ms, samples = eng.kernel_times()
+            eng.enable_timing(0)
+            out = {"elapsed": elapsed, "g_ms": g_ms, "p_ms": p_ms, "samples": samples, "host_cpu_s": round(t.host_cpu_seconds(), 3),
+                   "exchange": t.exchange(), "digest": plane_digest(t.download(0))}
+    except Exception as e:              # noqa: BLE001
+        out = {"error": f"{type(e).__name__}: {e}"}
+    _flush_c_stdio()
+    print("LEG " + json.dumps(out), flush=True)
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--leg-child":
+        leg_child(sys.argv[2])
+        return
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -2,7 +2,8 @@
 """What the cross-band schedule of the C row tiling costs a band that has a GPU to itself — the figure that decides
 the multi-GPU efficiency, measurable on ONE GPU: a 2048-row band of the 16384-wide plane next to a 48-row band (which
 is idle almost all the time), against the same rows solved whole.  J2P_TILED_EXCHANGE=direct|copy (and
-J2P_TILED_NORM=all with copy) select the schedule."""
+J2P_TILED_NORM=all with copy) select the schedule; J2P_BANDS_PER_GPU=k cuts the 2048 rows into k bands on streams of their
+own (what a GPU holding k bands of the canvas would run: while one band waits for an event the others compute)."""
 import json
 import os
 import sys
@@ -24,8 +25,10 @@ def timed(fn, reps=3):
     return (time.perf_counter() - t0) / reps
 
 
-res = {"norm": os.environ.get("J2P_TILED_NORM", "default")}
-with j.TiledSolver([p], 0.3, [0.001], its, devices=[0, 0], cuts=[0, 2048, 2096]) as t:
+k = int(os.environ.get("J2P_BANDS_PER_GPU", "1"))
+res = {"norm": os.environ.get("J2P_TILED_NORM", "default"), "bands_per_gpu": k}
+cuts = [2048 * i // k // 16 * 16 for i in range(k)] + [2048, 2096]
+with j.TiledSolver([p], 0.3, [0.001], its, devices=[0] * (k + 1), cuts=cuts) as t:
     res["exchange"] = t.exchange()
     def run():
         t.reset()
