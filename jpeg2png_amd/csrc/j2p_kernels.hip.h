@@ -284,7 +284,9 @@ struct GradArgs {
         unsigned nch_total;     // channels of the solver (partials per strip and tile row)
         unsigned fold_rows;     // tile rows this launch completes
         unsigned ntr_global;    // tile rows of the whole canvas (length of the tree's input)
-        RowsumPush push;        // (last: read by one wavefront per tile row only)
+        // linked bands: where every tile row's sum also goes, in DEVICE memory (one wavefront per tile row reads it; as
+        // 272 bytes of kernel arguments it cost every launch of every solver 0.5 us, same-box A/B); NULL = no push
+        const RowsumPush *push;
 };
 
 struct ProjArgs {
@@ -601,7 +603,7 @@ constexpr int kStripCols = 124;   // output columns per wavefront strip with two
 #endif
 constexpr int kRing = J2P_RING;   // row slots = hand-unroll factor of the marching loop (1 channel; 3 otherwise: registers);
                                   // rows are fetched (slots - 1) trips ahead (3 slots: 12 % slower; 2 or 5 ring turns per
-                                  // loop iteration: slower too, DESIGN.md §9)
+                                  // loop iteration: slower too, DESIGN.md §10)
 
 // compile-time description of a strip for k_gradient's march: `value` = it touches no image / band / coverage
 // edge (clamps and masks are the identity), `unit` = additionally every channel of the wavefront is sampled 1x1
@@ -928,10 +930,11 @@ __device__ __forceinline__ void fold_tile_row(const GradArgs &a, unsigned tr, si
         // row-tiled, bands in each other's reach: the sum into every band's copy of the global array (all eight lanes
         // of channel c's group hold it; lane j serves bands j, j + 8, ...).  System-scope stores: performed at the
         // destination, visible to the peers' projection launches through the event recorded behind this launch.
-        if(a.push.n && c < (int)nch) {
-                const size_t slot = (size_t)(a.push.first_tr + tr) * nch + (unsigned)c;
-                for(unsigned b = (unsigned)j; b < a.push.n; b += 8) {
-                        __hip_atomic_store(a.push.dst[b] + slot, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if(a.push && c < (int)nch) {
+                const RowsumPush &push = *a.push;
+                const size_t slot = (size_t)(push.first_tr + tr) * nch + (unsigned)c;
+                for(unsigned b = (unsigned)j; b < push.n; b += 8) {
+                        __hip_atomic_store(push.dst[b] + slot, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
         }
 }

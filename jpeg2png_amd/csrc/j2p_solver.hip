@@ -124,6 +124,7 @@ struct j2p_solver {
         double *rowsum_all_odd = nullptr;   // band solvers: the global array of odd iterations once the bands are linked
         bool linked = false;                // j2p_solver_link_bands: neighbours' rows read in place, row sums pushed
         j2p_band_links links;
+        RowsumPush *push_dev = nullptr;     // [2]: the push lists of even / odd iterations, in device memory (GradArgs::push)
         bool band_nip = true;               // band solvers: ||g|| from the global row sums inside k_project (NIP 2) instead of k_norm_finish
         float *norm = nullptr;           // [c]
         // logging
@@ -522,12 +523,10 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         a.row_ticket = s->fold ? s->tickets : nullptr;
         a.done_ticket = s->tickets + s->ntr_local;
         a.rowsum = (s->rowsum_alternate && (s->iter & 1)) ? s->rowsum_odd : s->rowsum_local;
-        a.push.n = 0;
-        a.push.first_tr = s->first_tr;
+        a.push = nullptr;
         if(s->linked) {
                 if(part != 0) { return fail(J2P_ESTATE, "linked bands run whole phases (there is no exchange to hide)"); }
-                a.push.n = s->links.npush;
-                for(unsigned b = 0; b < s->links.npush; b++) { a.push.dst[b] = s->links.push[s->iter & 1][b]; }
+                a.push = s->push_dev + (s->iter & 1);
         }
         a.norm_out = fold_norm ? s->norm : nullptr;
         a.nch_total = s->nch;
@@ -986,7 +985,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         // reductions: tile rows are counted on the canvas, the band owns a contiguous range
         // Gradient strips: columns per lane (px) and rows per strip = rows per norm partial ("tile row", rpw).
         // A canvas that fills the chip: 128-column strips (two columns per lane, packed arithmetic) of 16 rows (32 / 48 / 64
-        // measured no faster, DESIGN.md §9).  A smaller canvas leaves wavefront slots empty and is bound by how long ONE
+        // measured no faster, DESIGN.md §10).  A smaller canvas leaves wavefront slots empty and is bound by how long ONE
         // wavefront takes to walk its rows (wave timelines, profiles/r03_wave_trace.jsonl: ~0.9 us per row trip whatever
         // the SIMD's load), so it gets shorter strips (8 or 4 rows: fewer trips per wavefront).  64-column strips (one
         // column per lane: the same kernel instantiated on float instead of float2) exist behind J2P_PX=1 and do not
@@ -1063,6 +1062,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 else {
                         carve.take(s->rowsum_all, (size_t)s->ntr_global * nchannel);
                         carve.take(s->rowsum_all_odd, (size_t)s->ntr_global * nchannel);
+                        carve.take(s->push_dev, 2);
                         carve.take(s->rowsum_odd, (size_t)s->ntr_local * nchannel);
                 }
                 carve.take(s->norm, kMaxCh);
@@ -1516,6 +1516,19 @@ int j2p_solver_link_bands(j2p_solver *s, const j2p_band_links *links)
                 if(up != (s->row0 > 0) || down != (s->row0 + s->rows < s->H)) {
                         return fail(J2P_EINVAL, "link_bands: channel %u: neighbours do not match the band's place in the canvas", c);
                 }
+        }
+        // the push lists live in device memory (see GradArgs::push)
+        RowsumPush host[2];
+        for(int par = 0; par < 2; par++) {
+                memset(&host[par], 0, sizeof(host[par]));
+                host[par].n = links->npush;
+                host[par].first_tr = s->first_tr;
+                for(unsigned b = 0; b < links->npush; b++) { host[par].dst[b] = links->push[par][b]; }
+        }
+        {
+                DeviceGuard guard(s->device);
+                HIP_TRY(hipMemcpyAsync(s->push_dev, host, sizeof(host), hipMemcpyHostToDevice, s->stream));
+                HIP_TRY(hipStreamSynchronize(s->stream));       // `host` is on the stack
         }
         s->links = *links;
         s->linked = true;

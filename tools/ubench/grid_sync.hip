@@ -1,5 +1,5 @@
 // What a device-wide barrier inside ONE persistent launch costs on the GPU it runs on, against what it would replace:
-// the boundary between two dependent kernel launches on one stream.  The question behind it (DESIGN.md §9, "persistent
+// the boundary between two dependent kernel launches on one stream.  The question behind it (DESIGN.md §10, "persistent
 // solver for small images"): a FISTA iteration is two phases whose data crosses workgroups (g, x_{k+1}, the prob state, the
 // norm), so a persistent solver pays two barriers per iteration INCLUDING the cache maintenance that makes plain stores of
 // one XCD visible to the others (release = write back that XCD's L2, acquire = invalidate it) — the same maintenance a
