@@ -15,7 +15,9 @@ Workloads (BASELINE.json configs):
   N > 1 : configs[3]  16384-wide Y-only plane, Q=10, -i 100, row-tiled: 2048 rows per GPU
           (N = 8 is exactly the 16384x16384 config); weak scaling (fixed rows per GPU).  Every engine is
           timed, each with W warm-up and K timed steps between barriers, and the plane each leaves is hashed:
-            c      : the C row tiling (j2p_tiled: one process drives all N GPUs with one host thread per band) in its
+            c      : (and c_waitroot, c_waitcoll: the same with the projection waiting for one event of a root band / of a
+                     collecting stream instead of N - 1 events)
+                     the C row tiling (j2p_tiled: one process drives all N GPUs with one host thread per band) in its
                      default exchange — "direct": row sums of g^2 pushed from k_gradient and edge rows from k_project
                      as posted peer writes over xGMI, ||g|| reduced inside k_project, two launches and two event waits
                      per band and iteration — rank 0 drives it; the other ranks of the launch wait in a gloo (CPU)
@@ -559,15 +561,18 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
     if rank == 0 and want_c:
         np.save(plane_file, whole_plane.data)
 
-    def c_leg(name, exchange=None, norm="root"):
+    def c_leg(name, exchange=None, norm="root", wait=None):
         if rank == 0:
             devices = list(range(n_gpus)) if n_gpus > 1 and not one_device else [local_rank] * nband
             spec = {"plane": plane_file, "W": W, "H": H, "quant": [int(q) for q in np.asarray(whole_plane.quant_table).reshape(-1)],
                     "its": its, "devices": devices, "warmup": a.warmup, "steps": a.steps, "timing_every": a.timing_every}
             env = dict(os.environ, J2P_TILED_NORM=norm)
             env.pop("J2P_TILED_EXCHANGE", None)
+            env.pop("J2P_TILED_WAIT", None)
             if exchange:
                 env["J2P_TILED_EXCHANGE"] = exchange                  # read by j2p_tiled_create
+            if wait:
+                env["J2P_TILED_WAIT"] = wait
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
                 env.pop(k, None)
             import subprocess
@@ -581,8 +586,11 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
                 if "error" in res:
                     raise RuntimeError(res["error"])
                 how = res["exchange"]
-                what = {"direct": "row sums of g^2 pushed from k_gradient and edge rows from k_project as posted peer writes, ||g|| "
-                                  "reduced inside k_project: two launches and two event waits per band and iteration",
+                direct = ("row sums of g^2 pushed from k_gradient and edge rows from k_project as posted peer writes, ||g|| "
+                          "reduced inside k_project: two launches per band and iteration; the projection waits for ")
+                what = {"direct": direct + "the other bands' gradient events itself",
+                        "direct, wait root": direct + "ONE event of band 0, which waited for every band's gradient event",
+                        "direct, wait collector": direct + "ONE event of a helper stream that waited for the other bands' gradient events",
                         "copy": "round 3's exchange: a copy kernel pulls the neighbours' edge rows, "
                                 + ("one band reduces ||g|| for all" if norm == "root" else "every band reduces ||g|| itself")
                                 + ": four launches per band and iteration",
@@ -603,6 +611,11 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
     if want_c:
         c_leg("c")
         c_leg("c_copy", "copy")
+        if nband > 2:
+            # (what a wait for ANOTHER GPU's event costs is unknown here — on one GPU 13 us each, profiles/r04_event_waits.json —
+            # so the two other ways of learning that every band's gradient launch has finished are timed as well)
+            c_leg("c_waitroot", "direct", wait="root")
+            c_leg("c_waitcoll", "direct", wait="collector")
 
     # ---- leg 2: one process per GPU over RCCL ----
     watchdog = None

@@ -248,7 +248,8 @@ int j2p_solver_link_bands(j2p_solver *s, const j2p_band_links *links);   /* NULL
  * nband == 1 is a plain whole-canvas solver behind the same calls.  How the bands exchange their row sums of g^2 and
  * their edge rows is chosen at create time (j2p_tiled_exchange() names it; environment J2P_TILED_EXCHANGE forces one):
  *   "direct" (default where every GPU can write every other's memory): both exchanges ride on the two phase kernels
- *            as posted peer writes (j2p_solver_link_bands) — two launches and two event waits per band and iteration;
+ *            as posted peer writes (j2p_solver_link_bands) — two launches per band and iteration; J2P_TILED_WAIT=all
+ *            (default) | root | collector: how a band's projection learns that every band's gradient has finished;
  *   "copy"   round 3's schedule — a copy kernel pulls the neighbours' edge rows, one band reduces ||g|| for all
  *            (J2P_TILED_NORM=all: every band for itself) — kept as the cross-check of "direct" and for canvases taller
  *            than 16384 rows;
@@ -268,7 +269,7 @@ int j2p_tiled_run(j2p_tiled *t, unsigned n, j2p_log_row *rows);   /* asynchronou
 int j2p_tiled_sync(j2p_tiled *t);
 int j2p_tiled_download(j2p_tiled *t, unsigned c, float *out);      /* W * H floats */
 int j2p_tiled_host_cpu_seconds(const j2p_tiled *t, double *seconds);
-int j2p_tiled_exchange(const j2p_tiled *t, const char **name);    /* "direct", "copy", "rccl"; "none" for one plain band */
+int j2p_tiled_exchange(const j2p_tiled *t, const char **name);    /* "direct" ("direct, wait root" / "…collector"), "copy", "rccl"; "none": one plain band */
 
 /* CSV logging for band solvers (the "+3 doubles when logging" of the norm exchange): with logging on, the
  * phase calls also leave the band's tv / tv2 / prob sums in j2p_exchange.log_local; the caller adds the bands'

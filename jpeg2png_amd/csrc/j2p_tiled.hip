@@ -54,6 +54,16 @@ constexpr unsigned kTreeRowsInProject = 1024;   // tile rows k_project's in-kern
 
 enum Exchange { kDirect = 0, kCopy = 1, kRccl = 2 };
 const char *const kExchangeName[3] = {"direct", "copy", "rccl"};
+// `direct`: how a band's projection learns that EVERY band's gradient launch has finished (J2P_TILED_WAIT).  On one GPU a
+// stream pays ~13 us per event of another stream it waits for between two of its kernels, whatever the kernels touch
+// (tools/ubench/event_waits.hip, profiles/r04_event_waits.json: 7 waits +94 us, through a collecting stream +62);
+// what a wait for another GPU's event costs cannot be measured on this pool's one-GPU boxes, so all three exist and
+// bench.py --gpus N times them:
+//   all        the band's stream waits for the other N - 1 gradient events itself (one hop, N - 1 barrier packets)
+//   root       band 0 waits for them and records one event, the others wait for that (two hops, one packet each)
+//   collector  a helper stream of the band waits for the N - 1 events and records one event the band's stream waits for
+enum WaitMode { kWaitAll = 0, kWaitRoot = 1, kWaitCollector = 2 };
+const char *const kWaitName[3] = {"all", "root", "collector"};
 
 // ---------------------------------------------------------------------------------------------------------------
 // librccl through dlopen: the C host reaches RCCL without linking against it (the library must load on hosts that
@@ -127,7 +137,9 @@ struct Band {
         unsigned row0 = 0, row1 = 0;
         hipEvent_t ev_grad[2] = {nullptr, nullptr};    // behind the gradient phase of iteration it (slot it & 1)
         hipEvent_t ev_edge[2] = {nullptr, nullptr};    // behind the projection of iteration it
-        hipEvent_t ev_norm[2] = {nullptr, nullptr};    // `copy`, root band only: behind the norm of iteration it
+        hipEvent_t ev_norm[2] = {nullptr, nullptr};    // root band only: behind the norm (`copy`) / every band's gradient (`direct`, wait root) of iteration it
+        hipStream_t collector = nullptr;               // `direct`, wait collector: the stream that waits for the other bands' gradient events
+        hipEvent_t ev_all[2] = {nullptr, nullptr};     // ... and what it records behind them
         // iterations whose event has been recorded (guarded by j2p_tiled::seq_lock)
         uint64_t grad_recorded = 0, edge_recorded = 0, norm_recorded = 0;
         j2p_exchange rows[2];                  // halo / edge row addresses of x buffer 0 and 1
@@ -157,6 +169,7 @@ struct j2p_tiled {
         bool carried_valid = true;             // false after iterations run without logging (their prob sums were not kept)
         bool logging = false;                  // the band solvers currently run their logging kernels
         Exchange exchange = kDirect;
+        WaitMode wait = kWaitAll;
         bool threaded = false;                 // band threads exist (every run but the plain one-band one)
         bool norm_by_root = true;              // `copy`: one band reduces ||g|| for all (default); false: every band for itself
         bool self_neighbours = false;          // test hook (J2P_TILED_SELF_NEIGHBOURS=1, one band, rccl): the band exchanges with itself
@@ -212,8 +225,8 @@ int record(j2p_tiled *t, Band *me, Which w, uint64_t it)
         return J2P_OK;
 }
 
-// sleep (host) until band p has recorded its event of iteration `it`, then make `me`'s stream wait for it
-int wait_for(j2p_tiled *t, Band *me, Band *p, Which w, uint64_t it)
+// sleep (host) until band p has recorded its event of iteration `it`, then make `me`'s stream (or `on`) wait for it
+int wait_for(j2p_tiled *t, Band *me, Band *p, Which w, uint64_t it, hipStream_t on = nullptr)
 {
         {
                 std::unique_lock<std::mutex> g(t->seq_lock);
@@ -221,7 +234,7 @@ int wait_for(j2p_tiled *t, Band *me, Band *p, Which w, uint64_t it)
                 if(seq_of(p, w) <= it) { return j2p_fail(J2P_ESTATE, "another band failed"); }
         }
         hipEvent_t ev = w == kGrad ? p->ev_grad[it & 1] : (w == kEdge ? p->ev_edge[it & 1] : p->ev_norm[it & 1]);
-        BAND_HIP(hipStreamWaitEvent(me->stream, ev, 0));
+        BAND_HIP(hipStreamWaitEvent(on ? on : me->stream, ev, 0));
         return J2P_OK;
 }
 
@@ -321,8 +334,19 @@ int band_iterations(j2p_tiled *t, unsigned b, unsigned n, bool log)
                         BAND_TRY(record(t, me, kGrad, it));
                         // ---- phase B behind EVERY band's gradient launch (their row sums are in this band's global
                         // array; nobody still reads the halo rows this band's projection is about to overwrite) ----
-                        for(unsigned p = 0; p < t->nband; p++) {
-                                if(p != b) { BAND_TRY(wait_for(t, me, t->bands[p], kGrad, it)); }
+                        if(t->wait == kWaitAll || (t->wait == kWaitRoot && me == root)) {
+                                for(unsigned p = 0; p < t->nband; p++) {
+                                        if(p != b) { BAND_TRY(wait_for(t, me, t->bands[p], kGrad, it)); }
+                                }
+                                if(t->wait == kWaitRoot) { BAND_TRY(record(t, me, kNorm, it)); }      // "every gradient launch has finished"
+                        } else if(t->wait == kWaitRoot) {
+                                BAND_TRY(wait_for(t, me, root, kNorm, it));
+                        } else {
+                                for(unsigned p = 0; p < t->nband; p++) {
+                                        if(p != b) { BAND_TRY(wait_for(t, me, t->bands[p], kGrad, it, me->collector)); }
+                                }
+                                BAND_HIP(hipEventRecord(me->ev_all[it & 1], me->collector));
+                                BAND_HIP(hipStreamWaitEvent(me->stream, me->ev_all[it & 1], 0));
                         }
                         BAND_TRY(j2p_solver_phase_project(me->solver));
                         BAND_TRY(record(t, me, kEdge, it));
@@ -483,7 +507,9 @@ void j2p_tiled_destroy(j2p_tiled *t)
                         if(b->ev_grad[k]) { (void)hipEventDestroy(b->ev_grad[k]); }
                         if(b->ev_edge[k]) { (void)hipEventDestroy(b->ev_edge[k]); }
                         if(b->ev_norm[k]) { (void)hipEventDestroy(b->ev_norm[k]); }
+                        if(b->ev_all[k]) { (void)hipEventDestroy(b->ev_all[k]); }
                 }
+                if(b->collector) { (void)hipStreamSynchronize(b->collector); (void)hipStreamDestroy(b->collector); }
                 if(b->log_host) { (void)hipHostFree(b->log_host); }
                 delete b;
         }
@@ -543,6 +569,13 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                 t->root = 0;
                 env = getenv("J2P_TILED_SELF_NEIGHBOURS");
                 t->self_neighbours = nband == 1 && env && atoi(env) != 0;
+                env = getenv("J2P_TILED_WAIT");
+                if(env && *env) {
+                        int w = -1;
+                        for(int k = 0; k < 3; k++) { if(strcmp(env, kWaitName[k]) == 0) { w = k; } }
+                        if(w < 0) { rc = j2p_fail(J2P_EINVAL, "J2P_TILED_WAIT=%s: all, root or collector", env); }
+                        else { t->wait = (WaitMode)w; }
+                }
                 env = getenv("J2P_TILED_EXCHANGE");
                 int want = -1;
                 if(env && *env) {
@@ -567,7 +600,8 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                         } else if(!reach) {
                                 rc = j2p_fail(J2P_EDEVICE, "%s: J2P_TILED_EXCHANGE=%s needs it", why, kExchangeName[want]);
                         } else if(want == kCopy || rows_of_tiles > kTreeRowsInProject) {
-                                t->exchange = kCopy;        // (also: canvases whose row sums k_project's in-kernel tree cannot hold)
+                                t->exchange = kCopy;        // (also: canvases whose row sums k_project's in-kernel tree cannot hold;
+                                                            // decided again below from the first band's own tile-row count)
                         } else {
                                 t->exchange = kDirect;
                         }
@@ -602,6 +636,8 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                 bd->global_rows[0] = bd->global_rows[1] = e.partials_all;
                 bd->first_tr = e.first_tile_row;
                 bd->ntr = e.local_tile_rows;
+                // (small canvases have tile rows of 8 or 4 image rows: what counts is the solver's own number of them)
+                if(b == 0 && t->exchange == kDirect && e.global_tile_rows > kTreeRowsInProject) { t->exchange = kCopy; }
                 if(b > 0 && bd->ntr != t->bands[0]->ntr) { t->equal_counts = false; }
                 if(t->threaded && t->exchange == kCopy) {
                         rc = j2p_solver_alternate_rowsums(bd->solver, bd->rowsum);
@@ -627,9 +663,13 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                 for(int k = 0; k < 2 && rc == J2P_OK; k++) {
                         if(hipEventCreateWithFlags(&bd->ev_grad[k], evflags) != hipSuccess ||
                            hipEventCreateWithFlags(&bd->ev_edge[k], evflags) != hipSuccess ||
-                           hipEventCreateWithFlags(&bd->ev_norm[k], evflags) != hipSuccess) {
+                           hipEventCreateWithFlags(&bd->ev_norm[k], evflags) != hipSuccess ||
+                           hipEventCreateWithFlags(&bd->ev_all[k], evflags) != hipSuccess) {
                                 rc = j2p_fail(J2P_EDEVICE, "hipEventCreate failed");
                         }
+                }
+                if(rc == J2P_OK && t->wait == kWaitCollector && hipStreamCreateWithFlags(&bd->collector, hipStreamNonBlocking) != hipSuccess) {
+                        rc = j2p_fail(J2P_EDEVICE, "hipStreamCreate failed");
                 }
         }
         // ---- direct: tell every band where its neighbours' halo rows and everybody's global arrays are ----
@@ -680,7 +720,8 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
 int j2p_tiled_exchange(const j2p_tiled *t, const char **name)
 {
         if(!t || !name) { return j2p_fail(J2P_EINVAL, "NULL argument"); }
-        *name = t->threaded ? kExchangeName[t->exchange] : "none";
+        static const char *const direct_names[3] = {"direct", "direct, wait root", "direct, wait collector"};
+        *name = !t->threaded ? "none" : (t->exchange == kDirect ? direct_names[t->wait] : kExchangeName[t->exchange]);
         return J2P_OK;
 }
 

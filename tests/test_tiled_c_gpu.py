@@ -190,6 +190,41 @@ def test_direct_exchange_on_every_projection_path(lib, sub, y_only, W, H, monkey
             assert bit_equal(t.download(c), want[c]), f"channel {c}"
 
 
+@pytest.mark.parametrize("wait", ["all", "root", "collector"])
+def test_direct_exchange_wait_modes(lib, wait, monkeypatch):
+    """how a band's projection learns that every band's gradient launch has finished (J2P_TILED_WAIT): waiting for the
+    N - 1 events itself, for one event of a root band that waited for them, or for one event of a collecting stream —
+    orderings of the same launches, so the same bits; five bands, logged and not, reset in between"""
+    import jpeg2png_amd as j
+    planes = make_case(200, 330, "420", 10, seed=82)
+    pws = [0.001] * 3
+    want, want_rows = whole_canvas(planes, 0.3, pws, 9, log=True)
+    monkeypatch.setenv("J2P_TILED_EXCHANGE", "direct")
+    monkeypatch.setenv("J2P_TILED_WAIT", wait)
+    with j.TiledSolver(planes, 0.3, pws, 9, devices=[0] * 5) as t:
+        assert t.exchange() == ("direct" if wait == "all" else f"direct, wait {wait}")
+        t.run(9)
+        for c in range(3):
+            assert bit_equal(t.download(c), want[c]), f"{wait}: channel {c}"
+        t.reset()
+        rows = np.concatenate([t.run(4, log=True), t.run(5, log=True)])
+        for c in range(3):
+            assert bit_equal(t.download(c), want[c]), f"{wait}, logged: channel {c}"
+    np.testing.assert_allclose(rows, want_rows, rtol=1e-9, atol=1e-12)
+
+
+def test_tall_narrow_canvas_falls_back_to_the_copy_exchange(lib):
+    """a canvas with more than 1024 tile rows (here 4-row tile rows: few wavefronts, so short strips) does not fit the
+    tree k_project runs for linked bands: the engine takes the copy exchange by itself, same bits"""
+    import jpeg2png_amd as j
+    planes = make_case(64, 4128, "444", 10, seed=81, y_only=True)
+    want, _ = whole_canvas(planes, 0.3, [0.001], 5)
+    with j.TiledSolver(planes, 0.3, [0.001], 5, devices=[0] * 3) as t:
+        assert t.exchange() == "copy"
+        t.run(5)
+        assert bit_equal(t.download(0), want[0])
+
+
 def test_rccl_exchange_with_one_band_as_its_own_neighbour(lib, monkeypatch):
     """the RCCL transport of the C engine on ONE GPU: one band (RCCL wants a GPU per rank), driven through the band
     machinery — ncclCommInitAll, ncclAllGather of its row sums, grouped ncclSend / ncclRecv of its edge rows to

@@ -14,7 +14,12 @@ import jpeg2png_amd as j            # noqa: E402
 from jpeg2png_amd import synth      # noqa: E402
 
 W, its = 16384, 100
-p = synth.make_planes(W, 2096, "444", 10, seed=1238, y_only=True)[0]
+# J2P_DUMMY_BANDS=d: d idle 48-row bands instead of one (the big band then waits for d gradient events per iteration, as
+# on a (d + 1)-GPU node); J2P_BIG_BAND_LAST=1 puts them in front, so that the big band is not the copy exchange's root
+dummies = int(os.environ.get("J2P_DUMMY_BANDS", "1"))
+big_last = os.environ.get("J2P_BIG_BAND_LAST", "0") == "1"
+H = 2048 + 48 * dummies
+p = synth.make_planes(W, H, "444", 10, seed=1238, y_only=True)[0]
 
 
 def timed(fn, reps=3):
@@ -26,9 +31,12 @@ def timed(fn, reps=3):
 
 
 k = int(os.environ.get("J2P_BANDS_PER_GPU", "1"))
-res = {"norm": os.environ.get("J2P_TILED_NORM", "default"), "bands_per_gpu": k}
-cuts = [2048 * i // k // 16 * 16 for i in range(k)] + [2048, 2096]
-with j.TiledSolver([p], 0.3, [0.001], its, devices=[0] * (k + 1), cuts=cuts) as t:
+res = {"norm": os.environ.get("J2P_TILED_NORM", "default"), "bands_per_gpu": k, "dummy_bands": dummies, "big_band_last": big_last}
+if big_last:
+    cuts = [48 * i for i in range(dummies)] + [48 * dummies + 2048 * i // k // 16 * 16 for i in range(k)] + [H]
+else:
+    cuts = [2048 * i // k // 16 * 16 for i in range(k)] + [2048 + 48 * i for i in range(dummies)] + [H]
+with j.TiledSolver([p], 0.3, [0.001], its, devices=[0] * (k + dummies), cuts=cuts) as t:
     res["exchange"] = t.exchange()
     def run():
         t.reset()
@@ -41,6 +49,7 @@ with j.Solver([p], 0.3, [0.001], its) as s:
         s.reset()
         s.run(its)
         s.sync()
-    res["whole_2096_rows_us_per_iteration"] = round(timed(run) / its * 1e6, 2)
-res["efficiency"] = round(res["whole_2096_rows_us_per_iteration"] / res["band_2048_next_to_band_48_us_per_iteration"], 4)
+    res["whole_us_per_iteration"] = round(timed(run) / its * 1e6, 2)
+res["rows_whole"] = H
+res["efficiency"] = round(res["whole_us_per_iteration"] * 2048 / H / res["band_2048_next_to_band_48_us_per_iteration"], 4)
 print(json.dumps(res))
