@@ -66,7 +66,7 @@ BYTES_PROJECT = 22               # phase B
 BYTES_ITERATION = BYTES_GRADIENT + BYTES_PROJECT
 WEIGHT, PWEIGHT = 0.3, 0.001     # jpeg2png.c:22-23 defaults
 RCCL_LEG_TIMEOUT_S = 240         # watchdog of the Python RCCL harness leg of an N > 1 run
-C_LEG_TIMEOUT_S = 300            # ... and of each child process that runs one leg of the C row tiling
+C_LEG_TIMEOUT_S = 180            # ... and of each child process that runs one leg of the C row tiling
 
 
 def parse():
@@ -591,6 +591,8 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
                 what = {"direct": direct + "the other bands' gradient events itself",
                         "direct, wait root": direct + "ONE event of band 0, which waited for every band's gradient event",
                         "direct, wait collector": direct + "ONE event of a helper stream that waited for the other bands' gradient events",
+                        "direct, wait counter": direct + "ONE value in coherent host memory that every band's k_gradient counts up itself "
+                                                         "(hipStreamWaitValue64; the neighbours' projections are awaited through hipStreamWriteValue64 flags): no HIP events",
                         "copy": "round 3's exchange: a copy kernel pulls the neighbours' edge rows, "
                                 + ("one band reduces ||g|| for all" if norm == "root" else "every band reduces ||g|| itself")
                                 + ": four launches per band and iteration",
@@ -696,6 +698,12 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
         finish(strict=False)
     elif want_c and rank == 0:
         legs["c_rccl_error"] = "not run: the rccl exchange needs one GPU per band (this is a one-GPU run)"
+        finish(strict=False)
+    if want_c:
+        # ... and the one without events: the gradient kernels count up a value in host memory, one hipStreamWaitValue64
+        # (bands on GPUs of their own; with more than two bands on one GPU the engine takes the event form by itself)
+        if (n_gpus > 1 and not one_device) or nband <= 2:
+            c_leg("c_counter", "direct", wait="counter")
         finish(strict=False)
     if rank == 0 and want_c:
         try:

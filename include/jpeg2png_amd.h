@@ -237,6 +237,11 @@ typedef struct j2p_band_links {
         float *down_halo[2][J2P_MAX_CHANNELS];
         unsigned npush;
         double *push[2][32];
+        /* optional (ncount 0 = none): counters in memory every GPU can update atomically (coherent pinned host memory);
+         * the gradient launch adds 1 to each when the band's last tile row has been pushed, so that a band's stream can
+         * wait for "every band's gradient has finished" with ONE hipStreamWaitValue64 (nband counts per iteration) */
+        unsigned ncount;
+        unsigned long long *count[32];
 } j2p_band_links;
 int j2p_solver_global_rowsums(j2p_solver *s, double *arrays[2]);   /* band solvers: [global tile row][channel], even / odd iterations */
 int j2p_solver_link_bands(j2p_solver *s, const j2p_band_links *links);   /* NULL: back to halo rows of its own */

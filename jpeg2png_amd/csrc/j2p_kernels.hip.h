@@ -265,6 +265,11 @@ struct RowsumPush {
         double *dst[kMaxBands];             // band b's global array of this iteration's parity
         unsigned n;                         // 0 = no push
         unsigned first_tr;                  // this band's first global tile row
+        // J2P_TILED_WAIT=counter: when the band's LAST tile row has been pushed, one count goes to every band's counter
+        // (coherent pinned host memory): a band's projection then waits for ONE value (hipStreamWaitValue64: N counts per
+        // iteration) instead of N - 1 events
+        unsigned long long *count[kMaxBands];
+        unsigned ncount;                    // 0 = no counters
 };
 
 struct GradArgs {
@@ -994,13 +999,18 @@ __device__ __forceinline__ void fold_arrive(const GradArgs &a, unsigned tr, unsi
         // last strip of this tile row: every other strip's partials were acknowledged before its ticket
         fold_tile_row(a, tr, nparts, lane);
         if(lane == 0) { __hip_atomic_store(a.row_ticket + tr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // ready for the next launch
-        if(!a.norm_out) { return; }
+        const unsigned ncount = a.push ? a.push->ncount : 0u;         // (wave-uniform)
+        if(!a.norm_out && !ncount) { return; }
         unsigned done = 0;
-        stores_acknowledged();                                       // the row sums of lanes 0, 8, 16 before the ticket
+        stores_acknowledged();                                       // the row sums of lanes 0, 8, 16 (and their pushed copies) before the ticket
         if(lane == 0) { done = __hip_atomic_fetch_add(a.done_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         done = (unsigned)__builtin_amdgcn_readfirstlane((int)done);
         if(done + 1 != a.fold_rows) { return; }
-        fold_tree(a, buf, lane);
+        if(a.norm_out) { fold_tree(a, buf, lane); }
+        // the band's last tile row: every row sum of this launch has been acknowledged at its destinations (each finisher
+        // waited for its stores before it drew its ticket), and no strip of the band reads a halo row any more — tell
+        // every band (lane b: band b's counter)
+        if((unsigned)lane < ncount) { __hip_atomic_fetch_add(a.push->count[lane], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
         if(lane == 0) { __hip_atomic_store(a.done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 

@@ -1499,6 +1499,10 @@ int j2p_solver_link_bands(j2p_solver *s, const j2p_band_links *links)
         if(!s->fold) { return fail(J2P_ESTATE, "link_bands needs the folded norm reduction (the row sums leave from inside k_gradient)"); }
         if(s->rowsum_alternate) { return fail(J2P_ESTATE, "link_bands: this solver's row sums already alternate for norm_from_bands"); }
         if(links->npush == 0 || links->npush > (unsigned)kMaxBands) { return fail(J2P_EINVAL, "link_bands: 1..%d bands to push to", kMaxBands); }
+        if(links->ncount > (unsigned)kMaxBands) { return fail(J2P_EINVAL, "link_bands: at most %d counters", kMaxBands); }
+        for(unsigned b = 0; b < links->ncount; b++) {
+                if(!links->count[b]) { return fail(J2P_EINVAL, "link_bands: counter %u is NULL", b); }
+        }
         bool own[2] = {false, false};
         for(int par = 0; par < 2; par++) {
                 for(unsigned b = 0; b < links->npush; b++) {
@@ -1524,6 +1528,8 @@ int j2p_solver_link_bands(j2p_solver *s, const j2p_band_links *links)
                 host[par].n = links->npush;
                 host[par].first_tr = s->first_tr;
                 for(unsigned b = 0; b < links->npush; b++) { host[par].dst[b] = links->push[par][b]; }
+                host[par].ncount = links->ncount;
+                for(unsigned b = 0; b < links->ncount; b++) { host[par].count[b] = links->count[b]; }
         }
         {
                 DeviceGuard guard(s->device);

@@ -62,8 +62,14 @@ const char *const kExchangeName[3] = {"direct", "copy", "rccl"};
 //   all        the band's stream waits for the other N - 1 gradient events itself (one hop, N - 1 barrier packets)
 //   root       band 0 waits for them and records one event, the others wait for that (two hops, one packet each)
 //   collector  a helper stream of the band waits for the N - 1 events and records one event the band's stream waits for
-enum WaitMode { kWaitAll = 0, kWaitRoot = 1, kWaitCollector = 2 };
-const char *const kWaitName[3] = {"all", "root", "collector"};
+//   counter    no events at all: k_gradient itself adds one count to every band's counter (coherent pinned host memory)
+//              when the band's last tile row has been pushed, and the band's stream waits for ONE value —
+//              hipStreamWaitValue64(counter >= N (k + 1)) — in front of projection(k); behind it the stream writes the
+//              iteration number into the band's own flag (hipStreamWriteValue64), which the neighbours' streams wait for
+//              in front of gradient(k + 1).  One wait whatever N (on one GPU: +15 us at n = 7 against +94 for events,
+//              profiles/r04_wait_value.json), and the host threads never sleep on each other.
+enum WaitMode { kWaitAll = 0, kWaitRoot = 1, kWaitCollector = 2, kWaitCounter = 3 };
+const char *const kWaitName[4] = {"all", "root", "collector", "counter"};
 
 // ---------------------------------------------------------------------------------------------------------------
 // librccl through dlopen: the C host reaches RCCL without linking against it (the library must load on hosts that
@@ -176,6 +182,10 @@ struct j2p_tiled {
         bool equal_counts = true;              // `rccl`: every band has as many tile rows (one ncclAllGather; else grouped broadcasts)
         unsigned root = 0;
         Rccl *rccl = nullptr;
+        // wait counter: one 64-byte line per band and kind in coherent pinned host memory
+        unsigned long long *signals = nullptr;          // [2 * nband][8]: gradient counts, then projection flags
+        unsigned long long *grad_count(unsigned b) const { return signals + 8 * (size_t)b; }
+        unsigned long long *edge_flag(unsigned b) const { return signals + 8 * ((size_t)nband + b); }
         // command hand-over to the band threads
         std::mutex lock;
         std::condition_variable wake, done;
@@ -324,6 +334,18 @@ int band_iterations(j2p_tiled *t, unsigned b, unsigned n, bool log)
                 const uint64_t it = t->iter + i;
                 switch(t->exchange) {
                 case kDirect:
+                        if(t->wait == kWaitCounter) {
+                                // no events: values in host memory every GPU sees (see WaitMode)
+                                if(it > 0) {
+                                        if(up) { BAND_HIP(hipStreamWaitValue64(me->stream, t->edge_flag(b - 1), it, hipStreamWaitValueGte, ~0ull)); }
+                                        if(down) { BAND_HIP(hipStreamWaitValue64(me->stream, t->edge_flag(b + 1), it, hipStreamWaitValueGte, ~0ull)); }
+                                }
+                                BAND_TRY(j2p_solver_phase_gradient(me->solver));
+                                BAND_HIP(hipStreamWaitValue64(me->stream, t->grad_count(b), (uint64_t)t->nband * (it + 1), hipStreamWaitValueGte, ~0ull));
+                                BAND_TRY(j2p_solver_phase_project(me->solver));
+                                BAND_HIP(hipStreamWriteValue64(me->stream, t->edge_flag(b), it + 1, 0));
+                                break;
+                        }
                         // ---- phase A behind the neighbours' projection of the previous iteration (their edge rows are
                         // in this band's halo rows when that launch has finished) ----
                         if(it > 0) {
@@ -514,6 +536,7 @@ void j2p_tiled_destroy(j2p_tiled *t)
                 delete b;
         }
         if(prev >= 0) { (void)hipSetDevice(prev); }
+        if(t->signals) { (void)hipHostFree(t->signals); }
         delete t;
         j2p_pool_trim();        // band arenas are large and rarely reused at the same size: back to the device
 }
@@ -572,8 +595,8 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                 env = getenv("J2P_TILED_WAIT");
                 if(env && *env) {
                         int w = -1;
-                        for(int k = 0; k < 3; k++) { if(strcmp(env, kWaitName[k]) == 0) { w = k; } }
-                        if(w < 0) { rc = j2p_fail(J2P_EINVAL, "J2P_TILED_WAIT=%s: all, root or collector", env); }
+                        for(int k = 0; k < 4; k++) { if(strcmp(env, kWaitName[k]) == 0) { w = k; } }
+                        if(w < 0) { rc = j2p_fail(J2P_EINVAL, "J2P_TILED_WAIT=%s: all, root, collector or counter", env); }
                         else { t->wait = (WaitMode)w; }
                 }
                 env = getenv("J2P_TILED_EXCHANGE");
@@ -672,6 +695,31 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                         rc = j2p_fail(J2P_EDEVICE, "hipStreamCreate failed");
                 }
         }
+        // ---- direct, wait counter: the counters and flags, and stream memory operations on every device ----
+        // A stream that waits for a value blocks the hardware queue it is mapped to, and a device's streams share a few
+        // hardware queues (four by default): with more than two bands on ONE device a waiting band can sit in front of the
+        // band it waits for — seen as a hang with five bands on one GPU.  (Event waits do not have the problem: the runtime
+        // knows those dependencies.)  So: at most two bands per device, else the event form.
+        if(rc == J2P_OK && t->threaded && t->exchange == kDirect && t->wait == kWaitCounter) {
+                for(unsigned a = 0; a < nband; a++) {
+                        unsigned same = 0;
+                        for(unsigned b = 0; b < nband; b++) { same += devices[a] == devices[b]; }
+                        if(same > 2) { t->wait = kWaitAll; }
+                }
+        }
+        if(rc == J2P_OK && t->threaded && t->exchange == kDirect && t->wait == kWaitCounter) {
+                for(unsigned b = 0; b < nband && rc == J2P_OK; b++) {
+                        int can = 0;
+                        if(hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, devices[b]) != hipSuccess || !can) {
+                                rc = j2p_fail(J2P_EDEVICE, "J2P_TILED_WAIT=counter: device %d has no hipStreamWaitValue", devices[b]);
+                        }
+                }
+                if(rc == J2P_OK && hipHostMalloc((void **)&t->signals, (size_t)2 * nband * 64, hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) {
+                        (void)hipGetLastError();
+                        rc = j2p_fail(J2P_ENOMEM, "J2P_TILED_WAIT=counter: no pinned host memory for the counters");
+                }
+                if(rc == J2P_OK) { memset(t->signals, 0, (size_t)2 * nband * 64); }
+        }
         // ---- direct: tell every band where its neighbours' halo rows and everybody's global arrays are ----
         if(rc == J2P_OK && t->threaded && t->exchange == kDirect) {
                 for(unsigned b = 0; b < nband && rc == J2P_OK; b++) {
@@ -686,6 +734,10 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                                 for(unsigned p = 0; p < nband; p++) { l.push[buf][p] = t->bands[p]->global_rows[buf]; }
                         }
                         l.npush = nband;
+                        if(t->wait == kWaitCounter) {
+                                l.ncount = nband;
+                                for(unsigned p = 0; p < nband; p++) { l.count[p] = t->grad_count(p); }
+                        }
                         rc = j2p_solver_link_bands(bd->solver, &l);
                 }
         }
@@ -720,7 +772,7 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
 int j2p_tiled_exchange(const j2p_tiled *t, const char **name)
 {
         if(!t || !name) { return j2p_fail(J2P_EINVAL, "NULL argument"); }
-        static const char *const direct_names[3] = {"direct", "direct, wait root", "direct, wait collector"};
+        static const char *const direct_names[4] = {"direct", "direct, wait root", "direct, wait collector", "direct, wait counter"};
         *name = !t->threaded ? "none" : (t->exchange == kDirect ? direct_names[t->wait] : kExchangeName[t->exchange]);
         return J2P_OK;
 }
@@ -766,6 +818,7 @@ int j2p_tiled_reset(j2p_tiled *t)
                 for(Band *b : t->bands) { b->grad_recorded = b->edge_recorded = b->norm_recorded = 0; }
         }
         BAND_TRY(j2p_tiled_sync(t));
+        if(t->signals) { memset(t->signals, 0, (size_t)2 * t->nband * 64); }     // (every stream is idle: nobody waits or counts)
         t->iter = 0;
         for(unsigned c = 0; c < J2P_MAX_CHANNELS; c++) { t->carried[c] = 0.; }
         t->carried_valid = true;

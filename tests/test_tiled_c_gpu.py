@@ -190,19 +190,23 @@ def test_direct_exchange_on_every_projection_path(lib, sub, y_only, W, H, monkey
             assert bit_equal(t.download(c), want[c]), f"channel {c}"
 
 
-@pytest.mark.parametrize("wait", ["all", "root", "collector"])
-def test_direct_exchange_wait_modes(lib, wait, monkeypatch):
+@pytest.mark.parametrize("wait,nband", [("all", 5), ("root", 5), ("collector", 5), ("counter", 2), ("counter", 5)])
+@pytest.mark.timeout(180)
+def test_direct_exchange_wait_modes(lib, wait, nband, monkeypatch):
     """how a band's projection learns that every band's gradient launch has finished (J2P_TILED_WAIT): waiting for the
-    N - 1 events itself, for one event of a root band that waited for them, or for one event of a collecting stream —
-    orderings of the same launches, so the same bits; five bands, logged and not, reset in between"""
+    N - 1 events itself, for one event of a root band that waited for them, for one event of a collecting stream, or —
+    no events at all — for one VALUE in host memory that the gradient kernels count up themselves (hipStreamWaitValue64 /
+    hipStreamWriteValue64): orderings of the same launches, so the same bits; five bands, logged and not, reset in
+    between.  The value form is for bands on GPUs of their own (a waiting stream blocks its hardware queue, and a
+    device's streams share four): it runs with two bands here, and with five on one GPU the engine takes the event form"""
     import jpeg2png_amd as j
     planes = make_case(200, 330, "420", 10, seed=82)
     pws = [0.001] * 3
     want, want_rows = whole_canvas(planes, 0.3, pws, 9, log=True)
     monkeypatch.setenv("J2P_TILED_EXCHANGE", "direct")
     monkeypatch.setenv("J2P_TILED_WAIT", wait)
-    with j.TiledSolver(planes, 0.3, pws, 9, devices=[0] * 5) as t:
-        assert t.exchange() == ("direct" if wait == "all" else f"direct, wait {wait}")
+    with j.TiledSolver(planes, 0.3, pws, 9, devices=[0] * nband) as t:
+        assert t.exchange() == ("direct" if wait == "all" or (wait == "counter" and nband > 2) else f"direct, wait {wait}")
         t.run(9)
         for c in range(3):
             assert bit_equal(t.download(c), want[c]), f"{wait}: channel {c}"

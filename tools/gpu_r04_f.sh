@@ -1,18 +1,20 @@
 #!/bin/bash
-# same-box A/B: round 3's library (ab/r03tree, built from commit a770bed) against the current one, headline workload
+# same-box A/B: round 3's library (ab/r03tree, built from commit a770bed) against the current one: headline workload and the
+# other configurations of the bench line
 set -u
 O=gpurun_out/r04f
 mkdir -p $O
 export TMPDIR=/tmp
 R=$(pwd)
-for rep in 1 2 3; do
+for rep in 1 2; do
   for which in r03 cur; do
     if [ $which = r03 ]; then D=ab/r03tree; EXTRA=""; else D=.; EXTRA="--no-host-to-host"; fi
-    ( cd $D && timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs $EXTRA ) 2>&1 | grep '^{' | tail -1 > $R/$O/tmp.json
+    ( cd $D && timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline $EXTRA ) 2>&1 | grep '^{' | tail -1 > $R/$O/tmp.json
     python - <<PY
 import json
 d=json.load(open("$R/$O/tmp.json")); r=d["roofline"]
-print(json.dumps({"library":"$which","rep":$rep,"Mpx_it_per_s":d["value"],"us_per_iteration":round(r["iteration_ms"]*1e3,2),"k_gradient_us":round(r["per_kernel"]["k_gradient"]["avg_launch_ms"]*1e3,2),"k_project_us":round(r["per_kernel"]["k_project"]["avg_launch_ms"]*1e3,2)}))
+oc=d["other_configs"]
+print(json.dumps({"library":"$which","rep":$rep,"Mpx_it_per_s":d["value"],"us_per_iteration":round(r["iteration_ms"]*1e3,2),"config0_ms":oc[0]["ms_per_solve"],"config1_Mpx":oc[1]["Mpx_it_per_s"],"config4_slice_images_per_s":oc[2]["images_per_s"],"band_16384x2048_us":oc[3]["us_per_iteration"]}))
 PY
   done
-done | tee $O/ab_r03_vs_r04.jsonl
+done | tee $O/ab_r03_vs_r04_all.jsonl

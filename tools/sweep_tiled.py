@@ -18,7 +18,8 @@ from sweep_cases import cases
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng([seed, 4242])
-MODES = [("direct", "all", "root"), ("direct", "root", "root"), ("direct", "collector", "root"), ("copy", "all", "root"), ("copy", "all", "all")]
+MODES = [("direct", "all", "root"), ("direct", "root", "root"), ("direct", "collector", "root"), ("direct", "counter", "root"), ("copy", "all", "root"),
+         ("copy", "all", "all")]
 bad = ran = 0
 used = {}
 for cs in cases(seed, n):
