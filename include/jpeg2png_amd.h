@@ -254,7 +254,8 @@ int j2p_solver_link_bands(j2p_solver *s, const j2p_band_links *links);   /* NULL
  * their edge rows is chosen at create time (j2p_tiled_exchange() names it; environment J2P_TILED_EXCHANGE forces one):
  *   "direct" (default where every GPU can write every other's memory): both exchanges ride on the two phase kernels
  *            as posted peer writes (j2p_solver_link_bands) — two launches per band and iteration; J2P_TILED_WAIT=all
- *            (default) | root | collector: how a band's projection learns that every band's gradient has finished;
+ *            (default) | root | collector | counter: how a band's projection learns that every band's gradient has
+ *            finished (events, or — counter — a value in host memory the kernels count up, hipStreamWaitValue64);
  *   "copy"   round 3's schedule — a copy kernel pulls the neighbours' edge rows, one band reduces ||g|| for all
  *            (J2P_TILED_NORM=all: every band for itself) — kept as the cross-check of "direct" and for canvases taller
  *            than 16384 rows;
