@@ -65,8 +65,8 @@ BYTES_GRADIENT = 16              # per canvas pixel per launch (SURVEY.md §8d, 
 BYTES_PROJECT = 22               # phase B
 BYTES_ITERATION = BYTES_GRADIENT + BYTES_PROJECT
 WEIGHT, PWEIGHT = 0.3, 0.001     # jpeg2png.c:22-23 defaults
-RCCL_LEG_TIMEOUT_S = 240         # watchdog of the Python RCCL harness leg of an N > 1 run
-C_LEG_TIMEOUT_S = 180            # ... and of each child process that runs one leg of the C row tiling
+RCCL_LEG_TIMEOUT_S = 180         # watchdog of the Python RCCL harness leg of an N > 1 run
+C_LEG_TIMEOUT_S = 120            # ... and of each child process that runs one leg of the C row tiling
 
 
 def parse():

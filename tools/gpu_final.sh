@@ -6,7 +6,7 @@ TAG=${1:-r04}
 O=gpurun_out/${TAG}_final
 mkdir -p $O
 export TMPDIR=/tmp
-( timeout 1500 python -m pytest tests -m gpu -q --durations=8 ) > $O/pytest_gpu.log 2>&1; echo "pytest gpu rc=$?"; tail -26 $O/pytest_gpu.log
+( timeout 1500 python -m pytest tests -m gpu -q --durations=8 --timeout 900 ) > $O/pytest_gpu.log 2>&1; echo "pytest gpu rc=$?"; tail -26 $O/pytest_gpu.log
 ( timeout 300 python __graft_entry__.py --smoke ) 2>&1 | tail -1
 bash tools/collect_profiles.sh $TAG 2>&1 | tail -6
 # two ranks on this box's one GPU (gloo): the driver's --gpus N launch shape, rank 0 driving two bands, both C schedules
