@@ -517,6 +517,13 @@ void j2p_tiled_destroy(j2p_tiled *t)
         }
         int prev = -1;
         (void)hipGetDevice(&prev);
+        if(t->signals && t->abort.load()) {
+                // wait counter: a band that failed never counts or writes its flag, and the other bands' streams would sit in
+                // their hipStreamWaitValue64 for ever: let every waiter through (what they then compute is thrown away)
+                for(unsigned i = 0; i < 2 * t->nband; i++) {
+                        __atomic_store_n(t->signals + 8 * (size_t)i, (unsigned long long)1 << 62, __ATOMIC_SEQ_CST);
+                }
+        }
         for(Band *b : t->bands) {
                 (void)hipSetDevice(b->device);
                 if(b->stream) { (void)hipStreamSynchronize(b->stream); }
