@@ -1,6 +1,8 @@
 #!/bin/bash
 # same-box A/B: round 3's library (ab/r03tree, built from commit a770bed) against the current one: headline workload and the
-# other configurations of the bench line
+# other configurations of the bench line.  ab/r03tree is made here, before the call (ab/ travels with the lease):
+#   mkdir -p /tmp/r03tree ab && git archive a770bed jpeg2png_amd include bench.py oracle/bindings.py oracle/__init__.py | tar -x -C /tmp/r03tree
+#   (cd /tmp/r03tree && python -c "import jpeg2png_amd; jpeg2png_amd.build()") && cp -r /tmp/r03tree ab/r03tree
 set -u
 O=gpurun_out/r04f
 mkdir -p $O
