@@ -287,6 +287,7 @@ struct GradArgs {
         double *rowsum;         // [local tile row][channel]: the level-1 sums (what the bands of a tiled run exchange)
         float *norm_out;        // [channel]; NULL = stop after level 1 (band solvers, canvases above kFoldMaxRows tile rows)
         unsigned nch_total;     // channels of the solver (partials per strip and tile row)
+        unsigned fold_phase;    // 0 / 1: the iteration's parity, carried in the SIGN BIT of every partial of a folding launch (fold_tile_row)
         unsigned fold_rows;     // tile rows this launch completes
         unsigned ntr_global;    // tile rows of the whole canvas (length of the tree's input)
         // linked bands: where every tile row's sum also goes, in DEVICE memory (one wavefront per tile row reads it; as
@@ -913,14 +914,25 @@ __device__ __forceinline__ void fold_tile_row(const GradArgs &a, unsigned tr, si
                 // element i belongs to running sum i % 8, added in increasing i (strip_sum's order); loads batched
                 for(unsigned i0 = (unsigned)j; i0 < ntx; i0 += 64) {
                         double v[8];
+                        // The strips drew their tickets WITHOUT waiting for their partials to be acknowledged (that wait
+                        // held every wavefront of the launch until its last row of g was written: 3 us of k_gradient at
+                        // 4096^2).  A partial that has not landed yet shows: every partial of this launch carries the
+                        // iteration's parity in its sign bit (a sum of squares has none of its own), and what the slot
+                        // holds until then — the previous launch's partial, complete since that kernel ended, or the
+                        // fill pattern of reset — carries the other parity.  Read again until the parities are right.
+                        bool landed;
+                        do {
+                                landed = true;
+#pragma unroll
+                                for(int u = 0; u < 8; u++) {
+                                        const unsigned i = i0 + 8u * u;
+                                        v[u] = __hip_atomic_load(p + (i < ntx ? i : i0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        landed = landed && (unsigned)(__builtin_bit_cast(unsigned long long, v[u]) >> 63) == a.fold_phase;
+                                }
+                        } while(!landed);
 #pragma unroll
                         for(int u = 0; u < 8; u++) {
-                                const unsigned i = i0 + 8u * u;
-                                v[u] = __hip_atomic_load(p + (i < ntx ? i : i0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-#pragma unroll
-                        for(int u = 0; u < 8; u++) {
-                                if(i0 + 8u * u < ntx) { s += v[u]; }
+                                if(i0 + 8u * u < ntx) { s += __builtin_fabs(v[u]); }
                         }
                 }
         }
@@ -992,11 +1004,11 @@ __device__ __forceinline__ void stores_acknowledged()
 __device__ __forceinline__ void fold_arrive(const GradArgs &a, unsigned tr, unsigned mine, size_t nparts, double *buf, int lane)
 {
         unsigned old = 0;
-        stores_acknowledged();
+        // (no wait for the partial to be acknowledged: the reader checks for itself, see fold_tile_row)
         if(lane == 0) { old = __hip_atomic_fetch_add(a.row_ticket + tr, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
         if(old + mine != a.geo.ntx * a.nch_total) { return; }
-        // last strip of this tile row: every other strip's partials were acknowledged before its ticket
+        // last strip of this tile row: every other strip has ISSUED its partials
         fold_tile_row(a, tr, nparts, lane);
         if(lane == 0) { __hip_atomic_store(a.row_ticket + tr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // ready for the next launch
         const unsigned ncount = a.push ? a.push->ncount : 0u;         // (wave-uniform)
@@ -1387,6 +1399,12 @@ void k_gradient(GradArgs a)
                         double v = g2[c];
 #pragma unroll
                         for(int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); }
+                        // (a folding launch marks its partials with the iteration's parity, see fold_tile_row: the sign bit is SET
+                        // to it, whatever it was — a sum of squares is >= +0, and a NaN must not make the reader wait for ever)
+                        if(a.row_ticket) {
+                                const unsigned long long bits = (__builtin_bit_cast(unsigned long long, v) & ~(1ull << 63)) | ((unsigned long long)a.fold_phase << 63);
+                                v = __builtin_bit_cast(double, bits);
+                        }
                         if(lane == 0) { publish_double(&a.part_g2[(cbase + c) * nparts + (size_t)tr * ntiles_row + wcol], v); }
                 }
                 if(a.row_ticket) { fold_arrive(a, tr, (unsigned)NCH, nparts, fold_buf, lane); }

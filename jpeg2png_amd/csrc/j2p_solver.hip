@@ -296,6 +296,11 @@ struct Carver {
 constexpr size_t kNtWorkingSet = (size_t)260 << 20;      // see nt_policy in j2p_solver_create
 constexpr size_t kNormInProjectPixels = (size_t)5 << 19; // whole canvases up to this size (2.5 Mpixel) reduce ||g|| without a launch of its own
 constexpr size_t kMixedProjectPixels = (size_t)1 << 20;  // canvases up to this size project all channels in one launch
+// whole canvases from this size on (and at most kFoldMaxRows tile rows) reduce ||g|| entirely inside k_gradient: on wide
+// planes the k_norm_whole launch stages 17 K partials through one CU (9 us at W = 16384) — 16384x2048 232.1 -> 229.4 us per
+// iteration, 8192^2 521.6 -> 511.3; at 4096^2 the launch (4.7 us) is the cheaper one, 117.6 vs 119.4
+// (profiles/r04_fold_without_ack_waits.jsonl)
+constexpr size_t kFoldWholePixels = (size_t)1 << 25;
 // fewer gradient wavefronts than this (128-column, 16-row strips) -> 64-column strips.  0 = never: measured on canvases from
 // 0.26 to 16.8 Mpixel (profiles/r03_px_rpw_sweep.jsonl) the one-column-per-lane form is nowhere faster than the packed one
 // with the same rows per strip (512x512 4:2:0 29.2 vs 27.5 us per iteration, 1080p Y 31.1 vs 28.7, 2048^2 45.5 vs 44.4):
@@ -530,6 +535,7 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         }
         a.norm_out = fold_norm ? s->norm : nullptr;
         a.nch_total = s->nch;
+        a.fold_phase = s->iter & 1;
         a.fold_rows = s->ntr_local;
         a.ntr_global = s->ntr_global;
         const bool tgv = s->weight != 0.f;
@@ -804,6 +810,9 @@ int launch_init(j2p_solver *s)
                 }
         }
         HIP_TRY(hipGetLastError());
+        // the partials of a folding gradient launch carry the iteration's parity in their sign bit (fold_tile_row): what
+        // the slots hold before iteration 0 must carry the other one — all bits set
+        HIP_TRY(hipMemsetAsync(s->part_g2, 0xff, (size_t)s->ntx * s->ntr_local * s->nch * sizeof(double), s->stream));
         s->iter = 0;
         s->t = 1.f;
         s->cur = 0;
@@ -918,6 +927,8 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 s->fold = true;
                 s->norm_in_project = true;
         }
+        // ... and on whole canvases large enough for the reduction launch to cost more than the fold (kFoldWholePixels)
+        if(whole && (size_t)W * H >= kFoldWholePixels && (H + kTY - 1) / kTY <= kFoldMaxRows) { s->fold = true; }
         s->band_local = !whole && (band_local_arrays & J2P_BAND_LOCAL_ARRAYS) != 0;
         s->weight = weight;
         s->iterations = iterations;
@@ -1167,6 +1178,11 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
         switch(option) {
         case J2P_OPT_NORM_FOLD:
                 if((s->rowsum_alternate || s->linked) && !value) { return fail(J2P_ESTATE, "alternating / pushed row sums need the folded norm reduction"); }
+                if(value && !s->fold) {
+                        // (the slots must not carry the coming iteration's parity yet, see launch_init)
+                        DeviceGuard guard(s->device);
+                        HIP_TRY(hipMemsetAsync(s->part_g2, (s->iter & 1) ? 0x00 : 0xff, (size_t)s->ntx * s->ntr_local * s->nch * sizeof(double), s->stream));
+                }
                 s->fold = value != 0;
                 break;
         case J2P_OPT_JOINT_INWAVE:
