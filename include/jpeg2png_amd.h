@@ -103,7 +103,8 @@ void j2p_pool_trim(void);
  * schedules).  Only between iterations. */
 #define J2P_OPT_NORM_FOLD     1   /* 1 (default for band solvers and for whole canvases up to 2.5 Mpixel): level 1 of the
                                      ||g|| reduction runs inside the gradient kernel (its last-arriving wavefronts);
-                                     0 (default for larger whole canvases): separate reduction kernel — same bits */
+                                     0: separate reduction kernel; 2 (whole canvases): the gradient launch's last
+                                     workgroup reduces the partials as they arrive — same bits */
 #define J2P_OPT_JOINT_INWAVE  2   /* 1: all channels of a joint image in one wavefront; 0 (default): one wavefront
                                      per channel.  Environment J2P_JOINT_INWAVE sets the default at create time */
 #define J2P_OPT_NORM_IN_PROJECT 4 /* 1 (needs NORM_FOLD): the gradient kernel leaves per-tile-row sums and every wavefront of

@@ -290,6 +290,11 @@ struct GradArgs {
         unsigned fold_phase;    // 0 / 1: the iteration's parity, carried in the SIGN BIT of every partial of a folding launch (fold_tile_row)
         unsigned fold_rows;     // tile rows this launch completes
         unsigned ntr_global;    // tile rows of the whole canvas (length of the tree's input)
+        // whole canvases: non-NULL = no reduction launch between the phases and no tickets either: the grid has one more row
+        // of workgroups whose first workgroup — dispatched last, so every strip is at least on its way — waits for the
+        // partials to land (their sign bits carry the iteration's parity, see fold_tile_row), sums them exactly as
+        // k_norm_whole would and writes ||g|| here (norm_reducer)
+        float *reduce_norm;     // [channel]
         // linked bands: where every tile row's sum also goes, in DEVICE memory (one wavefront per tile row reads it; as
         // 272 bytes of kernel arguments it cost every launch of every solver 0.5 us, same-box A/B); NULL = no push
         const RowsumPush *push;
@@ -1026,6 +1031,54 @@ __device__ __forceinline__ void fold_arrive(const GradArgs &a, unsigned tr, unsi
         if(lane == 0) { __hip_atomic_store(a.done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
+// ---------------------------------------------------------------------------
+// The norm reduction as the LAST WORKGROUP of the gradient launch (GradArgs::reduce_norm): k_norm_whole's arithmetic —
+// strip_sum per tile row, then the padded pairwise tree — on partials that are still arriving.  No ticket, no
+// acknowledgement wait and no kernel boundary synchronise it: a slot whose sign bit does not carry this iteration's
+// parity has not been written yet and is read again.  Workgroups are dispatched in order, so when this one runs every
+// strip has been dispatched: it cannot keep anybody from starting.  buf: kFoldMaxRows doubles of LDS.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double strip_sum_arriving(const double *p, unsigned n, unsigned phase)
+{
+        // strip_sum's order: element i belongs to running sum i % 8, the eight combined pairwise
+        double s[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+        for(unsigned t = 0; t < n; t += 8) {
+                double v[8];
+                bool landed;
+                do {
+                        landed = true;
+#pragma unroll
+                        for(unsigned j = 0; j < 8; j++) {
+                                v[j] = __hip_atomic_load(p + (t + j < n ? t + j : t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                landed = landed && (unsigned)(__builtin_bit_cast(unsigned long long, v[j]) >> 63) == phase;
+                        }
+                } while(!landed);
+#pragma unroll
+                for(unsigned j = 0; j < 8; j++) {
+                        if(t + j < n) { s[j] += __builtin_fabs(v[j]); }
+                }
+        }
+        return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
+__device__ __forceinline__ void norm_reducer(const GradArgs &a, double *buf)
+{
+        const unsigned ntr = a.fold_rows, ntx = a.geo.ntx, T = blockDim.x;
+        unsigned P = 1;
+        while(P < ntr) { P <<= 1; }
+        for(unsigned c = 0; c < a.nch_total; c++) {
+                const double *part = a.part_g2 + (size_t)c * ntr * ntx;
+                for(unsigned r = threadIdx.x; r < P; r += T) { buf[r] = r < ntr ? strip_sum_arriving(part + (size_t)r * ntx, ntx, a.fold_phase) : 0.; }
+                for(unsigned st = P >> 1; st > 0; st >>= 1) {            // tree_sum_lds
+                        __syncthreads();
+                        for(unsigned i = threadIdx.x; i < st; i += T) { buf[i] = buf[i] + buf[i + st]; }
+                }
+                __syncthreads();
+                if(threadIdx.x == 0) { a.reduce_norm[c] = sqrtf((float)buf[0]); }   // compute.c:206
+                __syncthreads();
+        }
+}
+
 #ifndef J2P_GRAD_WAVES
 #define J2P_GRAD_WAVES 4
 #endif
@@ -1058,8 +1111,14 @@ void k_gradient(GradArgs a)
         // row-major run of (segment, strip-group) pairs — vertically adjacent strips then meet in one
         // L2 and their shared halo rows are fetched from HBM once.  Bijective for any grid size.
         unsigned bx = blockIdx.x, bseg = blockIdx.y;
+        // (reduce_norm: the grid's last row of workgroups is not strips — its first workgroup reduces ||g||)
+        const unsigned strip_rows = a.reduce_norm ? gridDim.y - 1 : gridDim.y;
+        if(blockIdx.y == strip_rows) {
+                if(blockIdx.x == 0) { norm_reducer(a, fold_buf); }
+                return;
+        }
         {
-                const unsigned nwg = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+                const unsigned nwg = gridDim.x * strip_rows, b = blockIdx.y * gridDim.x + blockIdx.x;
                 const unsigned xcd = b & 7, q = nwg >> 3, rem = nwg & 7;
                 const unsigned l = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
                 bx = l % gridDim.x;
@@ -1401,7 +1460,7 @@ void k_gradient(GradArgs a)
                         for(int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); }
                         // (a folding launch marks its partials with the iteration's parity, see fold_tile_row: the sign bit is SET
                         // to it, whatever it was — a sum of squares is >= +0, and a NaN must not make the reader wait for ever)
-                        if(a.row_ticket) {
+                        if(a.row_ticket || a.reduce_norm) {
                                 const unsigned long long bits = (__builtin_bit_cast(unsigned long long, v) & ~(1ull << 63)) | ((unsigned long long)a.fold_phase << 63);
                                 v = __builtin_bit_cast(double, bits);
                         }

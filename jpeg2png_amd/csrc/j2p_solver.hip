@@ -95,6 +95,7 @@ struct j2p_solver {
         size_t arena_bytes = 0;
         // reductions
         bool fold = false;       // norm reduction folded into k_gradient (J2P_OPT_NORM_FOLD); default: band solvers only
+        bool reducer = false;    // whole canvases: the gradient launch's last workgroup reduces ||g|| (GradArgs::reduce_norm; J2P_OPT_NORM_FOLD = 2)
         bool joint_inwave = false;   // J2P_OPT_JOINT_INWAVE
         bool norm_in_project = false;   // J2P_OPT_NORM_IN_PROJECT (with fold): level 2 of the norm inside k_project
         int nip_form = 1;               // ... by every wavefront (1: small canvases) or by the workgroup's first (2), see project_strip
@@ -407,6 +408,7 @@ void launch_gradient_n(const GradArgs &a, unsigned ntx, unsigned nseg, hipStream
 {
         // J == 1: 4 strips per 256-thread workgroup; J > 1: one strip per workgroup of J wavefronts
         constexpr unsigned wpb = 4;     // strips per workgroup
+        if(a.reduce_norm) { nseg++; }   // one more row of workgroups: the first of them reduces ||g|| (norm_reducer)
         const dim3 grid = J == 1 ? dim3((ntx + wpb - 1) / wpb, nseg) : dim3(ntx, nseg);
         const dim3 block = J == 1 ? dim3(64 * wpb) : dim3(64 * J);
         if constexpr(NCH == 1 && PX == 2) {
@@ -534,6 +536,8 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
                 a.push = s->push_dev + (s->iter & 1);
         }
         a.norm_out = fold_norm ? s->norm : nullptr;
+        const bool reduce_here = s->reducer && !s->fold && s->whole && part == 0 && s->ntr_global <= kFoldMaxRows;
+        a.reduce_norm = reduce_here ? s->norm : nullptr;
         a.nch_total = s->nch;
         a.fold_phase = s->iter & 1;
         a.fold_rows = s->ntr_local;
@@ -574,7 +578,7 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
                 return J2P_OK;
         }
         s->interior_done = false;
-        s->norm_ready = fold_norm;
+        s->norm_ready = fold_norm || reduce_here;
         s->norm_by_project = nip;
         if(part == 0 && !s->whole && !s->fold) {
                 launch_rowsums(s);
@@ -1178,12 +1182,15 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
         switch(option) {
         case J2P_OPT_NORM_FOLD:
                 if((s->rowsum_alternate || s->linked) && !value) { return fail(J2P_ESTATE, "alternating / pushed row sums need the folded norm reduction"); }
-                if(value && !s->fold) {
+                if(value && !s->fold && !s->reducer) {
                         // (the slots must not carry the coming iteration's parity yet, see launch_init)
                         DeviceGuard guard(s->device);
                         HIP_TRY(hipMemsetAsync(s->part_g2, (s->iter & 1) ? 0x00 : 0xff, (size_t)s->ntx * s->ntr_local * s->nch * sizeof(double), s->stream));
                 }
-                s->fold = value != 0;
+                // 0: reduction launch between the phases; 1: folded into k_gradient by tickets; 2 (whole canvases): the
+                // gradient launch's last workgroup reduces
+                s->fold = value == 1;
+                s->reducer = value == 2;
                 break;
         case J2P_OPT_JOINT_INWAVE:
                 if(value && s->px == 1) { return fail(J2P_ESTATE, "the in-wavefront joint kernel has no one-column-per-lane form (set J2P_JOINT_INWAVE=1 before the solver is created)"); }

@@ -577,6 +577,8 @@ def test_every_schedule_switch_leaves_the_bits_alone(lib, oracle, shape, monkeyp
         {},                                                                         # the solver's own choice
         {j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 0},                     # stand-alone norm kernel
         {j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 1},                     # both levels inside k_gradient
+        {j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 2},                     # ... by the launch's last workgroup, no tickets
+        {j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 2, j.J2P_OPT_NT_GRADIENT: 2, j.J2P_OPT_MIXED_PROJECT: 0},
         {j.J2P_OPT_NORM_FOLD: 1, j.J2P_OPT_NORM_IN_PROJECT: 1},                     # level 2 inside k_project, every wavefront
         {j.J2P_OPT_NORM_FOLD: 1, j.J2P_OPT_NORM_IN_PROJECT: 2, j.J2P_OPT_MIXED_PROJECT: 0},   # ... the workgroup's first wavefront
         {j.J2P_OPT_NORM_FOLD: 1, j.J2P_OPT_NORM_IN_PROJECT: 2, j.J2P_OPT_MIXED_PROJECT: 0, j.J2P_OPT_NT_GRADIENT: 3},
