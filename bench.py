@@ -176,6 +176,17 @@ def _timed(fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
+def pick_leg(timed, truth):
+    """Which leg of the row-tiled bench is `value`: the fastest among the legs whose plane hashes like `truth` (the same
+    canvas solved whole on one GPU); without a truth, or for a leg that left no hash (the per-rank Python harness),
+    `verified` is None and such legs only count when no leg could be verified; a leg with a WRONG plane never counts
+    while any other leg exists.  Sets leg["verified"]; returns the name."""
+    for v in timed.values():
+        v["verified"] = None if (truth is None or v.get("digest") is None) else v["digest"] == truth
+    good = ({k: v for k, v in timed.items() if v["verified"]} or {k: v for k, v in timed.items() if v["verified"] is None} or timed)
+    return min(good, key=lambda k: good[k]["elapsed"])
+
+
 def plane_digest(array):
     import hashlib
     return hashlib.blake2b(np.ascontiguousarray(array), digest_size=16).hexdigest()
@@ -643,10 +654,7 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
             raise SystemExit("bench: no row-tiling engine could run: " + json.dumps({k: v for k, v in legs.items() if not isinstance(v, dict)}))
         # the truth: the whole-canvas solve's hash; without it (skipped / failed) the copy exchange's, round 3's engine
         truth = (whole or {}).get("digest") or timed.get("c_copy", {}).get("digest")
-        for v in timed.values():
-            v["verified"] = None if (truth is None or v.get("digest") is None) else v["digest"] == truth
-        good = {k: v for k, v in timed.items() if v["verified"]} or {k: v for k, v in timed.items() if v["verified"] is None} or timed
-        best = min(good, key=lambda k: good[k]["elapsed"])
+        best = pick_leg(timed, truth)
         L = timed[best]
         value = px * its * a.steps / L["elapsed"] / 1e6
         # pixels per TIMED launch: in the split schedules the events bracket the interior launches only
