@@ -192,6 +192,35 @@ def plane_digest(array):
     return hashlib.blake2b(np.ascontiguousarray(array), digest_size=16).hexdigest()
 
 
+BENCH_DIGESTS = os.path.join(ROOT, "tests", "golden", "bench_digests.json")
+
+
+def reference_digest(W, H, its, seed):
+    """(entry name, blake2b-128) of the plane the UNMODIFIED reference returns (compute.c:455-461) for this bench workload,
+    from tests/golden/bench_digests.json (generated on the CPU box by tests/golden/make_golden.py --bench-digests from
+    oracle/_ref; tests/test_bench_logic.py keeps the file honest) — or (None, None) for a workload without an entry"""
+    try:
+        with open(BENCH_DIGESTS) as f:
+            entries = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    for name, e in entries.items():
+        if (isinstance(e, dict) and "rows_of_the_image" not in e and (e.get("W"), e.get("H"), e.get("iterations"), e.get("seed")) == (W, H, its, seed)
+                and e.get("quality") == 10 and abs(e.get("weight", -1) - WEIGHT) < 1e-12 and abs(e.get("pweight", -1) - PWEIGHT) < 1e-12):
+            return name, e["digest"]
+    return None, None
+
+
+def parity_object(fingerprint, W, H, its, seed):
+    """the second half of BASELINE.json's metric ("...; per-plane PSNR vs CPU reference") for the plane the timed solver
+    left behind: bit-identical to the reference's plane (infinite PSNR), or not, or no digest on file for this workload"""
+    name, want = reference_digest(W, H, its, seed)
+    return {"vs": "the unmodified reference's plane for this workload, by digest (tests/golden/bench_digests.json, blake2b-128)",
+            "entry": name, "bit_identical": None if want is None else fingerprint == want,
+            "psnr_db": "inf" if (want is not None and fingerprint == want) else None,
+            "digest": fingerprint, "reference_digest": want}
+
+
 def whole_canvas_on_one_gpu(j, plane, its, device=0, reps=2, digest=False):
     """a Y plane solved whole on ONE GPU, resident (reset + run): Mpx-it/s and the iteration fraction"""
     s = j.Solver([plane], WEIGHT, [PWEIGHT], its, device=device)
@@ -288,14 +317,15 @@ def other_configs(j, synth):
 
     # the N = 1 point of `--gpus N` (2048 rows of the 16384-wide plane per GPU): one such band, whole, on this GPU
     band = synth.make_planes(16384, 2048, "444", 10, seed=1234 + 4, y_only=True)[0]
-    r = whole_canvas_on_one_gpu(j, band, 100)
+    r = whole_canvas_on_one_gpu(j, band, 100, digest=True)
+    r["parity"] = parity_object(r.pop("digest"), 16384, 2048, 100, 1234 + 4)
     r["config"] = ("configs[3] N = 1 point: 16384x2048 Y-only Q10 -i 100 on one GPU (what `--gpus N` gives every GPU: "
                    "2048 rows of the 16384-wide plane)")
     out.append(r)
     return out
 
 
-def host_to_host(j, planes, its, resident_ms, device=0, reps=3):
+def host_to_host(j, planes, its, resident_ms, device=0, reps=5):
     """SURVEY.md §8(d) "with and without H2D/D2H + aux_init": the C drop-in j2p_compute() — what compute() (compute.h:8)
     is — called like the reference's decode_file() calls it: libc-allocated pageable planes in (int16 coefficients + the
     decoded float plane), the float canvas plane back in newly allocated memory (compute.c:278-310, 455-461 are inside
@@ -303,14 +333,24 @@ def host_to_host(j, planes, its, resident_ms, device=0, reps=3):
     for p in planes:
         if p.fdata is None:
             p.fdata = j.decode_plane(p, device=device)
-    _, secs = j.compute_c(planes, WEIGHT, [PWEIGHT] * len(planes), its, device=device, repeat=reps + 1)
+    splits = []
+    _, secs = j.compute_c(planes, WEIGHT, [PWEIGHT] * len(planes), its, device=device, repeat=reps + 1, splits=splits)
     ms = sorted(s * 1e3 for s in secs[1:])                    # (the first call creates the arena and the pinned slabs)
+    split_ms = {}
+    for key in ("create", "issue", "housekeeping", "wait", "download", "destroy"):
+        vals = sorted(sp[key + "_ms"] for sp in splits[1:])
+        if vals:
+            split_ms[key] = {"median": round(vals[len(vals) // 2], 3), "max": round(vals[-1], 3)}
     px = sum(p.w * p.w_samp * p.h * p.h_samp for p in planes[:1]) * len(planes)
     up = sum(p.w * p.h * 6 for p in planes)
     down = px * 4
     med = ms[len(ms) // 2]
     return {"ms_per_call": round(med, 3), "ms_per_call_all": [round(x, 3) for x in ms], "resident_ms_per_solve": round(resident_ms, 3),
             "boundary_ms": round(med - resident_ms, 3), "upload_bytes": up, "download_bytes": down,
+            "split_ms": split_ms,
+            "split_about": "j2p_compute_timing() per call, median and max over the calls: create = upload + aux_init (compute.c:278-310), issue = "
+                           "queueing the loop, wait = until the last iteration has finished, download (compute.c:455-461), destroy; housekeeping "
+                           "(output pages, freeing the inputs) runs on a helper thread beside issue + wait and is not part of the sum",
             "Mpx_it_per_s": round(px * its / (med * 1e-3) / 1e6, 1),
             "what": "j2p_compute() (the C drop-in behind compute(), compute.h:8) from libc-allocated pageable planes: upload of the "
                     "int16 coefficients and the decoded float plane, aux_init, all iterations, download into a newly allocated "
@@ -486,6 +526,8 @@ def single_gpu(a, j, synth, local_rank):
                                               solver, a.timing_every)
     px = W * H
     value = px * its * a.steps / elapsed / 1e6
+    # the plane the LAST timed step left behind (every step is a whole solve from iteration 0), against the reference's
+    parity = parity_object(plane_digest(solver.download(0)), W, H, its, seed)
     per_kernel = per_kernel_roofline(px, px, g_ms, p_ms)
     traffic, traffic_src = pmc_traffic() if not a.size else (None, None)
     out = {
@@ -496,7 +538,12 @@ def single_gpu(a, j, synth, local_rank):
         "config": {"workload": workload, "iterations_per_step": its, "weight": WEIGHT, "pweight": PWEIGHT,
                    "parallelism": "single GPU"},
         "roofline": roofline_object(value, 1, its, elapsed, a.steps, px, per_kernel, samples, a.timing_every, traffic, traffic_src),
+        "parity": parity,
     }
+    if parity["bit_identical"] is False:
+        # a plane that is not the reference's: the figure is set aside (the driver treats a null value as unmeasured)
+        out["unverified_value"] = out["value"]
+        out["value"] = None
     solver.close()
     if not a.no_host_to_host and not a.size:
         try:
@@ -685,8 +732,12 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
                        "parallelism": L["parallelism"], "engine": best, "band_threads_host_cpu_s": L.get("host_cpu_s"),
                        "bits_equal_to_the_whole_canvas_solve": L["verified"]},
             "roofline": roofline_object(value, gpus_used, its, L["elapsed"], a.steps, band_px, per_kernel, L["samples"], a.timing_every),
+            "parity": parity_object(L.get("digest"), W, H, its, seed),
             "other_configs": others,
         }
+        if out["parity"]["bit_identical"] is False or L["verified"] is False:
+            out["unverified_value"] = out["value"]
+            out["value"] = None
         state["out"] = out
 
     finish(strict=False)
@@ -770,6 +821,7 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
         extra = []
         if whole is not None and "error" not in whole:
             r = {k: v for k, v in whole.items() if k != "digest"}
+            r["parity"] = parity_object(whole.get("digest"), W, H, its, seed)
             r["config"] = (f"strong-scaling denominator: the SAME {W}x{H} canvas solved whole on ONE GPU, -i {its} "
                            "(value / this = speed-up of the tiling; its plane's hash is what every leg is compared with)")
             r["speedup_of_the_tiled_run"] = round(state["out"]["value"] / r["Mpx_it_per_s"], 3)

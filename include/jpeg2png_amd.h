@@ -376,6 +376,12 @@ void j2p_batch_destroy(j2p_batch *b);                       /* finishes queued j
 int j2p_batch_submit(j2p_batch *b, const j2p_job *job, int *ticket);
 int j2p_batch_wait(j2p_batch *b, int ticket);               /* the job's status; its error text in j2p_last_error() */
 
+/* test hook: n > 0: the n-th j2p_solver_run() / j2p_tiled_run() call from now on (any thread) fails with J2P_EDEVICE
+ * before it queues anything — how the tests make a solve fail after its create phase (j2p_compute()'s error contract);
+ * n < 0: in the |n|-th j2p_tiled_run() of a multi-band solver the LAST band fails halfway through its iterations, with
+ * the other bands' work queued behind it (the teardown of a failed row-tiled run); 0 disarms. */
+void j2p_debug_fail_run_after(int n);
+
 /* test hook: compares the kernels' fast division / square root (the compiler's IEEE
  * sequences without range scaling) with `/` and sqrtf() on n pseudo-random operand pairs
  * inside the range the kernels screen for; both counters must come back 0 */

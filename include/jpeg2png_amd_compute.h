@@ -69,9 +69,22 @@ struct coef {
 void compute(unsigned nchannel, struct coef coefs[], struct logger *log, struct progressbar *pb,
              float weight, float pweight[], unsigned iterations);
 
-/* same, with an explicit device and an error code instead of exit(); 0 on success */
+/* same, with an explicit device and an error code instead of exit(); 0 on success.
+ * On an error return the caller still owns its inputs: coefs[c].fdata (and w / h) are untouched unless the failure came
+ * AFTER every iteration had been queued on the device — the final synchronisation or the download, i.e. a device fault —
+ * in which case the input planes have already been released, as compute.c:304-305 does at aux_init, and fdata is NULL. */
 int j2p_compute(int device, unsigned nchannel, struct coef coefs[], struct logger *log,
                 struct progressbar *pb, float weight, const float pweight[], unsigned iterations);
+
+/* where the wall time of the calling thread's last successful compute() / j2p_compute() / j2p_compute_tiled() went (ms):
+ * create = upload + aux_init (compute.c:278-310), issue = queueing the iteration loop, housekeeping = preparing the output
+ * planes and freeing the inputs on a helper thread BESIDE the loop (not part of the sum), wait = until the last iteration
+ * has finished, download (compute.c:455-461), destroy; total = create + issue + wait + download + destroy.
+ * J2P_ESTATE when the thread has no successful call behind it. */
+typedef struct j2p_compute_times {
+        double create_ms, issue_ms, housekeeping_ms, wait_ms, download_ms, destroy_ms, total_ms;
+} j2p_compute_times;
+int j2p_compute_timing(j2p_compute_times *out);
 
 
 /* compute() with the canvas cut into `nband` row bands, band i on devices[i] (ids may repeat: several bands on

@@ -82,7 +82,7 @@ C_ABI_SYMBOLS = [
     "j2p_tiled_download", "j2p_tiled_host_cpu_seconds", "j2p_solver_norm_ptr", "j2p_solver_norm_external",
     "j2p_solver_global_rowsums", "j2p_solver_link_bands", "j2p_tiled_exchange",
     "j2p_batch_create", "j2p_batch_destroy", "j2p_batch_submit", "j2p_batch_wait",
-    "compute", "j2p_compute", "j2p_compute_tiled",
+    "compute", "j2p_compute", "j2p_compute_tiled", "j2p_compute_timing", "j2p_debug_fail_run_after",
     "j2p_debug_build", "j2p_solver_debug_violations", "j2p_solver_trace", "j2p_division_exhaustive",
 ]
 J2P_OPT_NORM_FOLD, J2P_OPT_JOINT_INWAVE, J2P_OPT_NORM_IN_PROJECT, J2P_OPT_NT_GRADIENT, J2P_OPT_MIXED_PROJECT = 1, 2, 4, 5, 6
@@ -580,12 +580,17 @@ class _CCoef(ctypes.Structure):
                 ("data", ctypes.c_void_p), ("fdata", ctypes.c_void_p), ("quant_table", ctypes.c_uint16 * 64)]
 
 
-def compute_c(planes, weight, pweight, iterations, device=0, repeat=1):
+class _CComputeTimes(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_double) for k in ("create_ms", "issue_ms", "housekeeping_ms", "wait_ms", "download_ms", "destroy_ms", "total_ms")]
+
+
+def compute_c(planes, weight, pweight, iterations, device=0, repeat=1, splits=None):
     """The C drop-in itself — j2p_compute(), what compute() (compute.h:8) is behind its die() wrapper — called the way
     the reference's decode_file() calls it (jpeg2png.c:141-152): planes that libc allocated (alloc_simd, utils.h:89-98),
     the float plane freed and a new one handed back (compute.c:304-305, 455-461), no logger, no progress bar.
     Returns (canvas planes of the last call, [seconds inside j2p_compute per call]): the host-to-host cost of the
-    boundary, pageable memory on both sides."""
+    boundary, pageable memory on both sides.  `splits` (a list) receives one dict per call from j2p_compute_timing():
+    where that call's wall time went."""
     import time
     lib = load_library()
     libc = ctypes.CDLL(None)
@@ -616,6 +621,10 @@ def compute_c(planes, weight, pweight, iterations, device=0, repeat=1):
         t0 = time.perf_counter()
         rc = lib.j2p_compute(int(device), n, coefs, None, None, float(weight), pw, int(iterations))
         seconds.append(time.perf_counter() - t0)
+        if splits is not None and rc == 0:
+            ct = _CComputeTimes()
+            if lib.j2p_compute_timing(ctypes.byref(ct)) == 0:
+                splits.append({k: getattr(ct, k) for k, _ in _CComputeTimes._fields_})
         try:
             _check(rc)
             outs = []

@@ -4,7 +4,7 @@
  * Plain C like the reference's host code; the device work is entirely behind
  * j2p_solver_* (include/jpeg2png_amd.h).
  */
-#define _POSIX_C_SOURCE 200809L        /* clock_gettime under -std=c11 */
+#define _DEFAULT_SOURCE                 /* clock_gettime, madvise under -std=c11 */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -12,6 +12,7 @@
 #include <assert.h>
 #include <pthread.h>
 #include <time.h>
+#include <sys/mman.h>
 
 #include "jpeg2png_amd.h"
 #include "jpeg2png_amd_compute.h"
@@ -33,16 +34,38 @@ extern void progressbar_inc(struct progressbar *pb) __attribute__((weak));
  * `jpeg2png: ` prefix goes out.  Used when the host has it, so that a failure in here reads like one of its own. */
 extern void die_message_start(void) __attribute__((weak));
 
-/* J2P_COMPUTE_TIMING=1: one line on stderr per call with where its wall time went (create = upload + aux_init issue,
- * housekeeping = freeing the inputs and preparing the output planes while the GPU iterates, wait = until the last
- * iteration has finished, download, destroy) — the host-to-host figure of bench.py taken apart */
+/* Where a call's wall time went: create = upload + aux_init issue, issue = queueing the iteration loop, housekeeping =
+ * preparing the output planes and freeing the inputs on a helper thread BESIDE the loop, wait = until the last iteration
+ * has finished, download, destroy.  Kept per calling thread for j2p_compute_timing() — the host-to-host figure of
+ * bench.py taken apart; J2P_COMPUTE_TIMING=1 also prints one line per call on stderr. */
+/* (internal, j2p_solver.hip) the calling thread's j2p_last_error() text */
+extern void j2p_set_last_error(const char *msg);
+extern int j2p_tiled_exchange_forced(void);          /* (internal, j2p_tiled.hip) */
+
 static double now_ms(void)
 {
         struct timespec ts;
         clock_gettime(CLOCK_MONOTONIC, &ts);
         return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
 }
+static _Thread_local j2p_compute_times last_times;
+static _Thread_local int last_times_valid;
 
+int j2p_compute_timing(j2p_compute_times *out)
+{
+        if(!out || !last_times_valid) { return J2P_ESTATE; }
+        *out = last_times;
+        return J2P_OK;
+}
+
+/* What the host owes the caller besides the solve, done by a helper thread while the GPU iterates: the planes compute()
+ * hands back (compute.c:455-461) are allocated and their pages touched, so that the download at the end writes into
+ * mapped memory, and the input planes are freed (aux_init frees them as soon as they are up-sampled, compute.c:304-305 —
+ * they are on the device since create).  In line, between two chunks of iterations, those ~12 ms for a 64 MiB plane left
+ * the GPU idle: it runs 32 iterations in 4.
+ * The inputs go only once the main thread says so (`verdict`): after EVERY iteration has been queued without an error —
+ * a call that fails before that returns with coefs[c].fdata untouched, so that the caller of j2p_compute() can retry,
+ * on another device for instance (tests/test_capi_gpu.py). */
 struct housekeeping {
         unsigned nchannel;
         struct coef *coefs;
@@ -50,20 +73,46 @@ struct housekeeping {
         float *out[J2P_MAX_CHANNELS];
         int failed;
         double ms;
+        pthread_mutex_t lock;
+        pthread_cond_t cv;
+        int verdict;               /* 0: undecided, 1: the loop is queued, free the inputs, -1: keep them */
 };
+
+static void housekeeping_outputs(struct housekeeping *h)
+{
+        for(unsigned c = 0; c < h->nchannel; c++) {
+                /* alloc_simd (utils.h:89-98) is aligned_alloc(16, ...); 2 MiB alignment + MADV_HUGEPAGE lets a kernel with
+                 * transparent huge pages map the plane with 32 faults per 64 MiB instead of 16384 (free() takes either) */
+                const size_t big = (size_t)2 << 20;
+                h->out[c] = h->out_bytes >= 4 * big ? aligned_alloc(big, (h->out_bytes + big - 1) & ~(big - 1)) : aligned_alloc(16, h->out_bytes);
+                if(!h->out[c]) { h->failed = 1; continue; }
+#ifdef MADV_HUGEPAGE
+                if(h->out_bytes >= 4 * big) { (void)madvise(h->out[c], h->out_bytes, MADV_HUGEPAGE); }
+#endif
+                for(size_t off = 0; off < h->out_bytes; off += 4096) { ((volatile char *)h->out[c])[off] = 0; }
+        }
+}
+
+static void housekeeping_inputs(struct housekeeping *h)
+{
+        for(unsigned c = 0; c < h->nchannel; c++) {
+                free(h->coefs[c].fdata);                                           /* compute.c:304-305 */
+                h->coefs[c].fdata = NULL;
+        }
+}
 
 static void *housekeeping_main(void *arg)
 {
         struct housekeeping *h = arg;
         const double t0 = now_ms();
-        for(unsigned c = 0; c < h->nchannel; c++) {
-                free(h->coefs[c].fdata);                                           /* compute.c:304-305 */
-                h->coefs[c].fdata = NULL;
-                h->out[c] = aligned_alloc(16, h->out_bytes);                       /* alloc_simd, utils.h:89-98 */
-                if(!h->out[c]) { h->failed = 1; continue; }
-                for(size_t off = 0; off < h->out_bytes; off += 4096) { ((volatile char *)h->out[c])[off] = 0; }
-        }
-        h->ms = now_ms() - t0;
+        housekeeping_outputs(h);
+        pthread_mutex_lock(&h->lock);
+        while(h->verdict == 0) { pthread_cond_wait(&h->cv, &h->lock); }
+        const int go = h->verdict > 0 && !h->failed;
+        pthread_mutex_unlock(&h->lock);
+        const double t1 = now_ms();
+        if(go) { housekeeping_inputs(h); }
+        h->ms = (t1 - t0) + (now_ms() - t1);        /* (the time spent waiting for the verdict is the main thread's) */
         return NULL;
 }
 
@@ -73,6 +122,7 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
                       struct progressbar *pb, float weight, const float pweight[], unsigned iterations)
 {
         assert(FLT_ROUNDS == 1);                               /* compute.c:408 */
+        last_times_valid = 0;
         if(nchannel == 0 || nchannel > J2P_MAX_CHANNELS || !coefs || !pweight || !devices || nband == 0) { return J2P_EINVAL; }
         j2p_plane planes[J2P_MAX_CHANNELS];
         for(unsigned c = 0; c < nchannel; c++) {
@@ -93,6 +143,13 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
         t_mark[0] = now_ms();
         if(nband > 1) {
                 rc = j2p_tiled_create(&t, nband, devices, NULL, nchannel, planes, weight, pweight, iterations);
+                if((rc == J2P_EDEVICE || rc == J2P_ENOMEM) && !j2p_tiled_exchange_forced()) {
+                        /* these GPUs cannot be tiled over (no peer access and no RCCL, or no exchange that reproduces the
+                         * one-GPU solve on them): the first of them solves the canvas alone — same bits, nothing has run yet */
+                        fprintf(stderr, "jpeg2png_amd: not row-tiling this canvas over %u GPUs (%s); solving it on GPU %d\n", nband, j2p_last_error(), devices[0]);
+                        j2p_band whole = {0, 0};
+                        rc = j2p_solver_create(&s, devices[0], NULL, nchannel, planes, weight, pweight, iterations, whole, 0);
+                }
         } else {
                 j2p_band whole = {0, 0};
                 rc = j2p_solver_create(&s, devices[0], NULL, nchannel, planes, weight, pweight, iterations, whole, 0);
@@ -103,21 +160,18 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
         j2p_log_row rows[J2P_CHUNK];
         unsigned W = 0, H = 0;
         if(t) { j2p_tiled_canvas(t, &W, &H, NULL); } else { j2p_solver_canvas(s, &W, &H); }
-        /* While the GPU iterates, a helper thread does what the host owes the caller: aux_init frees the input planes
-         * as soon as they are up-sampled (compute.c:304-305) — they are on the device since create — and the planes
-         * compute() hands back (compute.c:455-461) are allocated and their pages touched, so that the download at the
-         * end writes into mapped memory.  (In line, between two chunks of iterations, those ~12 ms for a 64 MiB plane
-         * left the GPU idle: it runs 32 iterations in 4.) */
         struct housekeeping hk;
         hk.nchannel = nchannel;
         hk.coefs = coefs;
         hk.out_bytes = (sizeof(float) * (size_t)W * H + 15) & ~(size_t)15;
         hk.failed = 0;
         hk.ms = 0.;
+        hk.verdict = 0;
+        pthread_mutex_init(&hk.lock, NULL);
+        pthread_cond_init(&hk.cv, NULL);
         for(unsigned c = 0; c < J2P_MAX_CHANNELS; c++) { hk.out[c] = NULL; }
         pthread_t hk_thread;
-        int hk_started = pthread_create(&hk_thread, NULL, housekeeping_main, &hk) == 0;
-        if(!hk_started) { housekeeping_main(&hk); }
+        const int hk_started = pthread_create(&hk_thread, NULL, housekeeping_main, &hk) == 0;
         unsigned done = 0;
         while(done < iterations) {
                 unsigned n = iterations - done;
@@ -137,13 +191,30 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
                 }
                 done += n;
         }
-        if(hk_started) { pthread_join(hk_thread, NULL); }
+        /* every iteration is queued (or one failed): the inputs may go (or stay) */
+        if(hk_started) {
+                pthread_mutex_lock(&hk.lock);
+                hk.verdict = rc == J2P_OK ? 1 : -1;
+                pthread_cond_signal(&hk.cv);
+                pthread_mutex_unlock(&hk.lock);
+                t_mark[2] = now_ms();
+                pthread_join(hk_thread, NULL);
+        } else {
+                t_mark[2] = now_ms();
+                const double h0 = now_ms();
+                housekeeping_outputs(&hk);
+                if(rc == J2P_OK && !hk.failed) { housekeeping_inputs(&hk); }
+                hk.ms = now_ms() - h0;
+        }
+        pthread_mutex_destroy(&hk.lock);
+        pthread_cond_destroy(&hk.cv);
         t_house = hk.ms;
         float **outp = hk.out;
-        if(rc == J2P_OK && hk.failed) { rc = J2P_ENOMEM; }
+        if(rc == J2P_OK && hk.failed) { j2p_set_last_error("out of host memory for the output planes"); rc = J2P_ENOMEM; }
+        t_mark[3] = t_mark[2];
         if(rc != J2P_OK) { goto out; }
-        t_mark[2] = now_ms();
-        if(timing) { rc = t ? j2p_tiled_sync(t) : j2p_solver_sync(s); if(rc != J2P_OK) { goto out; } }
+        rc = t ? j2p_tiled_sync(t) : j2p_solver_sync(s);
+        if(rc != J2P_OK) { goto out; }
         t_mark[3] = now_ms();
         for(unsigned c = 0; c < nchannel; c++) {
                 rc = t ? j2p_tiled_download(t, c, outp[c]) : j2p_solver_download(s, c, outp[c]);
@@ -161,10 +232,20 @@ out:
         if(t) { j2p_tiled_destroy(t); }
         if(s) { j2p_solver_destroy(s); }
         t_mark[5] = now_ms();
-        if(timing && rc == J2P_OK) {
-                fprintf(stderr, "j2p compute timing (ms): create %.2f, issue %.2f (beside it, on a helper thread: housekeeping %.2f), wait %.2f, download %.2f, destroy %.2f, total %.2f\n",
-                        t_mark[1] - t_mark[0], t_mark[2] - t_mark[1], t_house, t_mark[3] - t_mark[2], t_mark[4] - t_mark[3],
-                        t_mark[5] - t_mark[4], t_mark[5] - t_mark[0]);
+        if(rc == J2P_OK) {
+                last_times.create_ms = t_mark[1] - t_mark[0];
+                last_times.issue_ms = t_mark[2] - t_mark[1];
+                last_times.housekeeping_ms = t_house;
+                last_times.wait_ms = t_mark[3] - t_mark[2];
+                last_times.download_ms = t_mark[4] - t_mark[3];
+                last_times.destroy_ms = t_mark[5] - t_mark[4];
+                last_times.total_ms = t_mark[5] - t_mark[0];
+                last_times_valid = 1;
+                if(timing) {
+                        fprintf(stderr, "j2p compute timing (ms): create %.2f, issue %.2f (beside it, on a helper thread: housekeeping %.2f), wait %.2f, download %.2f, destroy %.2f, total %.2f\n",
+                                last_times.create_ms, last_times.issue_ms, t_house, last_times.wait_ms, last_times.download_ms,
+                                last_times.destroy_ms, last_times.total_ms);
+                }
         }
         return rc;
 }

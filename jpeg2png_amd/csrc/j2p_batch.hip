@@ -24,6 +24,8 @@
 #include "jpeg2png_amd.h"
 #include "j2p_internal.h"
 
+extern "C" int j2p_tiled_exchange_forced(void);     // j2p_tiled.hip
+
 namespace {
 
 struct Job {
@@ -132,9 +134,11 @@ int run_job_tiled(const j2p_job &d, const std::vector<int> &devices, bool *handl
                 } else {
                         rc = j2p_tiled_create(&t[k], nband, devices.data(), cuts, d.nchannel, d.planes, d.weight[0], d.pweight, its[k]);
                 }
-                if(rc == J2P_EDEVICE || rc == J2P_ENOMEM) {
-                        // these GPUs cannot be tiled over (or have no room for it): the image is solved on one of them,
-                        // as it would have been without `tile`.  Nothing has run yet.
+                if((rc == J2P_EDEVICE || rc == J2P_ENOMEM) && !j2p_tiled_exchange_forced()) {
+                        // these GPUs cannot be tiled over (no peer access and no RCCL, no exchange that verifies on them, or
+                        // no room for the band arenas): the image is solved on one of them, as it would have been without
+                        // `tile`.  Nothing has run yet.  (An exchange NAMED through J2P_TILED_EXCHANGE / J2P_TILED_WAIT that
+                        // cannot be had is an error: the caller asked for that one.)
                         fprintf(stderr, "jpeg2png_amd: not row-tiling this image over %u GPUs (%s); solving it on one\n", nband, j2p_last_error());
                         rc = J2P_OK;
                         goto out;

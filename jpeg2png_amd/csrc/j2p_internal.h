@@ -12,3 +12,8 @@ int j2p_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)
 void j2p_rows_from_sums_carry(unsigned nch, float weight, const float *pweight, unsigned n, const double *sums,
                               double *carried, bool carried_valid, j2p_log_row *rows);
 
+
+// test hook behind j2p_debug_fail_run_after(): true when THIS run call is the one that has to fail
+bool j2p_injected_failure();
+// ... (negative argument) true when the LAST band of this threaded run has to fail halfway through its iterations
+bool j2p_injected_band_failure();

@@ -1784,6 +1784,41 @@ struct NumScreen {
 __device__ __forceinline__ bool den_ok(float d) { return d >= 0x1p-20f && d <= 0x1p26f; }
 
 
+// Stores into a NEIGHBOURING BAND's halo rows (ProjArgs::halo_up / halo_down: another GPU's memory over xGMI, or this
+// GPU's) are system-scope write-through stores (sc0 sc1: performed at the destination, nothing left dirty in this XCD's
+// L2), so that they are visible to the peer as soon as the kernel has ended whatever publishes that fact — an event
+// record with its system-scope release, or a value written behind the kernel (J2P_TILED_WAIT=counter), which releases
+// nothing by itself.  Only the strips of a band's first / last block row get here: 4- and 8-byte stores are fast enough.
+// -DJ2P_EXP_DROP_HALO_PUSH (fault injection, tests/test_tiled_verify_gpu.py): the rows are NOT pushed — the exchange is
+// broken on purpose, and j2p_tiled_create's verification has to notice and demote it.
+__device__ __forceinline__ void peer_store(float *p, float v)
+{
+#ifndef J2P_EXP_DROP_HALO_PUSH
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+        (void)p; (void)v;
+#endif
+}
+__device__ __forceinline__ void peer_store2(float *p, float a, float b)      // p is 8-byte aligned
+{
+#ifndef J2P_EXP_DROP_HALO_PUSH
+        const v2f v = v2f{a, b};
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+        (void)p; (void)a; (void)b;
+#endif
+}
+template <int WS, class VWS>
+__device__ __forceinline__ void peer_store_ws(float *p, VWS o)
+{
+        if constexpr(WS == 2) { peer_store2(p, o[0], o[1]); }
+        else {
+#pragma unroll
+                for(int i = 0; i < WS; i++) { peer_store(p + i, o[i]); }
+        }
+}
+
 // Phase B front/back end for a SUBSAMPLED channel whose 64 x 8 coefficient strip lies wholly
 // inside the canvas: lane = coefficient column = WS canvas columns, 8*HS canvas rows.
 // Keeps the stepped pixels in registers between the block-mean (compute.c:348-360) and the
@@ -1883,8 +1918,8 @@ __device__ __forceinline__ void sub_store_residual(const ChanDev &k, size_t base
                         *reinterpret_cast<vws *>(k.xprev + base + (size_t)(r * HS + sy) * W) = o;
                         // (the strip covers whole block rows of the band: its rows 0, 1 / 8 HS - 2, 8 HS - 1 are the band's)
                         const int row = r * HS + sy;
-                        if(row < kHalo && halo_up) { *reinterpret_cast<vws *>(halo_up + (size_t)row * W) = o; }
-                        if(row >= 8 * HS - kHalo && halo_down) { *reinterpret_cast<vws *>(halo_down + (size_t)(row - (8 * HS - kHalo)) * W) = o; }
+                        if(row < kHalo && halo_up) { peer_store_ws<WS>(halo_up + (size_t)row * W, o); }
+                        if(row >= 8 * HS - kHalo && halo_down) { peer_store_ws<WS>(halo_down + (size_t)(row - (8 * HS - kHalo)) * W, o); }
                 }
         }
 }
@@ -2101,7 +2136,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                                 if(!covered) {
                                         k.xprev[off] = v[r];           // stepped but never projected (SURVEY §7 hard part 5); address checked by stepped()
                                         if constexpr(PUSH) {
-                                                if(float *h = halo_copy_of(ly0 + r)) { h[cx] = v[r]; }
+                                                if(float *h = halo_copy_of(ly0 + r)) { peer_store(h + cx, v[r]); }
                                         }
                                 }
                         }
@@ -2121,7 +2156,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                                                 else {
                                                         k.xprev[off] = f;
                                                         if constexpr(PUSH) {
-                                                                if(float *h = halo_copy_of(ly)) { h[x] = f; }
+                                                                if(float *h = halo_copy_of(ly)) { peer_store(h + x, f); }
                                                         }
                                                 }
                                         }
@@ -2241,9 +2276,8 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                         dst[1] = make_float4(v[4], v[5], v[6], v[7]);
                         if constexpr(PUSH) {
                                 if(float *h = halo_copy_of(ly0 + rr)) {
-                                        float4 *hd = reinterpret_cast<float4 *>(h + bx * 8);
-                                        hd[0] = make_float4(v[0], v[1], v[2], v[3]);
-                                        hd[1] = make_float4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+                                        for(int u = 0; u < 8; u += 2) { peer_store2(h + bx * 8 + u, v[u], v[u + 1]); }
                                 }
                         }
                 }
@@ -2263,7 +2297,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                                 const float o = (st1[r] - mean_old[r]) + v[r];
                                 k.xprev[base + (size_t)r * W] = o;
                                 if constexpr(PUSH) {
-                                        if(float *h = halo_copy_of(ly0 + r)) { h[cx] = o; }
+                                        if(float *h = halo_copy_of(ly0 + r)) { peer_store(h + cx, o); }
                                 }
                         }
                 } else if(covered) {
@@ -2277,7 +2311,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                                                 f = f - mean_old[r];
                                                 k.xprev[off] = f + v[r];
                                                 if constexpr(PUSH) {
-                                                        if(float *h = halo_copy_of(ly)) { h[x] = f + v[r]; }
+                                                        if(float *h = halo_copy_of(ly)) { peer_store(h + x, f + v[r]); }
                                                 }
                                         }
                                 }

@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -838,6 +839,16 @@ extern "C" {
 
 const char *j2p_version(void) { return "jpeg2png_amd 0.1 (gfx950)"; }
 const char *j2p_last_error(void) { return g_err; }
+void j2p_set_last_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }   // (for compute_host.c; not in the header)
+
+// test hook: the n-th j2p_solver_run / j2p_tiled_run from now on fails with J2P_EDEVICE before it queues anything
+// (0 = disarm) — how tests/test_capi_gpu.py makes a solve fail after create
+static std::atomic<int> g_fail_run{0}, g_fail_band{0};
+void j2p_debug_fail_run_after(int n)
+{
+        g_fail_run.store(n > 0 ? n : 0);
+        g_fail_band.store(n < 0 ? -n : 0);
+}
 
 int j2p_device_count(int *count)
 {
@@ -1362,6 +1373,17 @@ static void rows_from_sums(unsigned nch, float weight, const float *pweight, uns
 
 }  // extern "C"
 
+static bool countdown(std::atomic<int> &a)
+{
+        int v = a.load(std::memory_order_relaxed);
+        while(v > 0) {
+                if(a.compare_exchange_weak(v, v - 1)) { return v == 1; }
+        }
+        return false;
+}
+bool j2p_injected_failure() { return countdown(g_fail_run); }
+bool j2p_injected_band_failure() { return countdown(g_fail_band); }
+
 void j2p_rows_from_sums_carry(unsigned nch, float weight, const float *pweight, unsigned n, const double *sums,
                               double *carried, bool carried_valid, j2p_log_row *rows)
 {
@@ -1399,6 +1421,7 @@ int j2p_solver_run(j2p_solver *s, unsigned n, j2p_log_row *rows)
 {
         if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
         if(!s->whole) { return fail(J2P_ESTATE, "j2p_solver_run needs a whole-canvas solver; drive bands with the phase calls"); }
+        if(j2p_injected_failure()) { return fail(J2P_EDEVICE, "injected failure (j2p_debug_fail_run_after)"); }
         DeviceGuard guard(s->device);
         const bool log = rows != nullptr;
         constexpr unsigned kRow = 2 + kMaxCh;

@@ -36,7 +36,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <map>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -80,6 +82,7 @@ struct Rccl {
         void *handle = nullptr;
         int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
         int (*CommDestroy)(void *comm) = nullptr;
+        int (*CommAbort)(void *comm) = nullptr;             // optional: how a failed run leaves its queued collectives
         int (*AllGather)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t st) = nullptr;
         int (*Broadcast)(const void *send, void *recv, size_t count, int dtype, int root, void *comm, hipStream_t st) = nullptr;
         int (*Send)(const void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t st) = nullptr;
@@ -123,6 +126,7 @@ Rccl *rccl_load()
         } while(0)
         RCCL_SYM(CommInitAll, "ncclCommInitAll");
         RCCL_SYM(CommDestroy, "ncclCommDestroy");
+        *reinterpret_cast<void **>(&r->CommAbort) = dlsym(r->handle, "ncclCommAbort");
         RCCL_SYM(AllGather, "ncclAllGather");
         RCCL_SYM(Broadcast, "ncclBroadcast");
         RCCL_SYM(Send, "ncclSend");
@@ -330,8 +334,10 @@ int band_iterations(j2p_tiled *t, unsigned b, unsigned n, bool log)
         }
         const bool by_root = t->norm_by_root;
         Band *root = t->bands[t->root];
+        const bool doomed = b + 1 == t->nband && j2p_injected_band_failure();      // (test hook, j2p_debug_fail_run_after(-n))
         for(unsigned i = 0; i < n; i++) {
                 const uint64_t it = t->iter + i;
+                if(doomed && i == n / 2) { return j2p_fail(J2P_EDEVICE, "injected band failure (j2p_debug_fail_run_after)"); }
                 switch(t->exchange) {
                 case kDirect:
                         if(t->wait == kWaitCounter) {
@@ -420,6 +426,17 @@ double thread_cpu_seconds()
         return (double)u.ru_utime.tv_sec + (double)u.ru_stime.tv_sec + 1e-6 * ((double)u.ru_utime.tv_usec + (double)u.ru_stime.tv_usec);
 }
 
+// wait counter: a band that failed never counts or writes its flag, and the other bands' streams would sit in their
+// hipStreamWaitValue64 for ever — and with them every j2p_tiled_sync() and the destroy.  Let every waiter through (what
+// they then compute is thrown away: the solver is unusable once `abort` is set).
+void release_value_waiters(j2p_tiled *t)
+{
+        if(!t->signals) { return; }
+        for(unsigned i = 0; i < 2 * t->nband; i++) {
+                __atomic_store_n(t->signals + 8 * (size_t)i, (unsigned long long)1 << 62, __ATOMIC_SEQ_CST);
+        }
+}
+
 void band_main(j2p_tiled *t, unsigned b)
 {
         uint64_t seen = 0;
@@ -445,6 +462,7 @@ void band_main(j2p_tiled *t, unsigned b)
                                 t->abort.store(true);
                         }
                         t->seq_cv.notify_all();
+                        release_value_waiters(t);
                 }
                 {
                         std::lock_guard<std::mutex> g(t->lock);
@@ -517,21 +535,26 @@ void j2p_tiled_destroy(j2p_tiled *t)
         }
         int prev = -1;
         (void)hipGetDevice(&prev);
-        if(t->signals && t->abort.load()) {
-                // wait counter: a band that failed never counts or writes its flag, and the other bands' streams would sit in
-                // their hipStreamWaitValue64 for ever: let every waiter through (what they then compute is thrown away)
-                for(unsigned i = 0; i < 2 * t->nband; i++) {
-                        __atomic_store_n(t->signals + 8 * (size_t)i, (unsigned long long)1 << 62, __ATOMIC_SEQ_CST);
+        if(t->abort.load()) {
+                release_value_waiters(t);
+                // rccl: a band that failed mid-run leaves the other bands' all-gather / send / recv kernels queued and waiting
+                // for it; synchronising those streams would never return.  ncclCommAbort tears the communicators down with
+                // their kernels (where the library has it; without it the streams are NOT drained below)
+                if(t->rccl && t->rccl->CommAbort) {
+                        for(Band *b : t->bands) {
+                                if(b->comm) { (void)t->rccl->CommAbort(b->comm); b->comm = nullptr; }
+                        }
                 }
         }
+        const bool undrainable = t->abort.load() && t->exchange == kRccl && !(t->rccl && t->rccl->CommAbort);
         for(Band *b : t->bands) {
                 (void)hipSetDevice(b->device);
-                if(b->stream) { (void)hipStreamSynchronize(b->stream); }
+                if(b->stream && !undrainable) { (void)hipStreamSynchronize(b->stream); }
                 if(b->comm && t->rccl) { (void)t->rccl->CommDestroy(b->comm); }
         }
         for(Band *b : t->bands) {
                 (void)hipSetDevice(b->device);
-                if(b->solver) { j2p_solver_destroy(b->solver); }        // synchronises the band's stream first
+                if(b->solver && !undrainable) { j2p_solver_destroy(b->solver); }        // synchronises the band's stream first (undrainable: leaked rather than hung)
                 for(int k = 0; k < 2; k++) {
                         if(b->ev_grad[k]) { (void)hipEventDestroy(b->ev_grad[k]); }
                         if(b->ev_edge[k]) { (void)hipEventDestroy(b->ev_edge[k]); }
@@ -548,8 +571,19 @@ void j2p_tiled_destroy(j2p_tiled *t)
         j2p_pool_trim();        // band arenas are large and rarely reused at the same size: back to the device
 }
 
-int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const unsigned cuts[], unsigned nchannel,
-                     const j2p_plane planes[], float weight, const float pweight[], unsigned iterations)
+}  // extern "C"
+
+namespace {
+
+// how the bands of one tiled solver exchange: -1 = this layer decides (see j2p_tiled_create)
+struct Plan {
+        int exchange = -1;      // Exchange
+        int wait = -1;          // WaitMode (direct only)
+        bool forced = false;    // named by the caller's environment: no fallback to another one
+};
+
+int tiled_create_impl(j2p_tiled **out, unsigned nband, const int devices[], const unsigned cuts[], unsigned nchannel,
+                      const j2p_plane planes[], float weight, const float pweight[], unsigned iterations, Plan plan)
 {
         if(!out || !devices || !planes || !pweight) { return j2p_fail(J2P_EINVAL, "NULL argument"); }
         *out = nullptr;
@@ -592,49 +626,36 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
         int prev = -1;
         (void)hipGetDevice(&prev);
         int rc = J2P_OK;
-        // ---- how the bands exchange (see the head of this file) ----
+        // ---- how the bands exchange (see the head of this file): the plan names it, or the devices decide ----
         {
                 const char *env = getenv("J2P_TILED_NORM");
                 t->norm_by_root = !(env && strcmp(env, "all") == 0);
                 t->root = 0;
                 env = getenv("J2P_TILED_SELF_NEIGHBOURS");
                 t->self_neighbours = nband == 1 && env && atoi(env) != 0;
-                env = getenv("J2P_TILED_WAIT");
-                if(env && *env) {
-                        int w = -1;
-                        for(int k = 0; k < 4; k++) { if(strcmp(env, kWaitName[k]) == 0) { w = k; } }
-                        if(w < 0) { rc = j2p_fail(J2P_EINVAL, "J2P_TILED_WAIT=%s: all, root, collector or counter", env); }
-                        else { t->wait = (WaitMode)w; }
-                }
-                env = getenv("J2P_TILED_EXCHANGE");
-                int want = -1;
-                if(env && *env) {
-                        for(int k = 0; k < 3; k++) { if(strcmp(env, kExchangeName[k]) == 0) { want = k; } }
-                        if(want < 0) { rc = j2p_fail(J2P_EINVAL, "J2P_TILED_EXCHANGE=%s: direct, copy or rccl", env); }
-                }
+                if(plan.wait >= 0) { t->wait = (WaitMode)plan.wait; }
+                const int want = plan.exchange;
                 char why[200] = "";
                 const bool reach = peers_reachable(nband, devices, why, sizeof(why));
                 const unsigned rows_of_tiles = (H + J2P_TILE_ROWS - 1) / J2P_TILE_ROWS;
-                if(rc == J2P_OK) {
-                        if(want == kRccl || (want < 0 && !reach)) {
-                                // one communicator per band: RCCL wants a GPU per rank
-                                Rccl *r = rccl_load();
-                                if(!rccl_usable(r)) {
-                                        rc = j2p_fail(J2P_EDEVICE, "%s%s%s", reach ? "" : why, reach ? "" : ", and RCCL is not available: ", r ? r->why : "out of memory");
-                                } else if(!devices_distinct(nband, devices)) {
-                                        rc = j2p_fail(J2P_EDEVICE, "the rccl exchange needs one GPU per band (a device is listed twice)");
-                                } else {
-                                        t->rccl = r;
-                                        t->exchange = kRccl;
-                                }
-                        } else if(!reach) {
-                                rc = j2p_fail(J2P_EDEVICE, "%s: J2P_TILED_EXCHANGE=%s needs it", why, kExchangeName[want]);
-                        } else if(want == kCopy || rows_of_tiles > kTreeRowsInProject) {
-                                t->exchange = kCopy;        // (also: canvases whose row sums k_project's in-kernel tree cannot hold;
-                                                            // decided again below from the first band's own tile-row count)
+                if(want == kRccl || (want < 0 && !reach)) {
+                        // one communicator per band: RCCL wants a GPU per rank
+                        Rccl *r = rccl_load();
+                        if(!rccl_usable(r)) {
+                                rc = j2p_fail(J2P_EDEVICE, "%s%s%s", reach ? "" : why, reach ? "" : ", and RCCL is not available: ", r ? r->why : "out of memory");
+                        } else if(!devices_distinct(nband, devices)) {
+                                rc = j2p_fail(J2P_EDEVICE, "the rccl exchange needs one GPU per band (a device is listed twice)");
                         } else {
-                                t->exchange = kDirect;
+                                t->rccl = r;
+                                t->exchange = kRccl;
                         }
+                } else if(!reach) {
+                        rc = j2p_fail(J2P_EDEVICE, "%s: the %s exchange needs it", why, kExchangeName[want]);
+                } else if(want == kCopy || rows_of_tiles > kTreeRowsInProject) {
+                        t->exchange = kCopy;        // (also: canvases whose row sums k_project's in-kernel tree cannot hold;
+                                                    // decided again below from the first band's own tile-row count)
+                } else {
+                        t->exchange = kDirect;
                 }
         }
         // a single band is a whole-canvas solver: j2p_tiled_run hands it to j2p_solver_run (no thread, no exchange) —
@@ -704,9 +725,12 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
         }
         // ---- direct, wait counter: the counters and flags, and stream memory operations on every device ----
         // A stream that waits for a value blocks the hardware queue it is mapped to, and a device's streams share a few
-        // hardware queues (four by default): with more than two bands on ONE device a waiting band can sit in front of the
-        // band it waits for — seen as a hang with five bands on one GPU.  (Event waits do not have the problem: the runtime
-        // knows those dependencies.)  So: at most two bands per device, else the event form.
+        // hardware queues (four by default): a waiting band can sit in front of the band it waits for — seen as a hang with
+        // five bands on one GPU.  (Event waits do not have the problem: the runtime knows those dependencies.)  The value form
+        // is for bands on GPUs of their own, and that is the only place the picker (pick_plan) offers it; named through
+        // J2P_TILED_WAIT it is also taken with two bands on a device (the one-GPU rehearsal of the tests, where it has been
+        // running since round 4 — whether two band streams share a hardware queue is the runtime's choice, not a promise),
+        // and with more it silently becomes the event form.
         if(rc == J2P_OK && t->threaded && t->exchange == kDirect && t->wait == kWaitCounter) {
                 for(unsigned a = 0; a < nband; a++) {
                         unsigned same = 0;
@@ -776,6 +800,258 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
         return J2P_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Which exchange a set of GPUs gets is MEASURED AND CHECKED on those GPUs, once per process and device list, before the
+// first job runs on them (the loop being replaced: compute.c:427-453).  None of the exchanges can be assumed right on
+// hardware this code has not met: posted peer writes, waits on values in host memory and RCCL all depend on what the
+// runtime and the fabric of THAT node do.  So: a scratch canvas of the job's width, three 16-row tile rows per band,
+// cut from the job's own first rows, is solved for kVerifyIterations iterations (a) whole, by ONE plain solver on the
+// first GPU — no exchange at all: the truth — and (b) as nband bands through every candidate exchange; a candidate
+// whose canvas differs from (a) in a single bit is DEMOTED (one line on stderr), and the fastest of the others is the
+// plan for this device list from then on.  The scratch canvas is small on purpose: its planes stay in the caches
+// between iterations, which is where a missing release / acquire shows (a full-size band evicts its own stale lines).
+// J2P_TILED_EXCHANGE / J2P_TILED_WAIT name an exchange and skip all of this.  Devices that are listed twice share
+// caches and queues — nothing to find out — and get `direct` with event waits; J2P_TILED_VERIFY=1 runs the procedure
+// there too (tests), J2P_TILED_VERIFY=0 never runs it.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr unsigned kVerifyIterations = 8, kVerifyTimedIterations = 24;
+std::mutex g_plan_lock;
+std::map<std::vector<int>, Plan> g_plans;
+
+struct Candidate {
+        Plan plan;
+        const char *name;
+};
+
+// one scratch run: 0 = matches `truth` (seconds per timed iteration in *secs), 1 = ran and differs, 2 = could not run
+int verify_candidate(const Candidate &cand, unsigned nband, const int devices[], const unsigned cuts[], unsigned nchannel,
+                     const j2p_plane planes[], float weight, const float pweight[], size_t canvas_floats,
+                     const std::vector<std::vector<float>> &truth, double *secs, char *why, size_t why_len)
+{
+        j2p_tiled *t = nullptr;
+        int rc = tiled_create_impl(&t, nband, devices, cuts, nchannel, planes, weight, pweight, kVerifyIterations, cand.plan);
+        int verdict = 2;
+        std::vector<float> got(canvas_floats);
+        if(rc == J2P_OK) { rc = j2p_tiled_run(t, kVerifyIterations, nullptr); }
+        if(rc == J2P_OK) { rc = j2p_tiled_sync(t); }
+        if(rc == J2P_OK) {
+                verdict = 0;
+                for(unsigned c = 0; c < nchannel && rc == J2P_OK; c++) {
+                        rc = j2p_tiled_download(t, c, got.data());
+                        if(rc == J2P_OK && memcmp(got.data(), truth[c].data(), canvas_floats * sizeof(float)) != 0) {
+                                size_t bad = 0, first = canvas_floats;
+                                for(size_t i = 0; i < canvas_floats; i++) {
+                                        if(memcmp(&got[i], &truth[c][i], sizeof(float)) != 0) { bad++; if(first == canvas_floats) { first = i; } }
+                                }
+                                snprintf(why, why_len, "channel %u: %zu of %zu pixels differ from the one-GPU solve after %u iterations (first at pixel %zu)",
+                                         c, bad, canvas_floats, kVerifyIterations, first);
+                                verdict = 1;
+                                break;
+                        }
+                }
+        }
+        if(rc == J2P_OK && verdict == 0) {
+                // timed: the same canvas again, more iterations (the first run paid for first launches and page mappings)
+                rc = j2p_tiled_reset(t);
+                const auto t0 = std::chrono::steady_clock::now();
+                if(rc == J2P_OK) { rc = j2p_tiled_run(t, kVerifyTimedIterations, nullptr); }
+                if(rc == J2P_OK) { rc = j2p_tiled_sync(t); }
+                *secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / kVerifyTimedIterations;
+        }
+        if(rc != J2P_OK) {
+                snprintf(why, why_len, "%s", j2p_last_error());
+                verdict = 2;
+        }
+        if(t) { j2p_tiled_destroy(t); }
+        return verdict;
+}
+
+void device_list_text(unsigned nband, const int devices[], char *out, size_t len)
+{
+        size_t at = 0;
+        out[0] = 0;
+        for(unsigned b = 0; b < nband && at + 8 < len; b++) { at += (size_t)snprintf(out + at, len - at, b ? ",%d" : "%d", devices[b]); }
+}
+
+// J2P_TILED_EXCHANGE / J2P_TILED_WAIT: the caller names the exchange (plan->forced) — no verification, no fallback
+int plan_from_environment(Plan *plan)
+{
+        *plan = Plan();
+        const char *env = getenv("J2P_TILED_WAIT");
+        if(env && *env) {
+                for(int k = 0; k < 4; k++) { if(strcmp(env, kWaitName[k]) == 0) { plan->wait = k; } }
+                if(plan->wait < 0) { return j2p_fail(J2P_EINVAL, "J2P_TILED_WAIT=%s: all, root, collector or counter", env); }
+                plan->forced = true;
+        }
+        env = getenv("J2P_TILED_EXCHANGE");
+        if(env && *env) {
+                for(int k = 0; k < 3; k++) { if(strcmp(env, kExchangeName[k]) == 0) { plan->exchange = k; } }
+                if(plan->exchange < 0) { return j2p_fail(J2P_EINVAL, "J2P_TILED_EXCHANGE=%s: direct, copy or rccl", env); }
+                plan->forced = true;
+        }
+        return J2P_OK;
+}
+
+// the plan for this device list: from the cache, or by the procedure above.  Returns J2P_OK with plan->exchange < 0 when
+// there is nothing to decide (the caller takes the defaults), an error when no exchange works on these GPUs.
+int pick_plan(unsigned nband, const int devices[], unsigned nchannel, const j2p_plane planes[], float weight, const float pweight[], Plan *plan)
+{
+        *plan = Plan();
+        const std::vector<int> key(devices, devices + nband);
+        {
+                std::lock_guard<std::mutex> g(g_plan_lock);
+                auto it = g_plans.find(key);
+                if(it != g_plans.end()) { *plan = it->second; return J2P_OK; }
+        }
+        // ---- the scratch canvas: the job's first rows, three tile rows per band ----
+        unsigned align = J2P_TILE_ROWS, H = 0;
+        for(unsigned c = 0; c < nchannel; c++) {
+                const j2p_plane &p = planes[c];
+                if(p.w_samp == 0 || p.h_samp == 0 || p.w == 0 || p.h == 0) { return J2P_OK; }     // (the create proper reports it)
+                align = align / gcd_u(align, 8 * p.h_samp) * (8 * p.h_samp);
+                if(p.h * p.h_samp > H) { H = p.h * p.h_samp; }
+        }
+        const unsigned per_band = (3 * J2P_TILE_ROWS + align - 1) / align * align;
+        const unsigned rows = per_band * nband;
+        if(H < rows) { return J2P_OK; }                       // a canvas this short is not worth the exercise: defaults
+        j2p_plane scratch[J2P_MAX_CHANNELS];
+        unsigned W = 0;
+        for(unsigned c = 0; c < nchannel; c++) {
+                scratch[c] = planes[c];                        // data / fdata: the first rows ARE the arrays' prefixes
+                const unsigned h = rows / planes[c].h_samp;
+                if(scratch[c].h > h) { scratch[c].h = h; }
+                if(scratch[c].w * scratch[c].w_samp > W) { W = scratch[c].w * scratch[c].w_samp; }
+        }
+        unsigned Hs = 0;
+        for(unsigned c = 0; c < nchannel; c++) { if(scratch[c].h * scratch[c].h_samp > Hs) { Hs = scratch[c].h * scratch[c].h_samp; } }
+        if(Hs != rows) { return J2P_OK; }
+        unsigned cuts[33];
+        for(unsigned b = 0; b <= nband; b++) { cuts[b] = b * per_band; }
+        const size_t canvas_floats = (size_t)W * rows;
+        char devtext[160];
+        device_list_text(nband, devices, devtext, sizeof(devtext));
+        // ---- (a) the truth: one plain solver, no exchange ----
+        std::vector<std::vector<float>> truth(nchannel, std::vector<float>(canvas_floats));
+        {
+                j2p_solver *s = nullptr;
+                int rc = j2p_solver_create(&s, devices[0], nullptr, nchannel, scratch, weight, pweight, kVerifyIterations, j2p_band{0, 0}, 0);
+                if(rc == J2P_OK) { rc = j2p_solver_run(s, kVerifyIterations, nullptr); }
+                for(unsigned c = 0; c < nchannel && rc == J2P_OK; c++) { rc = j2p_solver_download(s, c, truth[c].data()); }
+                if(s) { j2p_solver_destroy(s); }
+                if(rc != J2P_OK) { return rc; }
+        }
+        // ---- (b) the candidates ----
+        char why[200] = "";
+        const bool reach = peers_reachable(nband, devices, why, sizeof(why));
+        const bool own_gpus = devices_distinct(nband, devices);
+        unsigned most = 0;
+        for(unsigned a = 0; a < nband; a++) {
+                unsigned same = 0;
+                for(unsigned b = 0; b < nband; b++) { same += devices[a] == devices[b]; }
+                if(same > most) { most = same; }
+        }
+        std::vector<Candidate> cands;
+        auto add = [&](int ex, int wait, const char *name) {
+                Candidate c;
+                c.plan.exchange = ex;
+                c.plan.wait = wait;
+                c.name = name;
+                cands.push_back(c);
+        };
+        if(reach) {
+                bool value_waits = most <= 2;                  // (two per device only ever under J2P_TILED_VERIFY=1: the rehearsal)
+                for(unsigned b = 0; b < nband && value_waits; b++) {
+                        int can = 0;
+                        value_waits = hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, devices[b]) == hipSuccess && can;
+                }
+                (void)hipGetLastError();
+                if(value_waits) { add(kDirect, kWaitCounter, "direct, wait counter"); }
+                if(nband > 2) { add(kDirect, kWaitCollector, "direct, wait collector"); }
+                add(kDirect, kWaitAll, "direct");
+                add(kCopy, -1, "copy");
+        }
+        if(own_gpus && (!reach || rccl_usable(rccl_load()))) { add(kRccl, -1, "rccl"); }
+        int best = -1;
+        double best_secs = 0.;
+        char line[512];
+        size_t at = 0;
+        line[0] = 0;
+        for(size_t k = 0; k < cands.size(); k++) {
+                // (RCCL costs seconds to initialise: only tried when nothing that writes peers' memory has been verified)
+                if(cands[k].plan.exchange == kRccl && best >= 0) { continue; }
+                double secs = 0.;
+                char cwhy[320] = "";
+                const int v = verify_candidate(cands[k], nband, devices, cuts, nchannel, scratch, weight, pweight, canvas_floats, truth, &secs, cwhy, sizeof(cwhy));
+                if(v == 1) {
+                        fprintf(stderr, "jpeg2png_amd: row tiling over GPUs %s: exchange '%s' DEMOTED, it does not reproduce the one-GPU solve (%s)\n", devtext, cands[k].name, cwhy);
+                } else if(v == 2) {
+                        fprintf(stderr, "jpeg2png_amd: row tiling over GPUs %s: exchange '%s' not available (%s)\n", devtext, cands[k].name, cwhy);
+                } else {
+                        if(at + 64 < sizeof(line)) { at += (size_t)snprintf(line + at, sizeof(line) - at, "%s'%s' %.1f us", at ? ", " : "", cands[k].name, secs * 1e6); }
+                        if(best < 0 || secs < best_secs) { best = (int)k; best_secs = secs; }
+                }
+        }
+        if(best < 0) {
+                return j2p_fail(J2P_EDEVICE, "row tiling over GPUs %s: no exchange reproduces the one-GPU solve on them (see stderr)%s%s", devtext,
+                                reach ? "" : "; ", reach ? "" : why);
+        }
+        *plan = cands[(size_t)best].plan;
+        if(getenv("J2P_COMPUTE_TIMING")) {
+                fprintf(stderr, "jpeg2png_amd: row tiling over GPUs %s: verified per scratch iteration %s -> '%s'\n", devtext, line, cands[(size_t)best].name);
+        }
+        {
+                std::lock_guard<std::mutex> g(g_plan_lock);
+                g_plans[key] = *plan;
+        }
+        return J2P_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// (internal, for compute_host.c and j2p_batch.hip) nonzero when the environment names the exchange: a job that cannot be
+// row-tiled THAT way fails instead of quietly running on one GPU
+int j2p_tiled_exchange_forced(void)
+{
+        Plan plan;
+        return plan_from_environment(&plan) != J2P_OK || plan.forced;
+}
+
+int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const unsigned cuts[], unsigned nchannel,
+                     const j2p_plane planes[], float weight, const float pweight[], unsigned iterations)
+{
+        if(!out || !devices || !planes || !pweight) { return j2p_fail(J2P_EINVAL, "NULL argument"); }
+        *out = nullptr;
+        if(nband == 0 || nband > 32) { return j2p_fail(J2P_EINVAL, "1..32 bands, got %u", nband); }
+        if(nchannel == 0 || nchannel > J2P_MAX_CHANNELS) { return j2p_fail(J2P_EINVAL, "nchannel must be 1..3 (compute.c:118)"); }
+        Plan plan;
+        const char *env = nullptr;
+        {
+                const int rc = plan_from_environment(&plan);
+                if(rc != J2P_OK) { return rc; }
+        }
+        if(!plan.forced && nband > 1) {
+                env = getenv("J2P_TILED_VERIFY");
+                const int verify = env && *env ? atoi(env) : -1;          // -1: where it can matter
+                if(verify > 0 || (verify < 0 && devices_distinct(nband, devices))) {
+                        int ndev = 0;
+                        if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+                                return j2p_fail(J2P_EDEVICE, "no HIP device available: the jpeg2png_amd solver has no CPU fallback");
+                        }
+                        for(unsigned b = 0; b < nband; b++) {
+                                if(devices[b] < 0 || devices[b] >= ndev) { return j2p_fail(J2P_EINVAL, "device %d out of range (0..%d)", devices[b], ndev - 1); }
+                        }
+                        int prev = -1;
+                        (void)hipGetDevice(&prev);
+                        const int rc = pick_plan(nband, devices, nchannel, planes, weight, pweight, &plan);
+                        if(prev >= 0) { (void)hipSetDevice(prev); }
+                        if(rc != J2P_OK) { return rc; }
+                }
+        }
+        return tiled_create_impl(out, nband, devices, cuts, nchannel, planes, weight, pweight, iterations, plan);
+}
+
 int j2p_tiled_exchange(const j2p_tiled *t, const char **name)
 {
         if(!t || !name) { return j2p_fail(J2P_EINVAL, "NULL argument"); }
@@ -807,6 +1083,8 @@ int j2p_tiled_band(const j2p_tiled *t, unsigned band, int *device, unsigned *row
 int j2p_tiled_sync(j2p_tiled *t)
 {
         if(!t) { return j2p_fail(J2P_EINVAL, "tiled solver is NULL"); }
+        // (after a band's failure the other bands' streams may hold collectives that can never complete: do not wait on them)
+        if(t->abort.load()) { return j2p_fail(J2P_ESTATE, "a band failed earlier; the tiled solver is unusable"); }
         for(Band *b : t->bands) { BAND_TRY(j2p_solver_sync(b->solver)); }
         return J2P_OK;
 }
@@ -837,6 +1115,7 @@ int j2p_tiled_run(j2p_tiled *t, unsigned n, j2p_log_row *rows)
         if(!t) { return j2p_fail(J2P_EINVAL, "tiled solver is NULL"); }
         if(n == 0) { return J2P_OK; }
         if(t->abort.load()) { return j2p_fail(J2P_ESTATE, "a band failed earlier; the tiled solver is unusable"); }
+        if(t->threaded && j2p_injected_failure()) { return j2p_fail(J2P_EDEVICE, "injected failure (j2p_debug_fail_run_after)"); }
         if(!t->threaded) {
                 // one band = a whole-canvas solver: its own loop (its norm reduction is not the band solvers')
                 BAND_TRY(j2p_solver_run(t->bands[0]->solver, n, rows));

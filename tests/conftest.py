@@ -113,6 +113,15 @@ def oracle():
     return bindings
 
 
+def band_devices(n):
+    """device ids for an n-band TiledSolver / an n-device Batch: the GPUs that are THERE, cycled to length n — on this
+    pool's one-GPU boxes [0] * n (all bands share the GPU: everything of the multi-GPU path but the xGMI hop), on an 8-GPU
+    node every exchange crosses real links and is compared with the reference / the whole-canvas solve just the same."""
+    import jpeg2png_amd as j
+    count = max(1, j.device_count())
+    return [i % count for i in range(n)]
+
+
 def psnr(a, b):
     """per-plane PSNR, peak 255."""
     mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))

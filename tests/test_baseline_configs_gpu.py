@@ -18,7 +18,7 @@ import warnings
 import numpy as np
 import pytest
 
-from conftest import bit_equal, parity_note, psnr
+from conftest import band_devices, bit_equal, parity_note, psnr
 
 pytestmark = pytest.mark.gpu
 
@@ -147,7 +147,7 @@ def test_config3_16384_wide_bands_match_whole_and_reference(lib, oracle):
     with j.Solver(planes, WEIGHT, [PWEIGHT], its) as s:
         s.run(its)
         whole = s.download(0)
-    with j.TiledSolver(planes, WEIGHT, [PWEIGHT], its, devices=[0] * 8) as t:
+    with j.TiledSolver(planes, WEIGHT, [PWEIGHT], its, devices=band_devices(8)) as t:
         assert [b[1:] for b in t.bands()] == [(r, r + 256) for r in range(0, H, 256)]
         t.run(its)
         banded = t.download(0)
@@ -187,7 +187,7 @@ def test_config3_full_size_i100_vs_reference_whole_and_8_bands(lib, oracle, conf
         whole = s.download(0)
     check_planes("configs[3] 16384x16384 -i 100, whole canvas", [whole], want, strict=not ALLOW_NORM_FLIP)
     j.load_library().j2p_pool_trim()
-    with j.TiledSolver([plane], WEIGHT, [PWEIGHT], its, devices=[0] * 8) as t:
+    with j.TiledSolver([plane], WEIGHT, [PWEIGHT], its, devices=band_devices(8)) as t:
         assert [b[1:] for b in t.bands()] == [(r, r + 2048) for r in range(0, 16384, 2048)]
         banded_rows = t.run(its, log=True)
         banded = t.download(0)
@@ -215,7 +215,7 @@ def test_config4_batch_of_256_images_vs_reference(lib, oracle):
     first = {}                      # content index -> planes of its first occurrence
     kept = {}                       # image index -> planes, for the reference comparison
     t0 = time.perf_counter()
-    with j.Batch(devices=[0], slots_per_device=8) as b:
+    with j.Batch(devices=band_devices(j.device_count()), slots_per_device=8) as b:      # every GPU that is there
         tickets = {}
 
         def collect(i):

@@ -6,7 +6,7 @@ import copy
 import numpy as np
 import pytest
 
-from conftest import bit_equal, make_case
+from conftest import band_devices, bit_equal, make_case
 
 pytestmark = pytest.mark.gpu
 
@@ -107,7 +107,7 @@ def test_tiled_job_equals_single_solver_job(lib, separate, monkeypatch):
     monkeypatch.setenv("J2P_TILE_MIN_BAND_PIXELS", "0")
     planes = make_case(152, 296, "420", 10, seed=83)
     weights, its = ([0.3, 0.1, 0.0], [12, 7, 5]) if separate else (0.3, 12)
-    with j.Batch(devices=[0, 0, 0], slots_per_device=1) as b:
+    with j.Batch(devices=band_devices(3), slots_per_device=1) as b:
         a_f = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate))
         a_rgb = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate, width=150, height=290, bits=8))
         t_f = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate, tile=True))
@@ -130,7 +130,7 @@ def test_tile_gate_and_device_shares(lib, monkeypatch):
     batch's device list and a bad output description are rejected before anything runs"""
     import jpeg2png_amd as j
     planes = make_case(152, 296, "420", 10, seed=84)
-    with j.Batch(devices=[0, 0, 0, 0], slots_per_device=1) as b:
+    with j.Batch(devices=band_devices(4), slots_per_device=1) as b:
         plain = b.wait(b.submit(planes, 0.3, [0.001] * 3, 6))
         gated = b.wait(b.submit(planes, 0.3, [0.001] * 3, 6, tile=True, tile_devices=(2, 2)))       # too small: untiled
         monkeypatch.setenv("J2P_TILE_MIN_BAND_PIXELS", "0")

@@ -30,3 +30,45 @@ def test_without_a_truth_the_fastest_leg_wins():
     t = legs(c=(1.0, "x"), c_copy=(0.9, "y"))
     assert bench.pick_leg(t, None) == "c_copy"
     assert t["c"]["verified"] is None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# tests/golden/bench_digests.json: what bench.py's `parity` object compares the timed solver's plane with
+# ---------------------------------------------------------------------------------------------------------------
+def _digests():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "bench_digests.json")) as f:
+        return json.load(f)
+
+
+def test_bench_digest_file_describes_the_workloads_bench_py_times():
+    import bench
+    d = _digests()
+    for name, (W, H, its, seed) in {"configs[2]": (4096, 4096, 500, 1234 + 3), "configs[3] N=1": (16384, 2048, 100, 1234 + 4)}.items():
+        e = d[name]
+        assert (e["W"], e["H"], e["iterations"], e["seed"], e["quality"]) == (W, H, its, seed, 10)
+        assert (e["weight"], e["pweight"]) == (bench.WEIGHT, bench.PWEIGHT)
+        assert len(e["digest"]) == 32
+        assert bench.reference_digest(W, H, its, seed) == (name, e["digest"])
+    assert bench.reference_digest(4096, 4096, 499, 1234 + 3) == (None, None)
+    ok = bench.parity_object(d["configs[2]"]["digest"], 4096, 4096, 500, 1234 + 3)
+    assert ok["bit_identical"] is True and ok["entry"] == "configs[2]"
+    assert bench.parity_object("0" * 32, 4096, 4096, 500, 1234 + 3)["bit_identical"] is False
+    assert bench.parity_object("0" * 32, 1024, 1024, 5, 1)["bit_identical"] is None
+
+
+def test_bench_digest_recipe_reproduces_from_the_compiled_reference():
+    """the generator's small entry — rows 0..256 of the configs[2] image, 10 iterations — recomputed here with oracle/_ref:
+    same synthesis, same decode, same reference, same hash function as the entries bench.py relies on"""
+    import hashlib
+    import numpy as np
+    import pytest
+    from jpeg2png_amd import synth
+    from oracle import bindings as ob
+    if not ob.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    e = _digests()["recipe"]
+    plane = synth.make_planes(e["W"], e["image_H"], "444", e["quality"], seed=e["seed"], y_only=True, rows=tuple(e["rows_of_the_image"]))[0]
+    plane.fdata = ob.decode_plane(plane)
+    outs, _, _ = ob.ref_compute([plane], e["weight"], [e["pweight"]], e["iterations"])
+    assert hashlib.blake2b(np.ascontiguousarray(outs[0]), digest_size=16).hexdigest() == e["digest"]

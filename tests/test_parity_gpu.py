@@ -14,7 +14,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import bit_equal, make_case, psnr
+from conftest import band_devices, bit_equal, make_case, psnr
 
 pytestmark = pytest.mark.gpu
 
@@ -615,7 +615,7 @@ def test_every_schedule_switch_leaves_the_bits_alone(lib, oracle, shape, monkeyp
                 assert bit_equal(got[c].fdata, want[c]), f"px {px} rpw {rpw} channel {c}"
             assert np.isfinite(rows).all()
             if h >= 128:
-                with j.TiledSolver(planes, 0.3, [0.001] * n, its, devices=[0, 0]) as t:
+                with j.TiledSolver(planes, 0.3, [0.001] * n, its, devices=band_devices(2)) as t:
                     t.run(its)
                     for c in range(n):
                         assert bit_equal(t.download(c), want[c]), f"px {px} rpw {rpw}, two bands: channel {c}"
@@ -629,7 +629,7 @@ def test_every_schedule_switch_leaves_the_bits_alone(lib, oracle, shape, monkeyp
         for c in range(n):
             assert bit_equal(got[c].fdata, want[c]), f"rpw {rpw} channel {c}"
         if h >= 128:
-            with j.TiledSolver(planes, 0.3, [0.001] * n, its, devices=[0, 0]) as t:
+            with j.TiledSolver(planes, 0.3, [0.001] * n, its, devices=band_devices(2)) as t:
                 t.run(its)
                 for c in range(n):
                     assert bit_equal(t.download(c), want[c]), f"rpw {rpw} (ignored by band solvers), two bands: channel {c}"

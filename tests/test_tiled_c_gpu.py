@@ -7,7 +7,7 @@ import copy
 import numpy as np
 import pytest
 
-from conftest import bit_equal, make_case
+from conftest import band_devices, bit_equal, make_case
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +27,7 @@ def test_equal_bands_match_whole_canvas(lib, sub, y_only, nband):
     pws = [0.001] * len(planes)
     its = 9
     want, want_rows = whole_canvas(planes, 0.3, pws, its, log=True)
-    with j.TiledSolver(planes, 0.3, pws, its, devices=[0] * nband) as t:
+    with j.TiledSolver(planes, 0.3, pws, its, devices=band_devices(nband)) as t:
         rows = t.run(its, log=True)
         for c in range(len(planes)):
             assert bit_equal(t.download(c), want[c]), f"channel {c}"
@@ -53,13 +53,13 @@ def test_random_cuts_and_chunked_runs(lib):
         cuts = [0] + sorted((rng.choice(np.arange(1, units), nb - 1, replace=False) * align).tolist()) + [H]
         its = 11
         want, want_rows = whole_canvas(planes, weight, pws, its, log=True)
-        with j.TiledSolver(planes, weight, pws, its, devices=[0] * nb, cuts=cuts) as t:
+        with j.TiledSolver(planes, weight, pws, its, devices=band_devices(nb), cuts=cuts) as t:
             rows = np.concatenate([t.run(4, log=True), t.run(7, log=True)])
             got = [t.download(c) for c in range(len(planes))]
         for c in range(len(planes)):
             assert bit_equal(got[c], want[c]), f"trial {trial} cuts {cuts} channel {c}"
         np.testing.assert_allclose(rows, want_rows, rtol=1e-9, atol=1e-12)
-        with j.TiledSolver(planes, weight, pws, its, devices=[0] * nb, cuts=cuts) as t:
+        with j.TiledSolver(planes, weight, pws, its, devices=band_devices(nb), cuts=cuts) as t:
             t.run(5)
             t.run(6)
             for c in range(len(planes)):
@@ -70,9 +70,9 @@ def test_bad_cuts_are_rejected(lib):
     import jpeg2png_amd as j
     planes = make_case(64, 96, "420", 10, seed=3)
     with pytest.raises(j.J2PError, match="aligned|cuts"):
-        j.TiledSolver(planes, 0.3, [0.001] * 3, 4, devices=[0, 0], cuts=[0, 40, 96])
+        j.TiledSolver(planes, 0.3, [0.001] * 3, 4, devices=band_devices(2), cuts=[0, 40, 96])
     with pytest.raises(j.J2PError, match="bands"):
-        j.TiledSolver(planes, 0.3, [0.001] * 3, 4, devices=[0] * 20)
+        j.TiledSolver(planes, 0.3, [0.001] * 3, 4, devices=band_devices(20))
 
 
 def test_norm_fold_on_and_off_agree(lib):
@@ -139,7 +139,7 @@ def test_unlogged_then_logged_runs_report_nan_for_the_unknown_distance(lib):
     planes = make_case(200, 330, "420", 10, seed=77)
     pws = [0.001] * 3
     _, want_rows = whole_canvas(planes, 0.3, pws, 9, log=True)
-    with j.TiledSolver(planes, 0.3, pws, 9, devices=[0] * 3) as t:
+    with j.TiledSolver(planes, 0.3, pws, 9, devices=band_devices(3)) as t:
         t.run(4)
         rows = t.run(5, log=True)
     assert np.isnan(rows[0, 0]) and np.isnan(rows[0, 1])
@@ -159,7 +159,7 @@ def test_every_schedule_of_the_tiling_gives_the_same_bits(lib, exchange, norm, m
     want, want_rows = whole_canvas(planes, 0.3, pws, 10, log=True)
     monkeypatch.setenv("J2P_TILED_EXCHANGE", exchange)
     monkeypatch.setenv("J2P_TILED_NORM", norm)
-    with j.TiledSolver(planes, 0.3, pws, 10, devices=[0] * 5) as t:
+    with j.TiledSolver(planes, 0.3, pws, 10, devices=band_devices(5)) as t:
         assert t.exchange() == exchange
         t.run(10)
         for c in range(3):
@@ -182,7 +182,7 @@ def test_direct_exchange_on_every_projection_path(lib, sub, y_only, W, H, monkey
     pws = [0.001] * len(planes)
     want, _ = whole_canvas(planes, 0.3, pws, 8)
     monkeypatch.setenv("J2P_TILED_EXCHANGE", "direct")
-    with j.TiledSolver(planes, 0.3, pws, 8, devices=[0] * 3) as t:
+    with j.TiledSolver(planes, 0.3, pws, 8, devices=band_devices(3)) as t:
         assert t.exchange() == "direct"
         t.run(3)
         t.run(5)
@@ -205,8 +205,10 @@ def test_direct_exchange_wait_modes(lib, wait, nband, monkeypatch):
     want, want_rows = whole_canvas(planes, 0.3, pws, 9, log=True)
     monkeypatch.setenv("J2P_TILED_EXCHANGE", "direct")
     monkeypatch.setenv("J2P_TILED_WAIT", wait)
-    with j.TiledSolver(planes, 0.3, pws, 9, devices=[0] * nband) as t:
-        assert t.exchange() == ("direct" if wait == "all" or (wait == "counter" and nband > 2) else f"direct, wait {wait}")
+    devices = band_devices(nband)
+    crowded = max(devices.count(d) for d in devices) > 2       # the value form needs (nearly) a GPU per band
+    with j.TiledSolver(planes, 0.3, pws, 9, devices=devices) as t:
+        assert t.exchange() == ("direct" if wait == "all" or (wait == "counter" and crowded) else f"direct, wait {wait}")
         t.run(9)
         for c in range(3):
             assert bit_equal(t.download(c), want[c]), f"{wait}: channel {c}"
@@ -223,7 +225,7 @@ def test_tall_narrow_canvas_falls_back_to_the_copy_exchange(lib):
     import jpeg2png_amd as j
     planes = make_case(64, 4128, "444", 10, seed=81, y_only=True)
     want, _ = whole_canvas(planes, 0.3, [0.001], 5)
-    with j.TiledSolver(planes, 0.3, [0.001], 5, devices=[0] * 3) as t:
+    with j.TiledSolver(planes, 0.3, [0.001], 5, devices=band_devices(3)) as t:
         assert t.exchange() == "copy"
         t.run(5)
         assert bit_equal(t.download(0), want[0])
