@@ -812,10 +812,125 @@ __device__ __forceinline__ void source_prepare(const V (&gx)[NCH], const V (&gy)
         }
 }
 
+// source_finish on the screened path without log sums (the hot one), LEVEL BY LEVEL.  The arithmetic is that of
+// norm_and_reciprocal<true, false> + div_exact_recip, operation for operation — sqrt_rsq and recip_exact for the two norms,
+// then one residual correction per quotient — but written breadth-first: the two norm chains side by side, the 7 quotient
+// chains of a channel side by side, with a scheduling barrier for vector instructions between the levels.  Why: on gfx950 a
+// packed f32 operation needs a wait state before an instruction that reads its result, and left to itself the compiler
+// emits each chain depth-first — 30 of the hot march's 250 instructions per row trip were `s_nop 0` between a v_pk_fma and
+// the v_pk_fma that consumes it (tools/isa_count.py), each one an issue slot of the wavefront.  Same bits, fewer slots.
+#ifndef J2P_LEVELS
+#define J2P_LEVELS 1
+#endif
+#define J2P_LEVEL_END() __builtin_amdgcn_sched_barrier(0x0094)      /* SALU, VMEM and DS may cross; vector ALU work may not */
+template <int NCH, bool TGV, class V>
+__device__ __forceinline__ void source_finish_levels(const V (&gx)[NCH], const V (&gy)[NCH], const SourcePrep<NCH, TGV, V> &p, float a_tv,
+                                                     float a_tgv, SourceTerms<NCH, TGV, V> &s)
+{
+        constexpr int K = TGV ? 2 : 1;                         // norms: TV, TGV2
+        const V one = splat<V>(1.f), half = splat<V>(0.5f), tiny = splat<V>(0x1p-120f);
+        V x[K], r[K], sq[K], h[K], e[K], n[K], rc[K];
+        x[0] = p.n1r + tiny;
+        if(TGV) { x[K - 1] = p.n2r + tiny; }
+        // ---- sqrt_rsq ----
+#pragma unroll
+        for(int k = 0; k < K; k++) { r[k] = hw_rsq(x[k]); }
+#pragma unroll
+        for(int k = 0; k < K; k++) { sq[k] = x[k] * r[k]; }
+#pragma unroll
+        for(int k = 0; k < K; k++) { h[k] = r[k] * 0.5f; }
+        J2P_LEVEL_END();
+#pragma unroll
+        for(int k = 0; k < K; k++) { e[k] = pk_fma(-h[k], sq[k], half); }
+        // (numerators have nothing to do with the norms: they fill the slots between the levels of the two chains)
+        V num[NCH][TGV ? 7 : 3];
+        const V a1 = splat<V>(a_tv), a2 = splat<V>(a_tgv);
+#pragma unroll
+        for(int c = 0; c < NCH; c++) {
+                num[c][0] = a1 * gx[c];
+                num[c][1] = a1 * gy[c];
+                num[c][2] = a1 * -(gx[c] + gy[c]);
+        }
+        J2P_LEVEL_END();
+#pragma unroll
+        for(int k = 0; k < K; k++) { h[k] = pk_fma(h[k], e[k], h[k]); }
+#pragma unroll
+        for(int k = 0; k < K; k++) { sq[k] = pk_fma(sq[k], e[k], sq[k]); }
+        if(TGV) {
+#pragma unroll
+                for(int c = 0; c < NCH; c++) {
+                        V t4[4];
+                        tgv_numerators<true>(p.xx[c], p.sy[c], p.yy[c], t4);
+#pragma unroll
+                        for(int i = 0; i < 4; i++) { num[c][(TGV ? 3 : 0) + i] = t4[i]; }
+                }
+        }
+        J2P_LEVEL_END();
+#pragma unroll
+        for(int k = 0; k < K; k++) { e[k] = pk_fma(-sq[k], sq[k], x[k]); }
+        J2P_LEVEL_END();
+#pragma unroll
+        for(int k = 0; k < K; k++) { n[k] = pk_fma(e[k], h[k], sq[k]); }          // the norms
+        J2P_LEVEL_END();
+        // ---- recip_exact(n, seed = r) ----
+#pragma unroll
+        for(int k = 0; k < K; k++) { e[k] = pk_fma(-n[k], r[k], one); }
+        J2P_LEVEL_END();
+#pragma unroll
+        for(int k = 0; k < K; k++) { h[k] = pk_fma(e[k], r[k], r[k]); }
+        J2P_LEVEL_END();
+#pragma unroll
+        for(int k = 0; k < K; k++) { e[k] = pk_fma(-n[k], h[k], one); }
+        J2P_LEVEL_END();
+#pragma unroll
+        for(int k = 0; k < K; k++) { rc[k] = pk_fma(e[k], h[k], h[k]); }
+        J2P_LEVEL_END();
+        // ---- the quotients: q0 = RN(x r), q = RN(q0 + (x - d q0) r)  (div_exact_recip) ----
+        constexpr int Q = TGV ? 7 : 3;
+        V q0[NCH][Q], er[NCH][Q];
+#pragma unroll
+        for(int c = 0; c < NCH; c++) {
+#pragma unroll
+                for(int i = 0; i < Q; i++) { q0[c][i] = num[c][i] * rc[i < 3 ? 0 : K - 1]; }
+        }
+        J2P_LEVEL_END();
+#pragma unroll
+        for(int c = 0; c < NCH; c++) {
+#pragma unroll
+                for(int i = 0; i < Q; i++) { er[c][i] = pk_fma(-n[i < 3 ? 0 : K - 1], q0[c][i], num[c][i]); }
+        }
+        J2P_LEVEL_END();
+#pragma unroll
+        for(int c = 0; c < NCH; c++) {
+#pragma unroll
+                for(int i = 0; i < Q; i++) { q0[c][i] = pk_fma(er[c][i], rc[i < 3 ? 0 : K - 1], q0[c][i]); }
+        }
+        J2P_LEVEL_END();
+#pragma unroll
+        for(int c = 0; c < NCH; c++) {
+                s.tvx[c] = q0[c][0];
+                s.tvy[c] = q0[c][1];
+                s.tvo[c] = q0[c][2];
+                if(TGV) {
+                        s.A[c] = a2 * q0[c][Q - 4];                                     // to (x-1,y), (x+1,y)
+                        s.B[c] = a2 * q0[c][Q - 3];                                     // to (x,y-1), (x,y+1)
+                        s.C[c] = a2 * -q0[c][Q - 2];                                    // to (x+1,y-1), (x-1,y+1)
+                        s.O[c] = own_term<true>(a2, q0[c][Q - 1]);                      // own
+                }
+        }
+}
+
 template <int NCH, bool TGV, bool LOG, bool FAST, class V>
 __device__ __forceinline__ void source_finish(const V (&gx)[NCH], const V (&gy)[NCH], const SourcePrep<NCH, TGV, V> &p, float a_tv,
                                               float a_tgv, bool log_row, double &tv, double &tv2, SourceTerms<NCH, TGV, V> &s)
 {
+#if J2P_LEVELS && !defined(J2P_EXP_NOARITH)
+        if constexpr(FAST && !LOG && NCH == 1) {
+                (void)log_row; (void)tv; (void)tv2;
+                source_finish_levels<NCH, TGV, V>(gx, gy, p, a_tv, a_tgv, s);
+                return;
+        }
+#endif
         // ---- TV (compute.c:90-104) ----
         V n1, d1, r1;
         norm_and_reciprocal<FAST, LOG>(p.n1r, n1, d1, r1);

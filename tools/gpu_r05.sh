@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round 5's GPU calls, one section per call (bash tools/gpu_r05.sh <section>); everything lands under gpurun_out/r05_*.
+set -u
+S=${1:-a}
+O=gpurun_out
+mkdir -p $O
+export TMPDIR=/tmp
+BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-host-to-host"
+line() { grep '^{' | tail -1; }
+brief() { python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']; k=r['per_kernel']
+print(json.dumps({'variant': '$1', 'Mpx_it_per_s': d['value'] or d.get('unverified_value'), 'us_per_iteration': round(r['iteration_ms']*1e3,2), 'k_gradient_us': round(k['k_gradient']['avg_launch_ms']*1e3,1), 'k_project_us': round(k['k_project']['avg_launch_ms']*1e3,1), 'bit_identical_to_reference': (d.get('parity') or {}).get('bit_identical')}))"; }
+case $S in
+a)
+  # new tests first, then the suite without the two long reference runs; then same-box A/B: levels on / off, decomposition
+  ( timeout 900 python -m pytest tests/test_fineprint_gpu.py tests/test_tiled_verify_gpu.py -q -x --timeout 900 -s ) > $O/r05_a_new_tests.log 2>&1; echo "new tests rc=$?"; tail -15 $O/r05_a_new_tests.log
+  ( timeout 1200 python -m pytest tests -m gpu -q --timeout 900 -k "not full_size_i100 and not config2_4096 and not fineprint and not tiled_verify" ) > $O/r05_a_suite.log 2>&1; echo "suite rc=$?"; tail -25 $O/r05_a_suite.log
+  for rep in 1 2; do
+    for v in base levels0; do
+      if [ $v = base ]; then $BENCH 2>/dev/null | line | brief $v; else J2P_LIBRARY=ab/libj2p_$v.so $BENCH 2>/dev/null | line | brief $v; fi
+    done
+  done | tee $O/r05_ab_levels.jsonl
+  for v in base noarith notraffic nohalo shortdiv; do
+    if [ $v = base ]; then $BENCH 2>/dev/null | line | brief $v; else J2P_LIBRARY=ab/libj2p_$v.so $BENCH 2>/dev/null | line | brief $v; fi
+  done | tee $O/r05_decomposition.jsonl
+  ;;
+esac
