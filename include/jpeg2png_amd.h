@@ -115,6 +115,8 @@ void j2p_pool_trim(void);
                                      create and reset (environment J2P_NT_SCOPE=solver: this solver's own only) */
 #define J2P_OPT_MIXED_PROJECT 6   /* 1 (default): canvases up to 1 Mpixel project all channels in ONE launch whatever their
                                      sampling; 0: one launch per sampling class, as large canvases do */
+#define J2P_OPT_FUSE 7             /* 1: one launch per iteration — projection(k) and gradient(k + 1) in one grid, ordered by per-block-row
+                                     counters (one full-resolution channel covering a whole canvas; default up to 8 Mpixel); 0: two launches */
 int j2p_solver_debug_option(j2p_solver *s, int option, int value);
 
 /* The checked build (the analogue of the reference's DEBUG=1, whose pixel indexer p() asserts every access,
@@ -134,6 +136,10 @@ int j2p_solver_trace(j2p_solver *s, int on, unsigned long long *host_out, unsign
 /* canvas geometry (compute.c:410-416) and band bookkeeping */
 int j2p_solver_canvas(const j2p_solver *s, unsigned *W, unsigned *H);
 int j2p_solver_band(const j2p_solver *s, unsigned *row_begin, unsigned *row_end);
+
+/* kernel launches per iteration of an unlogged j2p_solver_run(): 1 = projection(k) and gradient(k + 1) share a launch
+ * (J2P_OPT_FUSE), 2 = gradient and projection with ||g|| reduced inside them, 3 = with a reduction launch in between */
+int j2p_solver_launches_per_iteration(const j2p_solver *s, unsigned *n);
 
 /* back to iteration 0 from the inputs that are already resident in HBM */
 int j2p_solver_reset(j2p_solver *s);

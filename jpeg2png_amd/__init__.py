@@ -82,10 +82,10 @@ C_ABI_SYMBOLS = [
     "j2p_tiled_download", "j2p_tiled_host_cpu_seconds", "j2p_solver_norm_ptr", "j2p_solver_norm_external",
     "j2p_solver_global_rowsums", "j2p_solver_link_bands", "j2p_tiled_exchange",
     "j2p_batch_create", "j2p_batch_destroy", "j2p_batch_submit", "j2p_batch_wait",
-    "compute", "j2p_compute", "j2p_compute_tiled", "j2p_compute_timing", "j2p_debug_fail_run_after",
+    "compute", "j2p_compute", "j2p_compute_tiled", "j2p_compute_timing", "j2p_debug_fail_run_after", "j2p_solver_launches_per_iteration",
     "j2p_debug_build", "j2p_solver_debug_violations", "j2p_solver_trace", "j2p_division_exhaustive",
 ]
-J2P_OPT_NORM_FOLD, J2P_OPT_JOINT_INWAVE, J2P_OPT_NORM_IN_PROJECT, J2P_OPT_NT_GRADIENT, J2P_OPT_MIXED_PROJECT = 1, 2, 4, 5, 6
+J2P_OPT_NORM_FOLD, J2P_OPT_JOINT_INWAVE, J2P_OPT_NORM_IN_PROJECT, J2P_OPT_NT_GRADIENT, J2P_OPT_MIXED_PROJECT, J2P_OPT_FUSE = 1, 2, 4, 5, 6, 7
 
 _lib = None
 
@@ -362,6 +362,12 @@ class Solver:
         p = ctypes.c_void_p()
         _check(self._lib.j2p_solver_plane_ptr(self._h, c, ctypes.byref(p)))
         return p.value
+
+    def launches_per_iteration(self):
+        """kernel launches per iteration of an unlogged run (1: the single-launch iteration, k_iterate)"""
+        n = ctypes.c_uint()
+        _check(self._lib.j2p_solver_launches_per_iteration(self._h, ctypes.byref(n)))
+        return n.value
 
     def debug_option(self, option, value):
         """schedule switches (J2P_OPT_*): speed only, never results"""

@@ -327,6 +327,28 @@ struct ProjArgs {
         float *halo_down[kMaxCh];    // row 0 of the upper halo rows of the band below
 };
 
+// The single-launch iteration (k_iterate): projection(k) and gradient(k + 1) in ONE grid.  ||g|| is the only device-wide
+// dependency of the solver (compute.c:209-211): gradient(k + 1) of a strip needs x_{k+1} — and the prob state — only on
+// the block rows its rows t0 - 2 ... t1 + 1 touch, so a gradient workgroup can start as soon as THOSE block rows have
+// been projected, while the projection's last workgroups are still running; the launch boundary that remains is the one
+// the norm needs.
+//   * Work is CLAIMED, not mapped from blockIdx: a workgroup draws a ticket from the queue of the XCD it runs on (XCC id),
+//     projection items first; it takes a gradient item only after it has seen every queue's projection items handed out —
+//     to workgroups that are running, hence finish, since projection waits for nothing.  So a waiting gradient wavefront
+//     can never keep the workgroup it waits for from starting: no assumption about dispatch order or placement
+//     (MI355X_MICROARCH.md: "HIP promises nothing about dispatch order ... placement-independent protocols only").
+//   * Hand-over: projection stores x_{k+1} and the prob state write-through (sc1), waits for the stores' acknowledgement and
+//     adds one to its block row's counter; a gradient wavefront polls the counters of its block rows (monotonic over
+//     launches: target = wavefronts per block row x launches so far) and reads x_{k+1} and the prob state with sc1 loads.
+struct FuseArgs {
+        unsigned *head;         // [16]: tickets of THIS launch, [q] projection, [8 + q] gradient queue of XCD q; zero at launch
+        unsigned *head_next;    // [16]: the next launch's; zeroed by this one (nobody else touches it meanwhile)
+        unsigned *row_done;     // [block rows]: projection wavefronts finished, summed over the launches since reset
+        unsigned done_target;   // what a finished block row shows during this launch
+        unsigned np_wg, ng_wg;  // workgroups of the projection part / of the gradient part
+        unsigned g_gx;          // gradient workgroups per row segment
+};
+
 // rows per norm partial on canvases large enough to fill the chip: the granularity of the GPU-count invariant
 // reduction, and what band boundaries are aligned to (J2P_TILE_ROWS).  Small canvases use 8 or 4 (Geo::rpw).
 constexpr int kTY = 16;
@@ -433,6 +455,29 @@ __device__ __forceinline__ V buf_load(__amdgpu_buffer_rsrc_t r, unsigned lane_of
 {
         if constexpr(sizeof(V) == 8) { return buf_load2<NT>(r, lane_off, row_off); }
         else { return buf_load1<NT>(r, lane_off, row_off); }
+}
+// The same accesses at AGENT scope (the `sc1` bit, aux = 16): a store is written through to the memory side and leaves
+// nothing dirty in this XCD's L2, a load bypasses the CU's L1 — together the form in which data written by one workgroup
+// of a launch can be read by another workgroup of the SAME launch, whichever XCD either runs on (MI355X_MICROARCH.md,
+// "inter-workgroup visibility": L2s are kept coherent for what has reached the memory side, L1s are not).  Used by the
+// single-launch iteration (k_iterate): projection workgroups hand x_{k+1} and the prob state to gradient workgroups.
+constexpr int kAuxSc1 = 16;
+template <class V>
+__device__ __forceinline__ V buf_load_sc1(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned row_off)
+{
+        if constexpr(sizeof(V) == 8) {
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_off, (int)row_off, kAuxSc1));
+        } else {
+                return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)row_off, kAuxSc1));
+        }
+}
+__device__ __forceinline__ void buf_store4_sc1(float a, float b, float c, float d, __amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned row_off)
+{
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        const v4u raw = v4u{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c),
+                            __builtin_bit_cast(unsigned, d)};
+        __builtin_amdgcn_raw_buffer_store_b128(raw, r, (int)lane_off, (int)row_off, kAuxSc1);
 }
 
 // Everything below is written once for a lane's PIXEL VECTOR V: v2f = two neighbouring columns per lane, the arithmetic
@@ -1210,35 +1255,16 @@ constexpr int kGradWaves3 = 2;    // ... the three-channels-in-one-wavefront sch
 // 4096^2 Y (288 MiB): level 1, 137 -> 127 us per iteration; 16384x2048 (576 MiB, the planes x_k, x_{k-1} are exactly
 // 256 MiB): level 3, 292 -> 240 us; when everything fits the hint costs 1-2 %.
 // PX: columns per lane (2: packed arithmetic, 128-column strips; 1: 64-column strips, see the pixel-vector overloads above)
-template <int NCH, bool TGV, bool LOG, int J = 1, int NT = 0, int PX = 2>
-__global__ __launch_bounds__((J == 1 ? 256 : 64 * J), (PX == 1 ? (J == 1 && !LOG ? 6 : 2) : NCH == 1 ? kGradWaves1 : NCH == 2 ? 3 : kGradWaves3))
-void k_gradient(GradArgs a)
+// The body of the gradient phase for the workgroup's strips: (bx, bseg) = strip group and row segment; xchg / fold_buf = the
+// workgroup's LDS.  FUSED (k_iterate only, one 1x1 channel): x_k — which projection workgroups of the SAME launch are
+// writing — and the prob state are read with sc1 loads, after the block rows they lie in have reported in (FuseArgs).
+template <int NCH, bool TGV, bool LOG, int J, int NT, int PX, bool FUSED, class V>
+__device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, double *fold_buf, unsigned bx, unsigned bseg, const FuseArgs *fz)
 {
-        static_assert(J == 1 || NCH == 1, "channel-per-wavefront mode keeps one channel per wavefront");
-        static_assert(PX == 2 || NCH == 1, "one column per lane: one channel per wavefront");
-        typedef typename std::conditional<PX == 2, v2f, float>::type V;
+        static_assert(!FUSED || (NCH == 1 && J == 1 && PX == 2 && !LOG && NT == 0), "the single-launch iteration: one channel, packed strips, no logging");
         constexpr int kCols = 64 * PX - 4;                      // output columns per strip: 2 halo columns on each side
-        __shared__ __attribute__((aligned(16))) V xchg[J == 1 ? 1 : 2 * J * 64 * 3];
-        __shared__ double fold_buf[kFoldMaxRows];               // the norm tree of the launch's last wavefront
         const int lane = (int)threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // uniform: keeps row/strip arithmetic scalar
-        // XCD-aware order (speed only): workgroup b runs on XCD b % 8, so give every XCD a contiguous,
-        // row-major run of (segment, strip-group) pairs — vertically adjacent strips then meet in one
-        // L2 and their shared halo rows are fetched from HBM once.  Bijective for any grid size.
-        unsigned bx = blockIdx.x, bseg = blockIdx.y;
-        // (reduce_norm: the grid's last row of workgroups is not strips — its first workgroup reduces ||g||)
-        const unsigned strip_rows = a.reduce_norm ? gridDim.y - 1 : gridDim.y;
-        if(blockIdx.y == strip_rows) {
-                if(blockIdx.x == 0) { norm_reducer(a, fold_buf); }
-                return;
-        }
-        {
-                const unsigned nwg = gridDim.x * strip_rows, b = blockIdx.y * gridDim.x + blockIdx.x;
-                const unsigned xcd = b & 7, q = nwg >> 3, rem = nwg & 7;
-                const unsigned l = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
-                bx = l % gridDim.x;
-                bseg = a.geo.seg_off + (l / gridDim.x) * a.geo.seg_mul;
-        }
         const int wcol = J == 1 ? (int)bx * (int)(blockDim.x >> 6) + wave : (int)bx;   // J == 1: blockDim.x / 64 strips per workgroup
         const int cbase = J == 1 ? 0 : wave;                    // first channel of this wavefront
         if(wcol >= (int)a.geo.ntx) { return; }
@@ -1253,6 +1279,21 @@ void k_gradient(GradArgs a)
         const int rows = (int)a.geo.rows, row0 = (int)a.geo.row0;
         const int t0 = (int)(bseg * a.geo.rpw);                // band-local target rows [t0, t1)
         const int t1 = t0 + (int)a.geo.rpw < rows ? t0 + (int)a.geo.rpw : rows;
+        if constexpr(FUSED) {
+                // rows t0 - 2 ... t1 + 1 of x_{k+1} (and the prob state of rows t0 ... t1 - 1) come from THIS launch's projection
+                // workgroups: wait until the 8-row block rows they lie in have reported in.  Lane i polls block row b_lo + i
+                // (a strip of <= 16 rows touches at most 4); relaxed agent-scope loads, a short sleep between polls.
+                const int last_row = rows - 1;
+                const int r_lo = t0 - 2 < 0 ? 0 : t0 - 2, r_hi = t1 + 1 > last_row ? last_row : t1 + 1;
+                const int b_lo = r_lo >> 3, nb = (r_hi >> 3) - b_lo + 1;
+                for(;;) {
+                        bool ok = true;
+                        if(lane < nb) { ok = __hip_atomic_load(fz->row_done + b_lo + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= fz->done_target; }
+                        if(__builtin_amdgcn_ballot_w64(!ok) == 0) { break; }
+                        __builtin_amdgcn_s_sleep(4);
+                }
+                asm volatile("" ::: "memory");                   // (the row loads below stay below)
+        }
         // Strip i loads columns [kCols i, kCols i + 64 PX); its two outermost columns on each side are halo — except
         // at the image's left and right edges, where the neighbour beyond the edge contributes nothing anyway, so the
         // first strip also owns its left halo lanes and the last strip its right ones: n strips cover kCols n + 4
@@ -1320,7 +1361,8 @@ void k_gradient(GradArgs a)
                 for(int c = 0; c < NCH; c++) {
                         J2P_CHK(a.ch[cbase + c], x_read[0], reinterpret_cast<const char *>(a.ch[cbase + c].xcur + roff) + xoff, 4 * PX, 101);
                         J2P_CHK(a.ch[cbase + c], x_read[1], reinterpret_cast<const char *>(a.ch[cbase + c].xprev + roff) + xoff, 4 * PX, 102);
-                        rc[c] = buf_load<false, V>(res_cur[c], xoff, row_off);
+                        if constexpr(FUSED) { rc[c] = buf_load_sc1<V>(res_cur[c], xoff, row_off); }
+                        else { rc[c] = buf_load<false, V>(res_cur[c], xoff, row_off); }
                         rp[c] = buf_load<false, V>(res_prev[c], xoff, row_off);
                 }
         };
@@ -1388,7 +1430,8 @@ void k_gradient(GradArgs a)
                                 const float *prow = k.pg + (size_t)((unsigned)gt - k.crow0) * k.cw;
                                 J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + xoff, 4 * PX, 103);
                                 (void)prow;
-                                pv[c] = buf_load<(NT >= 2), V>(res_pg[c], xoff, (unsigned)(gt - row0 - grad_base) * k.cw * 4u);
+                                if constexpr(FUSED) { pv[c] = buf_load_sc1<V>(res_pg[c], xoff, (unsigned)(gt - row0 - grad_base) * k.cw * 4u); }
+                                else { pv[c] = buf_load<(NT >= 2), V>(res_pg[c], xoff, (unsigned)(gt - row0 - grad_base) * k.cw * 4u); }
                                 continue;
                         }
                         unsigned cr;
@@ -1400,7 +1443,10 @@ void k_gradient(GradArgs a)
                         }
                         const float *prow = k.pg + (size_t)(cr - k.crow0) * k.cw;
                         J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][0], 4, 104);
-                        if constexpr(PX == 2) {
+                        if constexpr(FUSED) {
+                                pv[c] = v2f{__hip_atomic_load(reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                            __hip_atomic_load(reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
+                        } else if constexpr(PX == 2) {
                                 J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][1], 4, 105);
                                 pv[c] = v2f{*reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][0]),
                                             *reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][1])};   // two dword loads whatever the sampling: no branch
@@ -1602,6 +1648,39 @@ void k_gradient(GradArgs a)
 #endif
         trace_put(a.geo.trace, a.geo.trace_cap, a.geo.trace_base, 1u, a.geo.trace_seq, tr_start, tr_data, trace_now());
 #endif
+}
+
+// item l of n, dealt to 8 queues in contiguous runs (queue q holds items [chunk_base(n, q), chunk_base(n, q + 1))): what
+// "workgroup b runs on XCD b % 8" turns into when every XCD is to work on one contiguous region of the canvas
+__device__ __forceinline__ unsigned chunk_base(unsigned n, unsigned q) { return q * (n >> 3) + (q < (n & 7) ? q : (n & 7)); }
+
+template <int NCH, bool TGV, bool LOG, int J = 1, int NT = 0, int PX = 2>
+__global__ __launch_bounds__((J == 1 ? 256 : 64 * J), (PX == 1 ? (J == 1 && !LOG ? 6 : 2) : NCH == 1 ? kGradWaves1 : NCH == 2 ? 3 : kGradWaves3))
+void k_gradient(GradArgs a)
+{
+        static_assert(J == 1 || NCH == 1, "channel-per-wavefront mode keeps one channel per wavefront");
+        static_assert(PX == 2 || NCH == 1, "one column per lane: one channel per wavefront");
+        typedef typename std::conditional<PX == 2, v2f, float>::type V;
+        __shared__ __attribute__((aligned(16))) V xchg[J == 1 ? 1 : 2 * J * 64 * 3];
+        __shared__ double fold_buf[kFoldMaxRows];               // the norm tree of the launch's last wavefront
+        // XCD-aware order (speed only): workgroup b runs on XCD b % 8, so give every XCD a contiguous,
+        // row-major run of (segment, strip-group) pairs — vertically adjacent strips then meet in one
+        // L2 and their shared halo rows are fetched from HBM once.  Bijective for any grid size.
+        unsigned bx = blockIdx.x, bseg = blockIdx.y;
+        // (reduce_norm: the grid's last row of workgroups is not strips — its first workgroup reduces ||g||)
+        const unsigned strip_rows = a.reduce_norm ? gridDim.y - 1 : gridDim.y;
+        if(blockIdx.y == strip_rows) {
+                if(blockIdx.x == 0) { norm_reducer(a, fold_buf); }
+                return;
+        }
+        {
+                const unsigned nwg = gridDim.x * strip_rows, b = blockIdx.y * gridDim.x + blockIdx.x;
+                const unsigned xcd = b & 7, q = nwg >> 3, rem = nwg & 7;
+                const unsigned l = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
+                bx = l % gridDim.x;
+                bseg = a.geo.seg_off + (l / gridDim.x) * a.geo.seg_mul;
+        }
+        gradient_strip<NCH, TGV, LOG, J, NT, PX, false, V>(a, xchg, fold_buf, bx, bseg, nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -2058,9 +2137,14 @@ struct __attribute__((aligned(16))) ProjShared {
 // 2: by the workgroup's FIRST wavefront, before anything else, and handed to the other three through LDS at the barrier
 // that publishes the quantisation tables anyway (bands of a row-tiled run: up to 1024 row sums, a quarter of the
 // loads and none of the registers of form 1 — the tree's values are dead before the row loads are issued)
-template <bool LOG, int WS, int HS, int NT, int NIP, bool PTR = false>
-__device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
+// FUSED (k_iterate only; one 1x1 channel that covers the canvas): `wg` of `nwg` is the workgroup's CLAIMED item — already
+// the position in the XCD-contiguous order — the new iterate and the prob state are stored write-through (sc1) and the
+// wavefront reports its block row in when those stores have been acknowledged (FuseArgs).
+template <bool LOG, int WS, int HS, int NT, int NIP, bool PTR = false, bool FUSED = false>
+__device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh, unsigned wg = blockIdx.x, unsigned nwg = gridDim.x,
+                                              const FuseArgs *fz = nullptr)
 {
+        static_assert(!FUSED || (WS == 1 && HS == 1 && !LOG && NT == 0), "the single-launch iteration: one full-resolution channel, no logging");
         float *const tp = sh.tp;
         float *const qs = sh.qs, *const qq = sh.qq, *const rqq = sh.rqq, *const rq = sh.rq;
         int &q_fast = sh.q_fast;
@@ -2072,7 +2156,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
 #endif
 #endif
 
-        const unsigned zi = blockIdx.z;
+        const unsigned zi = FUSED ? 0u : blockIdx.z;
         const int c = (int)a.chan_of_z[zi];
         const ChanDev &k = a.ch[c];
         const int lane = (int)threadIdx.x & 63;
@@ -2084,8 +2168,9 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
         // workgroup b runs on XCD b % 8: give every XCD a contiguous run of strips (as k_gradient does) — the eight
         // L2s then each stream one region of the planes instead of interleaving at 1 KB (68.8 -> 67.8 us at 4096^2)
         unsigned lstrip;
-        {
-                const unsigned nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, rem = nwg & 7;
+        if constexpr(FUSED) { lstrip = wg * 4 + wave; }
+        else {
+                const unsigned b = wg, xcd = b & 7, q = nwg >> 3, rem = nwg & 7;
                 const unsigned l = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
                 lstrip = l * 4 + wave;                                // index within this launch
         }
@@ -2129,7 +2214,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                           ly0 + 8 <= a.geo.rows;
         // band instantiations: strips of the band's first / last block row also store into the neighbours' halo rows
         // (ProjArgs::halo_up / halo_down).  Wave-uniform pointers; NULL for every other strip.
-        constexpr bool PUSH = NIP == 2;
+        constexpr bool PUSH = NIP == 2 && !FUSED;
         float *push_up = nullptr, *push_down = nullptr;
         if constexpr(PUSH) {
                 if(ly0 < (unsigned)kHalo) { push_up = a.halo_up[c]; }
@@ -2387,8 +2472,15 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                 if(bcov && ly0 + rr < a.geo.rows) {
                         float4 *dst = reinterpret_cast<float4 *>(k.xprev + (size_t)(ly0 + rr) * W + bx * 8);
                         J2P_CHK(k, x_own[1], dst, 32, 212);
+                        if constexpr(FUSED) {
+                                const __amdgpu_buffer_rsrc_t rx = rows_from(k.xprev + (size_t)ly0 * W);
+                                const unsigned off = ((unsigned)rr * W + bx * 8) * 4u;
+                                buf_store4_sc1(v[0], v[1], v[2], v[3], rx, off, 0u);
+                                buf_store4_sc1(v[4], v[5], v[6], v[7], rx, off + 16u, 0u);
+                        } else {
                         dst[0] = make_float4(v[0], v[1], v[2], v[3]);
                         dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+                        }
                         if constexpr(PUSH) {
                                 if(float *h = halo_copy_of(ly0 + rr)) {
 #pragma unroll
@@ -2447,7 +2539,12 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                         float4 *dst = reinterpret_cast<float4 *>(k.pg + (size_t)(cy0 - k.crow0 + rr) * k.cw + bx * 8);
 #endif
                         J2P_CHK(k, pg, dst, 32, 214);
-                        if constexpr(NT >= 2) {
+                        if constexpr(FUSED) {
+                                const __amdgpu_buffer_rsrc_t rpg = rows_from(k.pg + (size_t)(cy0 - k.crow0) * k.cw);
+                                const unsigned off = ((unsigned)rr * k.cw + bx * 8) * 4u;
+                                buf_store4_sc1(e[0], e[1], e[2], e[3], rpg, off, 0u);
+                                buf_store4_sc1(e[4], e[5], e[6], e[7], rpg, off + 16u, 0u);
+                        } else if constexpr(NT >= 2) {
                                 typedef float v4f __attribute__((ext_vector_type(4)));
                                 __builtin_nontemporal_store(v4f{e[0], e[1], e[2], e[3]}, reinterpret_cast<v4f *>(dst));
                                 __builtin_nontemporal_store(v4f{e[4], e[5], e[6], e[7]}, reinterpret_cast<v4f *>(dst) + 1);
@@ -2462,6 +2559,12 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                         for(int off = 32; off > 0; off >>= 1) { dist += __shfl_down(dist, off, 64); }
                         if(lane == 0) { a.part_prob[(size_t)c * a.strips_per_chan + strip] = dist; }
                 }
+        }
+        if constexpr(FUSED) {
+                // this wavefront's part of block row `by` is in place: every store above acknowledged (written through), then
+                // the count the gradient wavefronts of this launch poll (gradient_strip)
+                stores_acknowledged();
+                if(lane == 0) { __hip_atomic_fetch_add(fz->row_done + by, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
 #ifdef J2P_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2505,6 +2608,73 @@ __global__ __launch_bounds__(256) void k_project_mixed(ProjArgs a)
         if(k.ws == 1 && k.hs == 1) { project_strip<LOG, 1, 1, 0, (NIP ? 1 : 0)>(a, sh); }
         else if(k.ws == 2 && k.hs == 2) { project_strip<LOG, 2, 2, 0, (NIP ? 1 : 0)>(a, sh); }
         else { project_strip<LOG, 0, 0, 0, (NIP ? 1 : 0)>(a, sh); }
+}
+
+// ---------------------------------------------------------------------------
+// The single-launch iteration (see FuseArgs): projection(k) and gradient(k + 1) of ONE full-resolution channel that covers
+// its canvas (Y-only planes, the components of `-s`: jpeg2png.c:147-152) in one grid; reference loop compute.c:430-448.
+// ||g_k|| is reduced by every projection wavefront from the row sums gradient(k) left (NIP 1); gradient(k + 1) folds its
+// own row sums into the other parity's array.  One workgroup = one claimed item: 4 projection strips or 4 gradient strips.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned xcc_id()
+{
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        return x & 7u;
+}
+constexpr unsigned kNoItem = 0xffffffffu, kGradientItem = 0x80000000u;
+
+// one ticket for the calling workgroup (thread 0): a projection item while any is left ANYWHERE, then a gradient item
+__device__ __forceinline__ unsigned claim_item(const FuseArgs &fz)
+{
+        const unsigned q0 = xcc_id();
+        for(unsigned part = 0; part < 2; part++) {
+                const unsigned n = part == 0 ? fz.np_wg : fz.ng_wg;
+                unsigned *heads = fz.head + 8 * part;
+                for(unsigned d = 0; d < 8; d++) {
+                        const unsigned q = (q0 + d) & 7u;
+                        const unsigned base = chunk_base(n, q), size = chunk_base(n, q + 1) - base;
+                        // (another XCD's queue: look before drawing, so that its counter is not run up by everybody)
+                        if(d != 0 && __hip_atomic_load(heads + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= size) { continue; }
+                        const unsigned t = __hip_atomic_fetch_add(heads + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if(t < size) { return (part ? kGradientItem : 0u) | (base + t); }
+                }
+                // every queue of this part has been seen exhausted: all its items are in the hands of running workgroups
+        }
+        return kNoItem;
+}
+
+struct __attribute__((aligned(16))) IterateShared {
+        union {
+                ProjShared proj;
+                double fold_buf[kFoldMaxRows];
+        };
+        unsigned item;
+};
+
+// NIP: who reduces ||g_k|| from the row sums in the projection part: 1 = every wavefront, 2 = the workgroup's first (see project_strip)
+template <bool TGV, int NIP>
+__global__ __launch_bounds__(256, kGradWaves1) void k_iterate(ProjArgs pa, GradArgs ga, FuseArgs fz)
+{
+        __shared__ IterateShared sh;
+        if(threadIdx.x == 0) {
+                const unsigned it = claim_item(fz);
+                sh.item = it;
+                // the next launch's tickets start from zero (its launch comes after this one has ended)
+                if(it == 0u) {
+                        for(unsigned i = 0; i < 16; i++) { __hip_atomic_store(fz.head_next + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                }
+        }
+        __syncthreads();
+        const unsigned item = sh.item;
+        if(item == kNoItem) { return; }
+        if(!(item & kGradientItem)) {
+                project_strip<false, 1, 1, 0, NIP, false, true>(pa, sh.proj, item, fz.np_wg, &fz);
+        } else {
+                const unsigned l = item & ~kGradientItem;
+                v2f *no_xchg = nullptr;
+                gradient_strip<1, TGV, false, 1, 0, 2, true, v2f>(ga, no_xchg, sh.fold_buf, l % fz.g_gx, l / fz.g_gx, &fz);
+        }
 }
 
 // ---------------------------------------------------------------------------

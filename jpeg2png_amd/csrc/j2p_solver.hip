@@ -106,6 +106,11 @@ struct j2p_solver {
         size_t live_ws = 0, live_g = 0, live_planes = 0, live_d = 0;
         bool phase_log = false;         // the gradient phase of the running iteration was issued with logging
         bool mixed_project = true;      // small canvases: all samplings in one projection launch (J2P_OPT_MIXED_PROJECT)
+        // the single-launch iteration (k_iterate: projection(k) + gradient(k + 1) in one grid, see FuseArgs)
+        bool fuse_possible = false;     // one 1x1 channel covering a whole canvas of at most kWaveTreeMax tile rows
+        bool fuse = false;              // ... and in use (policy: canvases up to kFusePixels; J2P_OPT_FUSE)
+        unsigned *fuse_state = nullptr; // device: [2][16] queue heads, then [block rows] row_done
+        unsigned fuse_launches = 0;     // k_iterate launches since reset (row_done counts on)
         unsigned long long *dbg_counters = nullptr;   // J2P_DEBUG builds: [0] address violations, [1] first site, [2] first offset
         unsigned long long *trace = nullptr;          // J2P_TRACE builds: wave records (tools/wave_trace.py)
         unsigned trace_cap = 0, trace_used = 0;      // records reserved by the launches so far
@@ -298,6 +303,9 @@ struct Carver {
 constexpr size_t kNtWorkingSet = (size_t)260 << 20;      // see nt_policy in j2p_solver_create
 constexpr size_t kNormInProjectPixels = (size_t)5 << 19; // whole canvases up to this size (2.5 Mpixel) reduce ||g|| without a launch of its own
 constexpr size_t kMixedProjectPixels = (size_t)1 << 20;  // canvases up to this size project all channels in one launch
+// one-channel canvases up to this size iterate with ONE launch per iteration (k_iterate); above it the chip is full for the
+// whole of either phase and the second launch boundary is lost in the phases' own length
+constexpr size_t kFusePixels = (size_t)1 << 23;
 // whole canvases from this size on (and at most kFoldMaxRows tile rows) reduce ||g|| entirely inside k_gradient: on wide
 // planes the k_norm_whole launch stages 17 K partials through one CU (9 us at W = 16384) — 16384x2048 232.1 -> 229.4 us per
 // iteration, 8192^2 521.6 -> 511.3; at 4096^2 the launch (4.7 us) is the cheaper one, 117.6 vs 119.4
@@ -402,6 +410,14 @@ Geo geo_of(const j2p_solver *s)
         g.trace_base = s->trace_used;
 #endif
         return g;
+}
+
+// where the gradient phase of iteration `iter` leaves its level-1 row sums [tile row][channel]: band solvers whose sums
+// are read in place by other bands (j2p_solver_alternate_rowsums) and whole-canvas solvers that iterate with one launch
+// (k_iterate: gradient(k + 1) writes while projection(k) still reads) alternate between two arrays
+double *rowsums_of(const j2p_solver *s, unsigned iter)
+{
+        return ((s->rowsum_alternate || s->fuse) && (iter & 1)) ? s->rowsum_odd : s->rowsum_local;
 }
 
 template <int NCH, int J, int PX = 2>
@@ -530,7 +546,7 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         const bool fold_norm = !nip && s->fold && s->whole && part == 0 && s->ntr_global <= kFoldMaxRows;
         a.row_ticket = s->fold ? s->tickets : nullptr;
         a.done_ticket = s->tickets + s->ntr_local;
-        a.rowsum = (s->rowsum_alternate && (s->iter & 1)) ? s->rowsum_odd : s->rowsum_local;
+        a.rowsum = rowsums_of(s, s->iter);
         a.push = nullptr;
         if(s->linked) {
                 if(part != 0) { return fail(J2P_ESTATE, "linked bands run whole phases (there is no exchange to hide)"); }
@@ -666,7 +682,7 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
         while(P < s->ntr_global) { P <<= 1; }
         // the global [tile row][channel] sums a band solver finishes ||g|| from: gathered by the caller, or — linked
         // bands — stored there by every band's gradient launch, even and odd iterations in two arrays
-        const double *global_rows = (s->linked && (s->iter & 1)) ? s->rowsum_all_odd : s->rowsum_all;
+        const double *global_rows = s->whole ? rowsums_of(s, s->iter) : ((s->linked && (s->iter & 1)) ? s->rowsum_all_odd : s->rowsum_all);
         bool nip2 = false;
         if(part == 2 || s->norm_ready || s->norm_by_project) {
                 // the norm is already there, or every wavefront of k_project reduces the row sums itself
@@ -699,7 +715,7 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
         a.norm = s->norm;
         a.part_prob = s->part_prob;
         a.strips_per_chan = s->strips_stride;
-        a.norm_rowsums = nip2 ? global_rows : (s->norm_by_project ? s->rowsum_local : nullptr);
+        a.norm_rowsums = nip2 ? global_rows : (s->norm_by_project ? rowsums_of(s, s->iter) : nullptr);
         a.norm_rows = s->ntr_global;
         a.norm_nch = s->nch;
         const int nip = nip2 ? 2 : (s->norm_by_project ? s->nip_form : 0);
@@ -795,6 +811,79 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
         return J2P_OK;
 }
 
+// projection(k) + gradient(k + 1) in ONE launch (k_iterate; reference loop compute.c:430-448).  Entered with gradient(k)
+// issued (grad_done) and leaves gradient(k + 1) issued: the caller opens a run with do_phase_gradient and closes it with
+// do_phase_project.  One 1x1 channel covering a whole canvas, no logging (s->fuse).
+int do_fused_step(j2p_solver *s)
+{
+        if(!s->fuse || !s->grad_done || !s->norm_by_project || s->phase_log) { return fail(J2P_ESTATE, "fused step outside a fused run"); }
+        // ---- projection(k): as do_phase_project sets it up for this case ----
+        ProjArgs pa;
+        pa.ch[0] = chan_dev(s, 0);
+        pa.geo = geo_of(s);
+        pa.factor = s->factor;
+        const float radius = sqrtf((float)s->H * (float)s->W) / 2;             // compute.c:425
+        pa.step = radius / sqrtf((float)(1 + s->iterations));                   // compute.c:443
+        pa.norm = s->norm;
+        pa.part_prob = s->part_prob;
+        pa.strips_per_chan = s->strips_stride;
+        pa.chan_of_z[0] = 0;
+        const unsigned brows = (s->rows + 7) / 8, strips_x = (s->W + 63) / 64;
+        pa.by_offset[0] = 0;
+        pa.by_mul[0] = 1;
+        pa.nby[0] = brows;
+        pa.norm_rowsums = rowsums_of(s, s->iter);
+        pa.norm_rows = s->ntr_global;
+        pa.norm_nch = 1;
+        for(unsigned c = 0; c < kMaxCh; c++) { pa.halo_up[c] = pa.halo_down[c] = nullptr; }
+        // ---- SWAP(fdata, fista), compute.c:438: the buffer the projection part writes is x_{k+1} for the gradient part ----
+        s->cur ^= 1;
+        s->iter++;
+        // ---- gradient(k + 1): as do_phase_gradient sets it up for this case ----
+        const float tnext = (1 + sqrtf(1 + 4 * (s->t * s->t))) / 2;             // compute.c:431-432,440
+        s->factor = (s->t - 1) / tnext;
+        s->t = tnext;
+        GradArgs ga;
+        ga.ch[0] = chan_dev(s, 0);
+        ga.geo = geo_of(s);
+        ga.factor = s->factor;
+        ga.a_tv = (float)(1. / (double)sqrtf((float)s->nch));                   // compute.c:90
+        const float alpha = s->weight / sqrtf((float)(4 / 2));                  // compute.c:258
+        ga.a_tgv = (float)((double)alpha * 1. / (double)sqrtf((float)s->nch));  // compute.c:154
+        ga.part_g2 = s->part_g2;
+        ga.part_tv = s->part_tv;
+        ga.row_ticket = s->tickets;
+        ga.done_ticket = s->tickets + s->ntr_local;
+        ga.rowsum = rowsums_of(s, s->iter);
+        ga.norm_out = nullptr;
+        ga.nch_total = 1;
+        ga.fold_phase = s->iter & 1;
+        ga.fold_rows = s->ntr_local;
+        ga.ntr_global = s->ntr_global;
+        ga.reduce_norm = nullptr;
+        ga.push = nullptr;
+        FuseArgs fz;
+        fz.head = s->fuse_state + 16 * (s->fuse_launches & 1);
+        fz.head_next = s->fuse_state + 16 * ((s->fuse_launches + 1) & 1);
+        fz.row_done = s->fuse_state + 32;
+        fz.done_target = strips_x * (s->fuse_launches + 1);
+        fz.np_wg = (strips_x * brows + 3) / 4;
+        fz.g_gx = (s->ntx + 3) / 4;
+        fz.ng_wg = fz.g_gx * s->nseg;
+        const dim3 grid(fz.np_wg + fz.ng_wg);
+        if(s->nip_form == 2) {
+                if(s->weight != 0.f) { hipLaunchKernelGGL((k_iterate<true, 2>), grid, dim3(256), 0, s->stream, pa, ga, fz); }
+                else { hipLaunchKernelGGL((k_iterate<false, 2>), grid, dim3(256), 0, s->stream, pa, ga, fz); }
+        } else {
+                if(s->weight != 0.f) { hipLaunchKernelGGL((k_iterate<true, 1>), grid, dim3(256), 0, s->stream, pa, ga, fz); }
+                else { hipLaunchKernelGGL((k_iterate<false, 1>), grid, dim3(256), 0, s->stream, pa, ga, fz); }
+        }
+        HIP_TRY(hipGetLastError());
+        s->fuse_launches++;
+        // (state as do_phase_gradient leaves it: grad_done, the norm comes from the row sums, no logging)
+        return J2P_OK;
+}
+
 int upload(void *dst, const void *src, size_t bytes, hipStream_t st)
 {
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
@@ -818,6 +907,8 @@ int launch_init(j2p_solver *s)
         // the partials of a folding gradient launch carry the iteration's parity in their sign bit (fold_tile_row): what
         // the slots hold before iteration 0 must carry the other one — all bits set
         HIP_TRY(hipMemsetAsync(s->part_g2, 0xff, (size_t)s->ntx * s->ntr_local * s->nch * sizeof(double), s->stream));
+        if(s->fuse_state) { HIP_TRY(hipMemsetAsync(s->fuse_state, 0, (32 + (size_t)(s->rows + 7) / 8) * sizeof(unsigned), s->stream)); }
+        s->fuse_launches = 0;
         s->iter = 0;
         s->t = 1.f;
         s->cur = 0;
@@ -1043,6 +1134,18 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         s->ntr_local = s->nseg;
         s->ntr_global = (H + s->rpw - 1) / s->rpw;
         s->first_tr = row0 / s->rpw;
+        // the single-launch iteration: one full-resolution channel that covers the whole canvas, packed strips, a tree
+        // k_project's wavefronts can run themselves (NIP 1)
+#if !defined(J2P_DEBUG) && !defined(J2P_TRACE)
+        s->fuse_possible = whole && nchannel == 1 && planes[0].w_samp == 1 && planes[0].h_samp == 1 && s->px == 2 &&
+                           s->ntr_global <= kWaveTreeMax;
+#endif
+        s->fuse = s->fuse_possible && (size_t)W * H <= kFusePixels;
+        if(s->fuse) {
+                s->fold = true;                 // level 1 of ||g|| inside the gradient part, level 2 by every projection wavefront
+                s->norm_in_project = true;
+                s->nip_form = 1;
+        }
         const size_t ntiles = (size_t)s->ntx * s->ntr_local;
         unsigned max_strips = 0;
         for(unsigned c = 0; c < nchannel; c++) {
@@ -1084,8 +1187,11 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 carve.take(q_all, 64 * kMaxCh);
                 carve.take(s->part_g2, ntiles * nchannel);
                 carve.take(s->rowsum_local, (size_t)s->ntr_local * nchannel);
-                if(whole) { s->rowsum_all = s->rowsum_local; }
-                else {
+                if(whole) {
+                        s->rowsum_all = s->rowsum_local;
+                        carve.take(s->rowsum_odd, (size_t)s->ntr_local * nchannel);      // (the single-launch iteration alternates)
+                        carve.take(s->fuse_state, 32 + (size_t)(s->rows + 7) / 8);
+                } else {
                         carve.take(s->rowsum_all, (size_t)s->ntr_global * nchannel);
                         carve.take(s->rowsum_all_odd, (size_t)s->ntr_global * nchannel);
                         carve.take(s->push_dev, 2);
@@ -1202,6 +1308,7 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
                 // gradient launch's last workgroup reduces
                 s->fold = value == 1;
                 s->reducer = value == 2;
+                if(!s->fold) { s->fuse = false; }          // (the single-launch iteration folds: J2P_OPT_FUSE 1 turns both on again)
                 break;
         case J2P_OPT_JOINT_INWAVE:
                 if(value && s->px == 1) { return fail(J2P_ESTATE, "the in-wavefront joint kernel has no one-column-per-lane form (set J2P_JOINT_INWAVE=1 before the solver is created)"); }
@@ -1211,12 +1318,27 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
                 // 0: off; 1: the per-wavefront tree; 2: the per-workgroup tree; (needs NORM_FOLD)
                 s->norm_in_project = value != 0;
                 s->nip_form = value == 2 ? 2 : 1;
+                if(!s->norm_in_project) { s->fuse = false; }
                 break;
         case J2P_OPT_NT_GRADIENT:
                 s->nt_forced = value >= 0;                 // negative: back to the policy
                 s->nt = value < 0 ? nt_policy(s) : (value > 3 ? 3 : value);
                 break;
         case J2P_OPT_MIXED_PROJECT: s->mixed_project = value != 0; break;
+        case J2P_OPT_FUSE:
+                if(value && !s->fuse_possible) { return fail(J2P_ESTATE, "the single-launch iteration needs one full-resolution channel covering a whole canvas of at most %u tile rows", kWaveTreeMax); }
+                if(value && !s->fuse) {
+                        // row sums alternate from now on, ||g|| comes from them inside the projection; the partials' parity marks as at reset
+                        DeviceGuard guard(s->device);
+                        if(!s->fold && !s->reducer) {
+                                HIP_TRY(hipMemsetAsync(s->part_g2, (s->iter & 1) ? 0x00 : 0xff, (size_t)s->ntx * s->ntr_local * s->nch * sizeof(double), s->stream));
+                        }
+                        s->fold = true;
+                        s->reducer = false;
+                        s->norm_in_project = true;
+                }
+                s->fuse = value != 0;
+                break;
         default: return fail(J2P_EINVAL, "unknown option %d", option);
         }
         return J2P_OK;
@@ -1292,6 +1414,16 @@ int j2p_solver_band(const j2p_solver *s, unsigned *row_begin, unsigned *row_end)
         if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
         if(row_begin) { *row_begin = s->row0; }
         if(row_end) { *row_end = s->row0 + s->rows; }
+        return J2P_OK;
+}
+
+int j2p_solver_launches_per_iteration(const j2p_solver *s, unsigned *n)
+{
+        if(!s || !n) { return fail(J2P_EINVAL, "NULL argument"); }
+        // (unlogged runs of a whole-canvas solver; logging adds the log kernels and takes the two-launch form)
+        if(s->fuse) { *n = 1; }
+        else if(!s->whole) { *n = 2 + (s->band_nip ? 0u : 1u); }
+        else { *n = (s->fold || s->reducer) ? 2 : 3; }
         return J2P_OK;
 }
 
@@ -1431,6 +1563,17 @@ int j2p_solver_run(j2p_solver *s, unsigned n, j2p_log_row *rows)
                 s->logsums_cap = 0;
                 HIP_TRY(dev_malloc((void **)&s->logsums, (size_t)n * kRow * sizeof(double)));
                 s->logsums_cap = n;
+        }
+        // one launch per iteration where that pays (s->fuse): gradient(k0), then n - 1 launches of projection(k) + gradient(k + 1),
+        // then projection(k0 + n - 1).  Timing events bracket the two phases and logging needs their sums: both take the
+        // two-launch form.
+        if(s->fuse && s->fold && s->norm_in_project && !log && !s->timing && n >= 2) {
+                int rc = do_phase_gradient(s, false);
+                for(unsigned i = 1; i < n && rc == J2P_OK; i++) { rc = do_fused_step(s); }
+                if(rc == J2P_OK) { rc = do_phase_project(s, false); }
+                if(rc != J2P_OK) { return rc; }
+                s->carried_valid = false;
+                return J2P_OK;
         }
         for(unsigned i = 0; i < n; i++) {
                 int rc = do_phase_gradient(s, log);

@@ -1159,8 +1159,13 @@ int j2p_tiled_run(j2p_tiled *t, unsigned n, j2p_log_row *rows)
                 t->done.wait(g, [&] { return t->finished == t->nband; });
         }
         t->iter += n;
-        for(Band *b : t->bands) {
-                if(b->rc != J2P_OK) { return j2p_fail(b->rc, "band [%u,%u) on device %d: %s", b->row0, b->row1, b->device, b->err); }
+        // (the band that failed first, not one that stopped because of it)
+        for(int pass = 0; pass < 2; pass++) {
+                for(Band *b : t->bands) {
+                        if(b->rc != J2P_OK && (pass == 1 || !strstr(b->err, "another band failed"))) {
+                                return j2p_fail(b->rc, "band [%u,%u) on device %d: %s", b->row0, b->row1, b->device, b->err);
+                        }
+                }
         }
         if(log) {
                 BAND_TRY(j2p_tiled_sync(t));

@@ -589,9 +589,16 @@ def test_every_schedule_switch_leaves_the_bits_alone(lib, oracle, shape, monkeyp
         {j.J2P_OPT_MIXED_PROJECT: 0},                                               # what a > 1 Mpixel canvas gets
         {j.J2P_OPT_MIXED_PROJECT: 0, j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 0, "J2P_JOINT_INWAVE": "1"},
     ]
+    if n == 1:
+        # one full-resolution channel: projection(k) + gradient(k + 1) in ONE launch (k_iterate) — the solver's own choice at
+        # this size — against the two-launch form, and with ||g|| reduced by the workgroup's first wavefront
+        settings += [{j.J2P_OPT_FUSE: 0}, {j.J2P_OPT_NORM_FOLD: 0, j.J2P_OPT_FUSE: 1}, {j.J2P_OPT_FUSE: 1, j.J2P_OPT_NORM_IN_PROJECT: 2},
+                     {j.J2P_OPT_FUSE: 1, j.J2P_OPT_NT_GRADIENT: 2}]
     for px in ("2", "1"):
         monkeypatch.setenv("J2P_PX", px)
         for opts in settings:
+            if px == "1" and opts.get(j.J2P_OPT_FUSE) == 1:
+                continue                        # the single-launch iteration exists with two columns per lane only
             if "J2P_JOINT_INWAVE" in opts:
                 if px == "1":
                     continue                    # the in-wavefront joint kernel exists with two columns per lane only

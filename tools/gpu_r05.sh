@@ -25,4 +25,10 @@ a)
     if [ $v = base ]; then $BENCH 2>/dev/null | line | brief $v; else J2P_LIBRARY=ab/libj2p_$v.so $BENCH 2>/dev/null | line | brief $v; fi
   done | tee $O/r05_decomposition.jsonl
   ;;
+b)
+  # the single-launch iteration: correctness first (fused tests + the schedule-equivalence test), then same-box A/B by size
+  ( timeout 900 python -m pytest tests/test_fused_gpu.py tests/test_tiled_verify_gpu.py -q -x --timeout 600 ) > $O/r05_b_fused_tests.log 2>&1; echo "fused tests rc=$?"; tail -12 $O/r05_b_fused_tests.log
+  ( timeout 600 python -m pytest tests/test_parity_gpu.py -q -x --timeout 600 -k "schedule_switch or full_size_against or concurrent" ) > $O/r05_b_parity.log 2>&1; echo "parity subset rc=$?"; tail -5 $O/r05_b_parity.log
+  timeout 600 python tools/fuse_ab.py 100 | tee $O/r05_single_launch.jsonl
+  ;;
 esac
