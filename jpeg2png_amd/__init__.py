@@ -134,11 +134,42 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise J2PError(f"{LIB_PATH} is missing: run `python -m jpeg2png_amd.buildlib` "
+    _lib = _bind(LIB_PATH)
+    return _lib
+
+
+class library:
+    """context manager: another build of the library for the objects created inside the block — the experiments build
+    (-DJ2P_EXPERIMENTS: schedules and environment knobs the release build does not carry, buildlib.build_experiments)
+    in the schedule-equivalence tests.  Solvers remember the library they were created from; both copies share the
+    process's HIP runtime."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        global _lib
+        load_library()
+        self._saved = _lib
+        _lib = _bind(self.path)
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+
+
+_bound = {}
+
+
+def _bind(path):
+    if path in _bound:
+        return _bound[path]
+    if not os.path.exists(path):
+        raise J2PError(f"{path} is missing: run `python -m jpeg2png_amd.buildlib` "
                        "(the HIP extension is the only implementation; there is no fallback)")
     _share_torch_hip_runtime()
-    lib = ctypes.CDLL(LIB_PATH)   # RTLD_LOCAL: our `compute` must not interpose other libraries' symbols
+    lib = ctypes.CDLL(path)   # RTLD_LOCAL: our `compute` must not interpose other libraries' symbols
     lib.j2p_version.restype = ctypes.c_char_p
     lib.j2p_last_error.restype = ctypes.c_char_p
     lib.j2p_solver_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_void_p,
@@ -193,7 +224,7 @@ def load_library():
     lib.j2p_batch_destroy.restype = None
     lib.j2p_batch_submit.argtypes = [ctypes.c_void_p, ctypes.POINTER(_CJob), ctypes.POINTER(ctypes.c_int)]
     lib.j2p_batch_wait.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    _lib = lib
+    _bound[path] = lib
     return lib
 
 

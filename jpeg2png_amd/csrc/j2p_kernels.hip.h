@@ -1279,7 +1279,11 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
         const int rows = (int)a.geo.rows, row0 = (int)a.geo.row0;
         const int t0 = (int)(bseg * a.geo.rpw);                // band-local target rows [t0, t1)
         const int t1 = t0 + (int)a.geo.rpw < rows ? t0 + (int)a.geo.rpw : rows;
+#ifdef J2P_EXP_FUSE_NOWAIT
+        if constexpr(false) {                                    // (timing experiment: what the waiting costs; results wrong)
+#else
         if constexpr(FUSED) {
+#endif
                 // rows t0 - 2 ... t1 + 1 of x_{k+1} (and the prob state of rows t0 ... t1 - 1) come from THIS launch's projection
                 // workgroups: wait until the 8-row block rows they lie in have reported in.  Lane i polls block row b_lo + i
                 // (a strip of <= 16 rows touches at most 4); relaxed agent-scope loads, a short sleep between polls.
@@ -1361,7 +1365,11 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
                 for(int c = 0; c < NCH; c++) {
                         J2P_CHK(a.ch[cbase + c], x_read[0], reinterpret_cast<const char *>(a.ch[cbase + c].xcur + roff) + xoff, 4 * PX, 101);
                         J2P_CHK(a.ch[cbase + c], x_read[1], reinterpret_cast<const char *>(a.ch[cbase + c].xprev + roff) + xoff, 4 * PX, 102);
+#ifdef J2P_EXP_FUSE_PLAINLOAD
+                        if constexpr(false) { }                  // (timing experiment: what the L1-bypassing loads cost)
+#else
                         if constexpr(FUSED) { rc[c] = buf_load_sc1<V>(res_cur[c], xoff, row_off); }
+#endif
                         else { rc[c] = buf_load<false, V>(res_cur[c], xoff, row_off); }
                         rp[c] = buf_load<false, V>(res_prev[c], xoff, row_off);
                 }
@@ -1430,7 +1438,11 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
                                 const float *prow = k.pg + (size_t)((unsigned)gt - k.crow0) * k.cw;
                                 J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + xoff, 4 * PX, 103);
                                 (void)prow;
+#ifdef J2P_EXP_FUSE_PLAINLOAD
+                                if constexpr(false) { }
+#else
                                 if constexpr(FUSED) { pv[c] = buf_load_sc1<V>(res_pg[c], xoff, (unsigned)(gt - row0 - grad_base) * k.cw * 4u); }
+#endif
                                 else { pv[c] = buf_load<(NT >= 2), V>(res_pg[c], xoff, (unsigned)(gt - row0 - grad_base) * k.cw * 4u); }
                                 continue;
                         }
@@ -2472,7 +2484,12 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh,
                 if(bcov && ly0 + rr < a.geo.rows) {
                         float4 *dst = reinterpret_cast<float4 *>(k.xprev + (size_t)(ly0 + rr) * W + bx * 8);
                         J2P_CHK(k, x_own[1], dst, 32, 212);
-                        if constexpr(FUSED) {
+#ifdef J2P_EXP_FUSE_PLAINSTORE
+                        constexpr bool kThrough = false;         // (timing experiment: what the write-through stores cost)
+#else
+                        constexpr bool kThrough = FUSED;
+#endif
+                        if constexpr(kThrough) {
                                 const __amdgpu_buffer_rsrc_t rx = rows_from(k.xprev + (size_t)ly0 * W);
                                 const unsigned off = ((unsigned)rr * W + bx * 8) * 4u;
                                 buf_store4_sc1(v[0], v[1], v[2], v[3], rx, off, 0u);
@@ -2539,7 +2556,12 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh,
                         float4 *dst = reinterpret_cast<float4 *>(k.pg + (size_t)(cy0 - k.crow0 + rr) * k.cw + bx * 8);
 #endif
                         J2P_CHK(k, pg, dst, 32, 214);
-                        if constexpr(FUSED) {
+#ifdef J2P_EXP_FUSE_PLAINSTORE
+                        constexpr bool kThroughP = false;
+#else
+                        constexpr bool kThroughP = FUSED;
+#endif
+                        if constexpr(kThroughP) {
                                 const __amdgpu_buffer_rsrc_t rpg = rows_from(k.pg + (size_t)(cy0 - k.crow0) * k.cw);
                                 const unsigned off = ((unsigned)rr * k.cw + bx * 8) * 4u;
                                 buf_store4_sc1(e[0], e[1], e[2], e[3], rpg, off, 0u);
@@ -2658,7 +2680,15 @@ __global__ __launch_bounds__(256, kGradWaves1) void k_iterate(ProjArgs pa, GradA
 {
         __shared__ IterateShared sh;
         if(threadIdx.x == 0) {
+#ifdef J2P_EXP_FUSE_STATIC
+                // (timing experiment: what claiming costs — items from blockIdx, XCD-contiguous like the two-launch kernels)
+                const bool grad = blockIdx.x >= fz.np_wg;
+                const unsigned nwg = grad ? fz.ng_wg : fz.np_wg, b = grad ? blockIdx.x - fz.np_wg : blockIdx.x;
+                const unsigned xcd = b & 7, qq = nwg >> 3, rem = nwg & 7;
+                const unsigned it = (grad ? kGradientItem : 0u) | ((xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (b >> 3));
+#else
                 const unsigned it = claim_item(fz);
+#endif
                 sh.item = it;
                 // the next launch's tickets start from zero (its launch comes after this one has ended)
                 if(it == 0u) {

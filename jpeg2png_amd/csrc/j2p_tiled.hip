@@ -547,6 +547,24 @@ void j2p_tiled_destroy(j2p_tiled *t)
                 }
         }
         const bool undrainable = t->abort.load() && t->exchange == kRccl && !(t->rccl && t->rccl->CommAbort);
+        if(t->abort.load() && t->signals) {
+                // the release has to be REPEATED until every band stream is idle: the streams still hold hipStreamWriteValue64
+                // operations of the iterations that were queued before the failure, and each of them puts a small value back
+                // over the released one (seen: the failed band's own flag fell back to its last iteration and the other
+                // band's stream sat in front of it for ever).  Finitely many are queued, every pass lets the streams get
+                // further: this terminates.
+                for(;;) {
+                        release_value_waiters(t);
+                        bool idle = true;
+                        for(Band *b : t->bands) {
+                                (void)hipSetDevice(b->device);
+                                if(b->stream && hipStreamQuery(b->stream) == hipErrorNotReady) { idle = false; }
+                        }
+                        (void)hipGetLastError();
+                        if(idle) { break; }
+                        std::this_thread::sleep_for(std::chrono::microseconds(200));
+                }
+        }
         for(Band *b : t->bands) {
                 (void)hipSetDevice(b->device);
                 if(b->stream && !undrainable) { (void)hipStreamSynchronize(b->stream); }

@@ -14,6 +14,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import jpeg2png_amd as j  # noqa: E402
 from jpeg2png_amd import synth  # noqa: E402
 
+only = None
+if "--only" in sys.argv:
+    k = sys.argv.index("--only")
+    only = sys.argv[k + 1].split(",")
+    del sys.argv[k:k + 2]
 its = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 sizes = [(512, 512), (1024, 1024), (1920, 1080), (2048, 2048), (4096, 2048), (4096, 4096)]
 if len(sys.argv) > 3:
@@ -37,10 +42,12 @@ def timed(s, reps=5):
 
 for W, H in sizes:
     planes = synth.make_planes(W, H, "444", 10, seed=1234 + 3, y_only=True)
-    out = {"plane": f"{W}x{H} Y-only Q10 -i {its}"}
+    out = {"plane": f"{W}x{H} Y-only Q10 -i {its}", "library": os.path.basename(j.LIB_PATH)}
     digests = {}
     for name, opts in (("old", "old"), ("two", {j.J2P_OPT_FUSE: 0}), ("fused", {j.J2P_OPT_FUSE: 1}),
                        ("fused_wg", {j.J2P_OPT_FUSE: 1, j.J2P_OPT_NORM_IN_PROJECT: 2})):
+        if only and name not in only:
+            continue
         with j.Solver(planes, 0.3, [0.001], its) as s:
             if opts == "old":
                 s.debug_option(j.J2P_OPT_FUSE, 0)

@@ -31,4 +31,11 @@ b)
   ( timeout 600 python -m pytest tests/test_parity_gpu.py -q -x --timeout 600 -k "schedule_switch or full_size_against or concurrent" ) > $O/r05_b_parity.log 2>&1; echo "parity subset rc=$?"; tail -5 $O/r05_b_parity.log
   timeout 600 python tools/fuse_ab.py 100 | tee $O/r05_single_launch.jsonl
   ;;
+c)
+  # what makes the single-launch iteration slow: timing-only variants (results wrong where noted), then the teardown fix
+  for v in release fuse_plainstore fuse_plainload fuse_nowait fuse_static fuse_all; do
+    if [ $v = release ]; then timeout 200 python tools/fuse_ab.py 100 1920 1080 2048 2048 4096 4096 --only old,fused; else J2P_LIBRARY=ab/libj2p_$v.so timeout 200 python tools/fuse_ab.py 100 1920 1080 2048 2048 4096 4096 --only fused; fi
+  done 2>&1 | grep '^{' | tee $O/r05_single_launch_attribution.jsonl
+  ( timeout 600 python -m pytest tests/test_tiled_verify_gpu.py -q -x --timeout 120 ) > $O/r05_c_verify_tests.log 2>&1; echo "verify tests rc=$?"; tail -12 $O/r05_c_verify_tests.log
+  ;;
 esac
