@@ -633,7 +633,7 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
             devices = list(range(n_gpus)) if n_gpus > 1 and not one_device else [local_rank] * nband
             spec = {"plane": plane_file, "W": W, "H": H, "quant": [int(q) for q in np.asarray(whole_plane.quant_table).reshape(-1)],
                     "its": its, "devices": devices, "warmup": a.warmup, "steps": a.steps, "timing_every": a.timing_every}
-            env = dict(os.environ, J2P_TILED_NORM=norm)
+            env = dict(os.environ)
             env.pop("J2P_TILED_EXCHANGE", None)
             env.pop("J2P_TILED_WAIT", None)
             if exchange:

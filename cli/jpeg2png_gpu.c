@@ -281,6 +281,14 @@ static void decode_file(const char *infile, const char *outfile, const struct op
         }
         job.separate = !o->joint;
         job.tile = o->tile;
+        {
+                /* (tests row-tile small images: the pixel gate of the library can be lowered from outside the program) */
+                const char *gate = getenv("J2P_TILE_MIN_BAND_PIXELS");
+                if(gate && *gate) {
+                        const unsigned long long v = strtoull(gate, NULL, 10);
+                        job.tile_min_band_pixels = v ? (size_t)v : (size_t)-1;
+                }
+        }
         if(o->tile && o->nfiles > 1) {
                 /* several files, still fewer than GPUs: file i gets GPUs [i n / f, (i + 1) n / f) of the list */
                 job.tile_first = index * (unsigned)o->ndev / o->nfiles;

@@ -115,8 +115,9 @@ void j2p_pool_trim(void);
                                      create and reset (environment J2P_NT_SCOPE=solver: this solver's own only) */
 #define J2P_OPT_MIXED_PROJECT 6   /* 1 (default): canvases up to 1 Mpixel project all channels in ONE launch whatever their
                                      sampling; 0: one launch per sampling class, as large canvases do */
-#define J2P_OPT_FUSE 7             /* 1: one launch per iteration — projection(k) and gradient(k + 1) in one grid, ordered by per-block-row
-                                     counters (one full-resolution channel covering a whole canvas; default up to 8 Mpixel); 0: two launches */
+#define J2P_OPT_FUSE 7             /* 1 (experiments build only; measured slower everywhere, profiles/r05_single_launch.jsonl): one launch per
+                                     iteration — projection(k) and gradient(k + 1) in one grid, ordered by per-block-row counters
+                                     (one full-resolution channel covering a whole canvas); 0 (default): two launches */
 int j2p_solver_debug_option(j2p_solver *s, int option, int value);
 
 /* The checked build (the analogue of the reference's DEBUG=1, whose pixel indexer p() asserts every access,
@@ -371,11 +372,13 @@ typedef struct j2p_job {
          * entries [tile_first, tile_first + tile_count) of the list given to j2p_batch_create (tile_count 0 = all of
          * them), so that a few large images can each have a share of the GPUs.  How many bands there are is the
          * library's decision: a band costs its GPU ~35 us per iteration of cross-band scheduling whatever its size
-         * (profiles/r03_band_alone.jsonl), so a band gets at least 2 Mpixel per channel (J2P_TILE_MIN_BAND_PIXELS
-         * overrides, tests) and at least 48 rows; an image too small for two such bands — and any image when the
-         * devices cannot be tiled over (no peer access and no RCCL) — is solved on ONE GPU instead */
+         * (profiles/r03_band_alone.jsonl), so a band gets at least 2 Mpixel per channel (tile_min_band_pixels: another
+         * gate; (size_t)-1 = none: tests with small images) and at least 48 rows; an image too small for two such bands —
+         * and any image when the devices cannot be tiled over (no peer access and no RCCL, or no exchange that verifies on
+         * them) — is solved on ONE GPU instead */
         int tile;
         unsigned tile_first, tile_count;
+        size_t tile_min_band_pixels;           /* 0 = the library's gate (2 Mpixel) */
 } j2p_job;
 int j2p_batch_create(j2p_batch **out, unsigned ndev, const int devices[], unsigned slots_per_device);
 void j2p_batch_destroy(j2p_batch *b);                       /* finishes queued jobs first */

@@ -54,7 +54,7 @@ class _CJob(ctypes.Structure):
                 ("out_bits", ctypes.c_uint), ("out_w", ctypes.c_uint), ("out_h", ctypes.c_uint),
                 ("out_rgb", ctypes.c_void_p), ("out_planes", ctypes.c_void_p * 3),
                 ("on_rows", _ROWS_CB), ("on_progress", _PROGRESS_CB), ("user", ctypes.c_void_p), ("tile", ctypes.c_int),
-                ("tile_first", ctypes.c_uint), ("tile_count", ctypes.c_uint)]
+                ("tile_first", ctypes.c_uint), ("tile_count", ctypes.c_uint), ("tile_min_band_pixels", ctypes.c_size_t)]
 
 
 class _CExchange(ctypes.Structure):
@@ -545,7 +545,7 @@ class Batch:
         self._pending = {}
 
     def submit(self, planes, weight, pweight, iterations, separate=False, width=None, height=None, bits=0, tile=False,
-               tile_devices=None):
+               tile_devices=None, tile_min_band_pixels=None):
         """tile=True: the image is row-tiled over the batch's devices instead of solved on one of them;
         tile_devices=(first, count): over that slice of the batch's device list only"""
         n = len(planes)
@@ -554,6 +554,8 @@ class Batch:
         job.tile = 1 if tile else 0
         if tile_devices:
             job.tile_first, job.tile_count = int(tile_devices[0]), int(tile_devices[1])
+        if tile_min_band_pixels is not None:           # 0 = no gate at all (tests with small images)
+            job.tile_min_band_pixels = int(tile_min_band_pixels) if tile_min_band_pixels else ctypes.c_size_t(-1).value
         cpl, keep = _c_planes(planes)
         for c in range(n):
             job.planes[c] = cpl[c]

@@ -106,6 +106,38 @@ def build_debug(force=False, verbose=False):
     return DEBUG_LIB
 
 
+EXP_LIB = os.path.join(HERE, "libjpeg2png_amd_exp.so")
+
+
+def build_experiments(force=False, verbose=False):
+    """The experiments build (-DJ2P_EXPERIMENTS, jpeg2png_amd/libjpeg2png_amd_exp.so): the release sources plus the
+    schedules that lost their measurements (one column per lane, all channels of a joint image in one wavefront, the
+    reduction as the gradient launch's last workgroup, split phases, the single-launch iteration) and the environment
+    knobs that select them (j2p_internal.h: j2p_exp_env).  What the schedule-equivalence tests load (conftest.exp_lib)
+    and the timing tools run on (J2P_LIBRARY=<this file>); never what a user of the library gets."""
+    build(force=False, verbose=verbose)             # compute_host.o is shared
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    common = [os.path.join(CSRC, f) for f in HEADERS] + [os.path.join(INCLUDE, "jpeg2png_amd.h"), os.path.abspath(__file__)]
+    # (the objects do not travel with a gpurun lease, the library does: up to date against the SOURCES is enough)
+    sources = [os.path.join(CSRC, u) for u in HIP_UNITS] + common + [os.path.join(CSRC, "compute_host.c")]
+    if not force and os.path.exists(EXP_LIB) and not _newer(EXP_LIB, sources):
+        return EXP_LIB
+    jobs, objs = [], []
+    for u in HIP_UNITS:
+        src, obj = os.path.join(CSRC, u), os.path.join(CSRC, u.replace(".hip", "_exp.o"))
+        objs.append(obj)
+        deps = [src] + (common if u == "j2p_solver.hip" else common[1:])
+        if force or _newer(obj, deps):
+            jobs.append([hipcc, *HIP_FLAGS, "-DJ2P_EXPERIMENTS", "-I", INCLUDE, "-I", CSRC, "-c", src, "-o", obj])
+    objs.append(os.path.join(CSRC, "compute_host.o"))
+    if jobs or _newer(EXP_LIB, objs):
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            list(ex.map(lambda c: _run(c, verbose), jobs))
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lpthread", "-Wl,-soname,libjpeg2png_amd_exp.so", "-o", EXP_LIB], verbose)
+    return EXP_LIB
+
+
 CLI = os.path.join(HERE, "jpeg2png_gpu")
 
 

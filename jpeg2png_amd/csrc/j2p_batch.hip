@@ -74,10 +74,9 @@ int validate_job(const j2p_job &d)
 // pixels per channel a band must at least have: the cross-band schedule costs every band ~35 us per iteration
 // whatever its size (profiles/r03_band_alone.jsonl: 276 vs 245 us for a 2048-row band of a 16384-wide plane), which
 // is more than a whole 1080p iteration takes on one GPU
-size_t tile_min_band_pixels()
+size_t tile_min_band_pixels(const j2p_job &d)
 {
-        const char *env = getenv("J2P_TILE_MIN_BAND_PIXELS");       // (per job, not per iteration)
-        return env && *env ? (size_t)strtoull(env, nullptr, 10) : (size_t)2 << 20;
+        return d.tile_min_band_pixels ? (d.tile_min_band_pixels == (size_t)-1 ? 0 : d.tile_min_band_pixels) : (size_t)2 << 20;
 }
 
 // One image over several of the batch's devices (j2p_job::tile): every solve of the job becomes a j2p_tiled with band
@@ -108,7 +107,7 @@ int run_job_tiled(const j2p_job &d, const std::vector<int> &devices, bool *handl
         unsigned per = 3 * J2P_TILE_ROWS;
         per = (per + align - 1) / align * align;
         unsigned nband = hmin / per;
-        if(tile_min_band_pixels() && pixels_min / tile_min_band_pixels() < nband) { nband = (unsigned)(pixels_min / tile_min_band_pixels()); }
+        if(tile_min_band_pixels(d) && pixels_min / tile_min_band_pixels(d) < nband) { nband = (unsigned)(pixels_min / tile_min_band_pixels(d)); }
         if(nband > devices.size()) { nband = (unsigned)devices.size(); }
         if(nband > 32) { nband = 32; }
         if(nband < 2) { return J2P_OK; }

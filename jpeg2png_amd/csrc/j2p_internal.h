@@ -1,6 +1,23 @@
 // jpeg2png_amd — declarations shared by the translation units of libjpeg2png_amd.so; not part of the C-ABI.
 #pragma once
+#include <stdlib.h>
 #include "jpeg2png_amd.h"
+
+// Environment knobs of the EXPERIMENTS build (-DJ2P_EXPERIMENTS: jpeg2png_amd/libjpeg2png_amd_exp.so, built by
+// buildlib.build_experiments() for the schedule-equivalence tests and the timing tools): schedules that measured slower
+// everywhere (one column per lane, all channels of a joint image in one wavefront, the reduction as the gradient
+// launch's last workgroup, split phases) and the switches that select them.  The release library carries neither the
+// kernels nor the switches and reads only J2P_DEVICE, J2P_DEVICES, J2P_TILED_EXCHANGE, J2P_TILED_WAIT,
+// J2P_TILED_VERIFY, J2P_RCCL_LIBRARY, J2P_POOL_MIB and J2P_COMPUTE_TIMING.
+static inline const char *j2p_exp_env(const char *name)
+{
+#ifdef J2P_EXPERIMENTS
+        return getenv(name);
+#else
+        (void)name;
+        return nullptr;
+#endif
+}
 
 // error text of the calling thread (what j2p_last_error() returns); returns `code`
 int j2p_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));

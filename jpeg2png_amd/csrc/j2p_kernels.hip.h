@@ -1680,11 +1680,15 @@ void k_gradient(GradArgs a)
         // L2 and their shared halo rows are fetched from HBM once.  Bijective for any grid size.
         unsigned bx = blockIdx.x, bseg = blockIdx.y;
         // (reduce_norm: the grid's last row of workgroups is not strips — its first workgroup reduces ||g||)
+#ifdef J2P_EXPERIMENTS
         const unsigned strip_rows = a.reduce_norm ? gridDim.y - 1 : gridDim.y;
         if(blockIdx.y == strip_rows) {
                 if(blockIdx.x == 0) { norm_reducer(a, fold_buf); }
                 return;
         }
+#else
+        const unsigned strip_rows = gridDim.y;
+#endif
         {
                 const unsigned nwg = gridDim.x * strip_rows, b = blockIdx.y * gridDim.x + blockIdx.x;
                 const unsigned xcd = b & 7, q = nwg >> 3, rem = nwg & 7;

@@ -303,9 +303,7 @@ struct Carver {
 constexpr size_t kNtWorkingSet = (size_t)260 << 20;      // see nt_policy in j2p_solver_create
 constexpr size_t kNormInProjectPixels = (size_t)5 << 19; // whole canvases up to this size (2.5 Mpixel) reduce ||g|| without a launch of its own
 constexpr size_t kMixedProjectPixels = (size_t)1 << 20;  // canvases up to this size project all channels in one launch
-// one-channel canvases up to this size iterate with ONE launch per iteration (k_iterate); above it the chip is full for the
-// whole of either phase and the second launch boundary is lost in the phases' own length
-constexpr size_t kFusePixels = (size_t)1 << 23;
+
 // whole canvases from this size on (and at most kFoldMaxRows tile rows) reduce ||g|| entirely inside k_gradient: on wide
 // planes the k_norm_whole launch stages 17 K partials through one CU (9 us at W = 16384) — 16384x2048 232.1 -> 229.4 us per
 // iteration, 8192^2 521.6 -> 511.3; at 4096^2 the launch (4.7 us) is the cheaper one, 117.6 vs 119.4
@@ -340,7 +338,7 @@ unsigned lcm_u(unsigned a, unsigned b) { return a / gcd_u(a, b) * b; }
 int nt_policy(const j2p_solver *s)
 {
         static const bool own_only = [] {
-                const char *env = getenv("J2P_NT_SCOPE");
+                const char *env = j2p_exp_env("J2P_NT_SCOPE");
                 return env && strcmp(env, "solver") == 0;
         }();
         LiveBytes l = live_on(s->device);
@@ -565,6 +563,7 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         // wavefronts at 4 per SIMD), beats all channels in one wavefront (248 VGPRs, 2 per SIMD) at every
         // size measured: 198 vs 293 us at 12 Mpixel 4:2:0, 494 vs 717 us at 36 Mpixel.  J2P_JOINT_INWAVE=1
         // selects the in-wavefront kernel (kept: it is the same arithmetic in another schedule, and tested).
+#ifdef J2P_EXPERIMENTS
         const bool inwave = s->joint_inwave;
         switch(s->nch) {
         case 1:
@@ -582,6 +581,14 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
                 else { launch_gradient_n<1, 3>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); }
                 break;
         }
+#else
+        // (release build: one wavefront per channel, two columns per lane — the schedules that won everywhere)
+        switch(s->nch) {
+        case 1: launch_gradient_n<1, 1>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); break;
+        case 2: launch_gradient_n<1, 2>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); break;
+        default: launch_gradient_n<1, 3>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); break;
+        }
+#endif
         if(part != 2) { mark(s); }
         HIP_TRY(hipGetLastError());
 #ifdef J2P_TRACE
@@ -871,6 +878,10 @@ int do_fused_step(j2p_solver *s)
         fz.g_gx = (s->ntx + 3) / 4;
         fz.ng_wg = fz.g_gx * s->nseg;
         const dim3 grid(fz.np_wg + fz.ng_wg);
+#ifndef J2P_EXPERIMENTS
+        (void)grid;
+        return fail(J2P_ESTATE, "the single-launch iteration exists in the experiments build only");
+#else
         if(s->nip_form == 2) {
                 if(s->weight != 0.f) { hipLaunchKernelGGL((k_iterate<true, 2>), grid, dim3(256), 0, s->stream, pa, ga, fz); }
                 else { hipLaunchKernelGGL((k_iterate<false, 2>), grid, dim3(256), 0, s->stream, pa, ga, fz); }
@@ -880,6 +891,7 @@ int do_fused_step(j2p_solver *s)
         }
         HIP_TRY(hipGetLastError());
         s->fuse_launches++;
+#endif
         // (state as do_phase_gradient leaves it: grad_done, the norm comes from the row sums, no logging)
         return J2P_OK;
 }
@@ -1041,13 +1053,13 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         {
                 // the one schedule switch tests reach through the environment (read once, here): all channels of a
                 // joint image inside one wavefront instead of one wavefront per channel — same bits, slower
-                const char *env = getenv("J2P_JOINT_INWAVE");
+                const char *env = j2p_exp_env("J2P_JOINT_INWAVE");
                 s->joint_inwave = env && atoi(env) != 0;
                 // ... and: one projection launch per sampling class also on small canvases (J2P_OPT_MIXED_PROJECT)
-                env = getenv("J2P_MIXED_PROJECT");
+                env = j2p_exp_env("J2P_MIXED_PROJECT");
                 if(env) { s->mixed_project = atoi(env) != 0; }
                 // ... and (A/B timing): band solvers finish ||g|| with a k_norm_finish launch instead of inside k_project
-                env = getenv("J2P_BAND_NIP");
+                env = j2p_exp_env("J2P_BAND_NIP");
                 if(env) { s->band_nip = atoi(env) != 0; }
         }
         int rc = J2P_OK;
@@ -1118,11 +1130,11 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 if(g == 8 && waves(px, g) < kShortStripWaves) { g = 4; }
                 // (timing experiments: J2P_PX = 1 / 2, J2P_RPW = 2 ... 64 for every solver of the process; band solvers take
                 // only the divisors of the band alignment, 16 — tools/rpw_fine.py sweeps the rest on whole canvases)
-                if(const char *env = getenv("J2P_PX")) {
+                if(const char *env = j2p_exp_env("J2P_PX")) {
                         const int v = atoi(env);
                         if((v == 1 && !s->joint_inwave) || v == 2) { px = (unsigned)v; }
                 }
-                if(const char *env = getenv("J2P_RPW")) {
+                if(const char *env = j2p_exp_env("J2P_RPW")) {
                         const int v = atoi(env);
                         if(v >= 2 && v <= 64 && (s->whole || kTY % v == 0)) { g = (unsigned)v; }
                 }
@@ -1134,18 +1146,15 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         s->ntr_local = s->nseg;
         s->ntr_global = (H + s->rpw - 1) / s->rpw;
         s->first_tr = row0 / s->rpw;
-        // the single-launch iteration: one full-resolution channel that covers the whole canvas, packed strips, a tree
-        // k_project's wavefronts can run themselves (NIP 1)
-#if !defined(J2P_DEBUG) && !defined(J2P_TRACE)
+        // the single-launch iteration (k_iterate, J2P_OPT_FUSE): one full-resolution channel that covers the whole canvas,
+        // packed strips, a tree k_project's wavefronts can run themselves.  Experiments build only and never the policy's
+        // choice: measured slower than two launches at every size, and slower even with its synchronisation switched off
+        // (profiles/r05_single_launch.jsonl)
+#if defined(J2P_EXPERIMENTS) && !defined(J2P_DEBUG) && !defined(J2P_TRACE)
         s->fuse_possible = whole && nchannel == 1 && planes[0].w_samp == 1 && planes[0].h_samp == 1 && s->px == 2 &&
                            s->ntr_global <= kWaveTreeMax;
 #endif
-        s->fuse = s->fuse_possible && (size_t)W * H <= kFusePixels;
-        if(s->fuse) {
-                s->fold = true;                 // level 1 of ||g|| inside the gradient part, level 2 by every projection wavefront
-                s->norm_in_project = true;
-                s->nip_form = 1;
-        }
+        s->fuse = false;
         const size_t ntiles = (size_t)s->ntx * s->ntr_local;
         unsigned max_strips = 0;
         for(unsigned c = 0; c < nchannel; c++) {
@@ -1306,11 +1315,17 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
                 }
                 // 0: reduction launch between the phases; 1: folded into k_gradient by tickets; 2 (whole canvases): the
                 // gradient launch's last workgroup reduces
+#ifndef J2P_EXPERIMENTS
+                if(value == 2) { return fail(J2P_ESTATE, "J2P_OPT_NORM_FOLD 2 (the launch's last workgroup reduces) exists in the experiments build only"); }
+#endif
                 s->fold = value == 1;
                 s->reducer = value == 2;
                 if(!s->fold) { s->fuse = false; }          // (the single-launch iteration folds: J2P_OPT_FUSE 1 turns both on again)
                 break;
         case J2P_OPT_JOINT_INWAVE:
+#ifndef J2P_EXPERIMENTS
+                if(value) { return fail(J2P_ESTATE, "J2P_OPT_JOINT_INWAVE 1 (all channels in one wavefront) exists in the experiments build only"); }
+#endif
                 if(value && s->px == 1) { return fail(J2P_ESTATE, "the in-wavefront joint kernel has no one-column-per-lane form (set J2P_JOINT_INWAVE=1 before the solver is created)"); }
                 s->joint_inwave = value != 0;
                 break;
@@ -1447,6 +1462,12 @@ int j2p_solver_phase_gradient(j2p_solver *s)
 int j2p_solver_phase_gradient_part(j2p_solver *s, int part, void *stream)
 {
         if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+        (void)stream;
+#ifndef J2P_EXPERIMENTS
+        // (measured slower than whole phases wherever tried, DESIGN.md section 10: the release build keeps the entry points, not the schedule)
+        (void)part;
+        return fail(J2P_ESTATE, "split phases exist in the experiments build only (buildlib.build_experiments)");
+#endif
         if(part != J2P_GRADIENT_INTERIOR && part != J2P_GRADIENT_EDGES) { return fail(J2P_EINVAL, "part must be J2P_GRADIENT_INTERIOR or J2P_GRADIENT_EDGES"); }
         DeviceGuard guard(s->device);
         return do_phase_gradient(s, s->log_phases, part, (hipStream_t)stream);
@@ -1469,6 +1490,11 @@ int j2p_solver_phase_project(j2p_solver *s)
 int j2p_solver_phase_project_part(j2p_solver *s, int part)
 {
         if(!s) { return fail(J2P_EINVAL, "solver is NULL"); }
+#ifndef J2P_EXPERIMENTS
+        // (measured slower than whole phases wherever tried, DESIGN.md section 10: the release build keeps the entry points, not the schedule)
+        (void)part;
+        return fail(J2P_ESTATE, "split phases exist in the experiments build only (buildlib.build_experiments)");
+#endif
         if(part != J2P_PROJECT_BOUNDARY && part != J2P_PROJECT_INTERIOR) { return fail(J2P_EINVAL, "part must be J2P_PROJECT_BOUNDARY or J2P_PROJECT_INTERIOR"); }
         DeviceGuard guard(s->device);
         return do_phase_project(s, s->log_phases, part);

@@ -646,10 +646,10 @@ int tiled_create_impl(j2p_tiled **out, unsigned nband, const int devices[], cons
         int rc = J2P_OK;
         // ---- how the bands exchange (see the head of this file): the plan names it, or the devices decide ----
         {
-                const char *env = getenv("J2P_TILED_NORM");
+                const char *env = j2p_exp_env("J2P_TILED_NORM");
                 t->norm_by_root = !(env && strcmp(env, "all") == 0);
                 t->root = 0;
-                env = getenv("J2P_TILED_SELF_NEIGHBOURS");
+                env = j2p_exp_env("J2P_TILED_SELF_NEIGHBOURS");
                 t->self_neighbours = nband == 1 && env && atoi(env) != 0;
                 if(plan.wait >= 0) { t->wait = (WaitMode)plan.wait; }
                 const int want = plan.exchange;
@@ -724,7 +724,7 @@ int tiled_create_impl(j2p_tiled **out, unsigned nband, const int devices[], cons
                 // hipEventDisableSystemFence.  Honoured ONLY when all bands share one GPU: between GPUs the system-scope
                 // release of the record is what makes a band's stores into its peers' memory visible to them)
                 unsigned evflags = hipEventDisableTiming;
-                if(const char *env = getenv("J2P_TILED_EVENT_FLAGS")) {
+                if(const char *env = j2p_exp_env("J2P_TILED_EVENT_FLAGS")) {
                         bool one_device = true;
                         for(unsigned k = 1; k < nband; k++) { one_device = one_device && devices[k] == devices[0]; }
                         if(one_device) { evflags |= (unsigned)strtoul(env, nullptr, 16); }
@@ -830,7 +830,7 @@ int tiled_create_impl(j2p_tiled **out, unsigned nband, const int devices[], cons
 // between iterations, which is where a missing release / acquire shows (a full-size band evicts its own stale lines).
 // J2P_TILED_EXCHANGE / J2P_TILED_WAIT name an exchange and skip all of this.  Devices that are listed twice share
 // caches and queues — nothing to find out — and get `direct` with event waits; J2P_TILED_VERIFY=1 runs the procedure
-// there too (tests), J2P_TILED_VERIFY=0 never runs it.
+// there too (tests; =2 also prints what was measured), J2P_TILED_VERIFY=0 never runs it.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr unsigned kVerifyIterations = 8, kVerifyTimedIterations = 24;
 std::mutex g_plan_lock;
@@ -912,7 +912,7 @@ int plan_from_environment(Plan *plan)
 
 // the plan for this device list: from the cache, or by the procedure above.  Returns J2P_OK with plan->exchange < 0 when
 // there is nothing to decide (the caller takes the defaults), an error when no exchange works on these GPUs.
-int pick_plan(unsigned nband, const int devices[], unsigned nchannel, const j2p_plane planes[], float weight, const float pweight[], Plan *plan)
+int pick_plan(unsigned nband, const int devices[], unsigned nchannel, const j2p_plane planes[], float weight, const float pweight[], bool verbose, Plan *plan)
 {
         *plan = Plan();
         const std::vector<int> key(devices, devices + nband);
@@ -1014,7 +1014,7 @@ int pick_plan(unsigned nband, const int devices[], unsigned nchannel, const j2p_
                                 reach ? "" : "; ", reach ? "" : why);
         }
         *plan = cands[(size_t)best].plan;
-        if(getenv("J2P_COMPUTE_TIMING")) {
+        if(verbose) {
                 fprintf(stderr, "jpeg2png_amd: row tiling over GPUs %s: verified per scratch iteration %s -> '%s'\n", devtext, line, cands[(size_t)best].name);
         }
         {
@@ -1062,7 +1062,7 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                         }
                         int prev = -1;
                         (void)hipGetDevice(&prev);
-                        const int rc = pick_plan(nband, devices, nchannel, planes, weight, pweight, &plan);
+                        const int rc = pick_plan(nband, devices, nchannel, planes, weight, pweight, verify >= 2, &plan);
                         if(prev >= 0) { (void)hipSetDevice(prev); }
                         if(rc != J2P_OK) { return rc; }
                 }

@@ -106,6 +106,17 @@ def lib():
     return jpeg2png_amd.load_library()
 
 
+@pytest.fixture
+def exp_lib(lib):
+    """The experiments build of the library (-DJ2P_EXPERIMENTS: the schedules that lost their measurements and the
+    environment knobs that select them) for the duration of one test: every Solver / TiledSolver / Batch created inside
+    the test comes from it.  Built on demand (it travels with the tree when __graft_entry__.build() made it)."""
+    import jpeg2png_amd
+    from jpeg2png_amd.buildlib import build_experiments
+    with jpeg2png_amd.library(build_experiments()) as l:
+        yield l
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import bindings

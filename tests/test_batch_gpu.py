@@ -104,18 +104,17 @@ def test_tiled_job_equals_single_solver_job(lib, separate, monkeypatch):
     equal the untiled job's; a canvas too short to tile falls back to the single-solver path.  (The library tiles only
     images with at least 2 Mpixel per band; the gate is lowered here so that a small image exercises the path.)"""
     import jpeg2png_amd as j
-    monkeypatch.setenv("J2P_TILE_MIN_BAND_PIXELS", "0")
     planes = make_case(152, 296, "420", 10, seed=83)
     weights, its = ([0.3, 0.1, 0.0], [12, 7, 5]) if separate else (0.3, 12)
     with j.Batch(devices=band_devices(3), slots_per_device=1) as b:
         a_f = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate))
         a_rgb = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate, width=150, height=290, bits=8))
-        t_f = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate, tile=True))
-        t_rgb = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate, width=150, height=290, bits=8, tile=True))
-        t_rgb16 = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate, width=150, height=290, bits=16, tile=True))
+        t_f = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate, tile=True, tile_min_band_pixels=0))
+        t_rgb = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate, width=150, height=290, bits=8, tile=True, tile_min_band_pixels=0))
+        t_rgb16 = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate, width=150, height=290, bits=16, tile=True, tile_min_band_pixels=0))
         a_rgb16 = b.wait(b.submit(planes, weights, [0.001] * 3, its, separate=separate, width=150, height=290, bits=16))
         short = make_case(64, 48, "444", 20, seed=3)
-        s_t = b.wait(b.submit(short, 0.3, [0.001] * 3, 4, tile=True))
+        s_t = b.wait(b.submit(short, 0.3, [0.001] * 3, 4, tile=True, tile_min_band_pixels=0))
         s_a = b.wait(b.submit(short, 0.3, [0.001] * 3, 4))
     for c in range(3):
         assert bit_equal(t_f[c], a_f[c]), f"channel {c}"
@@ -133,10 +132,9 @@ def test_tile_gate_and_device_shares(lib, monkeypatch):
     with j.Batch(devices=band_devices(4), slots_per_device=1) as b:
         plain = b.wait(b.submit(planes, 0.3, [0.001] * 3, 6))
         gated = b.wait(b.submit(planes, 0.3, [0.001] * 3, 6, tile=True, tile_devices=(2, 2)))       # too small: untiled
-        monkeypatch.setenv("J2P_TILE_MIN_BAND_PIXELS", "0")
-        share = b.wait(b.submit(planes, 0.3, [0.001] * 3, 6, tile=True, tile_devices=(1, 2)))       # two bands
+        share = b.wait(b.submit(planes, 0.3, [0.001] * 3, 6, tile=True, tile_devices=(1, 2), tile_min_band_pixels=0))       # two bands
         with pytest.raises(j.J2PError, match="tile devices"):
-            b.wait(b.submit(planes, 0.3, [0.001] * 3, 6, tile=True, tile_devices=(3, 2)))
+            b.wait(b.submit(planes, 0.3, [0.001] * 3, 6, tile=True, tile_devices=(3, 2), tile_min_band_pixels=0))
         with pytest.raises(j.J2PError, match="out_bits"):
             b.wait(b.submit(planes, 0.3, [0.001] * 3, 6, tile=True, width=150, height=290, bits=12))
     for c in range(3):

@@ -300,7 +300,7 @@ def test_drop_in_compute_dies_like_the_reference(lib, tmp_path):
     assert r.stderr.startswith("jpeg2png: ")
 
 
-def test_tiled_engine_on_one_gpu(lib, oracle):
+def test_tiled_engine_on_one_gpu(exp_lib, oracle):
     """the row-tiling driver's HIP engine: device memory aliased as torch tensors, two bands on
     one GPU exchanging halos / partials through those tensors, and a world-size-1 RCCL group
     driving RowTiledSolver end to end.  Both must reproduce the whole-canvas solver bit for bit."""
@@ -509,7 +509,7 @@ def test_out_of_range_operands_take_the_ieee_path(lib, oracle):
         np.testing.assert_allclose(got_log, want_log, rtol=1e-9, atol=1e-9)
 
 
-def test_noise_around_zero_takes_the_ieee_path(lib, oracle, monkeypatch):
+def test_noise_around_zero_takes_the_ieee_path(exp_lib, oracle, monkeypatch):
     """all-zero coefficient blocks (a flat grey area: chroma 0) leave rounding noise of 1e-17 and
     below around 0 for the first iterations — far under the 2^-20 the short division / sqrt
     sequences are screened for, down to values whose squares are subnormal.  Such rows must take
@@ -547,7 +547,7 @@ def test_noise_around_zero_takes_the_ieee_path(lib, oracle, monkeypatch):
             assert bit_equal(got[0].fdata, want1[0]), f"its {its} separate channel {c}"
 
 
-def test_both_joint_modes_agree(lib, oracle, monkeypatch):
+def test_both_joint_modes_agree(exp_lib, oracle, monkeypatch):
     """channels-in-one-wavefront and one-wavefront-per-channel gradient kernels are two schedules of
     the same arithmetic"""
     import jpeg2png_amd as j
@@ -562,7 +562,7 @@ def test_both_joint_modes_agree(lib, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("shape", [(520, 136, "420", False), (1000, 96, "444", True), (264, 200, "422", False)])
-def test_every_schedule_switch_leaves_the_bits_alone(lib, oracle, shape, monkeypatch):
+def test_every_schedule_switch_leaves_the_bits_alone(exp_lib, oracle, shape, monkeypatch):
     """the J2P_OPT_* switches select schedules of the same arithmetic (where the norm is reduced, whether g is
     streamed non-temporally, one projection launch or one per sampling class), J2P_PX / J2P_RPW the geometry of the
     gradient strips (one or two columns per lane, rows per strip): every combination the solver can pick by itself —
@@ -814,6 +814,9 @@ def test_two_channel_joint_against_the_compiled_reference(lib, oracle, inwave):
     import subprocess
     import sys
     env = dict(os.environ, J2P_JOINT_INWAVE=inwave)
+    if inwave == "1":               # that schedule lives in the experiments build
+        from jpeg2png_amd.buildlib import build_experiments
+        env["J2P_LIBRARY"] = build_experiments()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "two_channel.py")], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]

@@ -148,7 +148,7 @@ def test_unlogged_then_logged_runs_report_nan_for_the_unknown_distance(lib):
 
 
 @pytest.mark.parametrize("exchange,norm", [("direct", "root"), ("copy", "root"), ("copy", "all")])
-def test_every_schedule_of_the_tiling_gives_the_same_bits(lib, exchange, norm, monkeypatch):
+def test_every_schedule_of_the_tiling_gives_the_same_bits(exp_lib, exchange, norm, monkeypatch):
     """the exchanges riding on the phase kernels as peer writes (direct: two launches per band and iteration, the
     default) or round 3's copy kernel + one band reducing ||g|| for all / every band for itself (copy;
     J2P_TILED_NORM=all): the same tree over the same array and the same kernels on the same rows, so the same planes
@@ -231,7 +231,7 @@ def test_tall_narrow_canvas_falls_back_to_the_copy_exchange(lib):
         assert bit_equal(t.download(0), want[0])
 
 
-def test_rccl_exchange_with_one_band_as_its_own_neighbour(lib, monkeypatch):
+def test_rccl_exchange_with_one_band_as_its_own_neighbour(exp_lib, monkeypatch):
     """the RCCL transport of the C engine on ONE GPU: one band (RCCL wants a GPU per rank), driven through the band
     machinery — ncclCommInitAll, ncclAllGather of its row sums, grouped ncclSend / ncclRecv of its edge rows to
     itself (they land above / below the image, where the kernels mask) — against the plain whole-canvas solver,

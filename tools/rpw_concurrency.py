@@ -7,6 +7,10 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# (the switches this tool turns live in the experiments build of the library)
+if "J2P_LIBRARY" not in os.environ:
+    from jpeg2png_amd.buildlib import build_experiments
+    os.environ["J2P_LIBRARY"] = build_experiments()
 import jpeg2png_amd as j            # noqa: E402
 from jpeg2png_amd import synth      # noqa: E402
 

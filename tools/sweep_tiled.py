@@ -11,6 +11,10 @@ import numpy as np
 
 sys.path.insert(0, ".")
 sys.path.insert(0, "tests")
+# (the switches this tool turns live in the experiments build of the library)
+if "J2P_LIBRARY" not in os.environ:
+    from jpeg2png_amd.buildlib import build_experiments
+    os.environ["J2P_LIBRARY"] = build_experiments()
 import jpeg2png_amd as j
 from jpeg2png_amd import tiled
 from sweep_cases import cases

@@ -1,5 +1,6 @@
 """nchannel == 2 (allowed by compute.c:118, never used by the CLI) against the compiled reference"""
 import copy
+import os
 import sys
 
 import numpy as np
