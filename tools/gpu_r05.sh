@@ -38,4 +38,14 @@ c)
   done 2>&1 | grep '^{' | tee $O/r05_single_launch_attribution.jsonl
   ( timeout 600 python -m pytest tests/test_tiled_verify_gpu.py -q -x --timeout 120 ) > $O/r05_c_verify_tests.log 2>&1; echo "verify tests rc=$?"; tail -12 $O/r05_c_verify_tests.log
   ;;
+d)
+  # the whole GPU suite on the pruned release library (+ experiments build for the schedule tests), smoke, then A/B: five wavefronts per SIMD
+  ( timeout 1500 python -m pytest tests -m gpu -q --durations=6 --timeout 900 ) > $O/r05_d_suite.log 2>&1; echo "suite rc=$?"; tail -40 $O/r05_d_suite.log
+  ( timeout 300 python __graft_entry__.py --smoke ) 2>&1 | tail -1
+  for rep in 1 2; do
+    for v in base waves5_ring3 ring3; do
+      if [ $v = base ]; then $BENCH 2>/dev/null | line | brief $v; else J2P_LIBRARY=ab/libj2p_$v.so $BENCH 2>/dev/null | line | brief $v; fi
+    done
+  done | tee $O/r05_ab_waves5.jsonl
+  ;;
 esac
