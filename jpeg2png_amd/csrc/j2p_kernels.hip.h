@@ -1243,6 +1243,16 @@ __device__ __forceinline__ void norm_reducer(const GradArgs &a, double *buf)
 #define J2P_GRAD_WAVES 4
 #endif
 constexpr int kGradWaves1 = J2P_GRAD_WAVES;    // waves per SIMD the 1-channel gradient kernel is register-limited to (5 needs <= 96 VGPRs: spills)
+// ... except the hot instantiation — one channel per workgroup wavefront, no logging (Y-only planes, the components of `-s`):
+// with a ring of three row slots it fits 96 registers without a spill, i.e. five wavefronts per SIMD (round 5; the same
+// ring at four wavefronts and either ring in the joint / logging kernels do not: 20-56 bytes of scratch)
+#ifndef J2P_HOT_WAVES
+#define J2P_HOT_WAVES 4
+#endif
+#ifndef J2P_HOT_RING
+#define J2P_HOT_RING 4
+#endif
+constexpr int kHotWaves = J2P_HOT_WAVES, kHotRing = J2P_HOT_RING;
 constexpr int kGradWaves3 = 2;    // ... the three-channels-in-one-wavefront schedule
 // NCH channels are handled inside one wavefront (J == 1, workgroup = 4 strips), or — for a
 // jointly optimised image — J wavefronts of a workgroup take one channel each of the same strip
@@ -1474,7 +1484,7 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
         for(int c = 0; c < NCH; c++) { g2[c] = 0.; }
         const size_t ntiles_row = a.geo.ntx;
         const size_t nparts = (size_t)((rows + (int)a.geo.rpw - 1) / (int)a.geo.rpw) * ntiles_row;
-        constexpr int R = NCH == 1 ? kRing : 3;
+        constexpr int R = NCH == 1 ? (J == 1 && !LOG && PX == 2 ? kHotRing : kRing) : 3;
 
         // The march over the strip's rows, compiled twice: once general, once for strips that touch neither an
         // image edge, a band edge nor a channel's coverage limit (all but the outermost strips and segments).
@@ -1667,7 +1677,7 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
 __device__ __forceinline__ unsigned chunk_base(unsigned n, unsigned q) { return q * (n >> 3) + (q < (n & 7) ? q : (n & 7)); }
 
 template <int NCH, bool TGV, bool LOG, int J = 1, int NT = 0, int PX = 2>
-__global__ __launch_bounds__((J == 1 ? 256 : 64 * J), (PX == 1 ? (J == 1 && !LOG ? 6 : 2) : NCH == 1 ? kGradWaves1 : NCH == 2 ? 3 : kGradWaves3))
+__global__ __launch_bounds__((J == 1 ? 256 : 64 * J), (PX == 1 ? (J == 1 && !LOG ? 6 : 2) : NCH == 1 ? (J == 1 && !LOG ? kHotWaves : kGradWaves1) : NCH == 2 ? 3 : kGradWaves3))
 void k_gradient(GradArgs a)
 {
         static_assert(J == 1 || NCH == 1, "channel-per-wavefront mode keeps one channel per wavefront");

@@ -48,4 +48,18 @@ d)
     done
   done | tee $O/r05_ab_waves5.jsonl
   ;;
+e)
+  # the two tests the prune broke, then five wavefronts per SIMD for the hot gradient kernel by size (same box, alternating)
+  ( timeout 900 python -m pytest tests/test_tiled_verify_gpu.py tests/test_parity_gpu.py -q --timeout 600 -k "picker or broken or randomised_band_splits" ) > $O/r05_e_tests.log 2>&1; echo "tests rc=$?"; tail -6 $O/r05_e_tests.log
+  for sz in "1920 1080" "2048 2048" "4096 4096" "16384 2048"; do
+    set -- $sz
+    for v in base hot5 base hot5; do
+      L=""; [ $v = hot5 ] && L=ab/libj2p_hot5.so
+      ( J2P_LIBRARY=$L timeout 200 python bench.py --size $1 --height $2 --iterations 100 --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-host-to-host ) 2>/dev/null | line | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print(json.dumps({'plane': '$1x$2', 'variant': '$v', 'us_per_iteration': round(r['iteration_ms']*1e3,2), 'k_gradient_us': round(r['per_kernel']['k_gradient']['avg_launch_ms']*1e3,1)}))"
+    done
+  done | tee $O/r05_ab_hot5_by_size.jsonl
+  ;;
 esac
