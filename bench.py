@@ -348,14 +348,16 @@ def host_to_host(j, planes, its, resident_ms, device=0, reps=5):
     return {"ms_per_call": round(med, 3), "ms_per_call_all": [round(x, 3) for x in ms], "resident_ms_per_solve": round(resident_ms, 3),
             "boundary_ms": round(med - resident_ms, 3), "upload_bytes": up, "download_bytes": down,
             "split_ms": split_ms,
-            "split_about": "j2p_compute_timing() per call, median and max over the calls: create = upload + aux_init (compute.c:278-310), issue = "
-                           "queueing the loop, wait = until the last iteration has finished, download (compute.c:455-461), destroy; housekeeping "
-                           "(output pages, freeing the inputs) runs on a helper thread beside issue + wait and is not part of the sum",
+            "split_about": "j2p_compute_timing() per call, median and max over the calls: create = upload + aux_init (compute.c:278-310) with the "
+                           "output planes allocated and touched beside it on helper threads (housekeeping: how long that took; create ends when "
+                           "both are done), issue = queueing the loop, wait = until the last iteration has finished, download (compute.c:455-461), "
+                           "destroy = freeing the inputs + the solver.  Nothing maps, unmaps or faults host memory while the loop runs: doing so "
+                           "stalls one launch of the loop 12-16 ms (profiles/r05_host_to_host.jsonl)",
             "Mpx_it_per_s": round(px * its / (med * 1e-3) / 1e6, 1),
             "what": "j2p_compute() (the C drop-in behind compute(), compute.h:8) from libc-allocated pageable planes: upload of the "
                     "int16 coefficients and the decoded float plane, aux_init, all iterations, download into a newly allocated "
-                    "plane; the whole iteration loop is queued at once and the input planes are freed / the output pages touched by a helper "
-                    "thread while the GPU iterates (compute_host.c)"}
+                    "plane; the output pages are touched beside the upload, the whole iteration loop is queued at once, the input planes "
+                    "are freed behind the download (compute_host.c)"}
 
 
 def bench_batch(a, j, synth):

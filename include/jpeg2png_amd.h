@@ -259,18 +259,24 @@ int j2p_solver_link_bands(j2p_solver *s, const j2p_band_links *links);   /* NULL
  * lcm(16, 8 * h_samp), or NULL for near-equal bands.  run / sync / download mirror the j2p_solver calls; the
  * planes are bit-identical to a whole-canvas solver's whatever the cut.  (Reference loop: compute.c:427-453.)
  * nband == 1 is a plain whole-canvas solver behind the same calls.  How the bands exchange their row sums of g^2 and
- * their edge rows is chosen at create time (j2p_tiled_exchange() names it; environment J2P_TILED_EXCHANGE forces one):
- *   "direct" (default where every GPU can write every other's memory): both exchanges ride on the two phase kernels
+ * their edge rows is chosen at create time (j2p_tiled_exchange() names it).  Environment J2P_TILED_EXCHANGE / J2P_TILED_WAIT
+ * NAME one (then nothing else is tried and a failure is an error).  Unnamed, and with every band on a GPU of its own, the
+ * first create on a device list VERIFIES the candidates there: a scratch canvas cut from the job's first rows (three
+ * 16-row tile rows per band) is solved whole by one plain solver — no exchange: the truth — and as bands through each
+ * candidate; a candidate whose planes differ in one bit is demoted (one line on stderr), the fastest of the rest is kept
+ * for that device list for the life of the process (J2P_TILED_VERIFY=0: never; =1: also when bands share a GPU; =2: also
+ * print the timings).  Bands that share a GPU get "direct" with event waits.  The exchanges:
+ *   "direct" (needs every GPU to be able to write every other's memory): both exchanges ride on the two phase kernels
  *            as posted peer writes (j2p_solver_link_bands) — two launches per band and iteration; J2P_TILED_WAIT=all
  *            (default) | root | collector | counter: how a band's projection learns that every band's gradient has
  *            finished (events, or — counter — a value in host memory the kernels count up, hipStreamWaitValue64);
  *   "copy"   round 3's schedule — a copy kernel pulls the neighbours' edge rows, one band reduces ||g|| for all
  *            (J2P_TILED_NORM=all: every band for itself) — kept as the cross-check of "direct" and for canvases taller
  *            than 16384 rows;
- *   "rccl"   (default without peer access) ncclAllGather + grouped ncclSend / ncclRecv on the band's own stream, one
+ *   "rccl"   (the candidate without peer access) ncclAllGather + grouped ncclSend / ncclRecv on the band's own stream, one
  *            communicator per band from ncclCommInitAll, librccl loaded with dlopen (J2P_RCCL_LIBRARY names another
  *            copy); needs one GPU per band.
- * J2P_EDEVICE when none of them can work on the devices given.  host_cpu_seconds: user + system time the band
+ * J2P_EDEVICE when none of them works — or verifies — on the devices given.  host_cpu_seconds: user + system time the band
  * threads have spent issuing work so far. */
 typedef struct j2p_tiled j2p_tiled;
 int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const unsigned cuts[], unsigned nchannel,

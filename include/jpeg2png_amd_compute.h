@@ -70,17 +70,16 @@ void compute(unsigned nchannel, struct coef coefs[], struct logger *log, struct 
              float weight, float pweight[], unsigned iterations);
 
 /* same, with an explicit device and an error code instead of exit(); 0 on success.
- * On an error return the caller still owns its inputs: coefs[c].fdata (and w / h) are untouched unless the failure came
- * AFTER every iteration had been queued on the device — the final synchronisation or the download, i.e. a device fault —
- * in which case the input planes have already been released, as compute.c:304-305 does at aux_init, and fdata is NULL. */
+ * On ANY error return the caller still owns its inputs: coefs[c].fdata, w and h are untouched (the inputs are released
+ * only behind a successful download), so the call can be retried — on another device, for instance. */
 int j2p_compute(int device, unsigned nchannel, struct coef coefs[], struct logger *log,
                 struct progressbar *pb, float weight, const float pweight[], unsigned iterations);
 
 /* where the wall time of the calling thread's last successful compute() / j2p_compute() / j2p_compute_tiled() went (ms):
- * create = upload + aux_init (compute.c:278-310), issue = queueing the iteration loop, housekeeping = preparing the output
- * planes and freeing the inputs on a helper thread BESIDE the loop (not part of the sum), wait = until the last iteration
- * has finished, download (compute.c:455-461), destroy; total = create + issue + wait + download + destroy.
- * J2P_ESTATE when the thread has no successful call behind it. */
+ * create = upload + aux_init (compute.c:278-310) — beside it, on helper threads, the output planes are allocated and their
+ * pages touched (housekeeping: how long that took; create ends when both are done) —, issue = queueing the iteration loop,
+ * wait = until the last iteration has finished, download (compute.c:455-461), destroy = freeing the inputs and the solver;
+ * total = create + issue + wait + download + destroy.  J2P_ESTATE when the thread has no successful call behind it. */
 typedef struct j2p_compute_times {
         double create_ms, issue_ms, housekeeping_ms, wait_ms, download_ms, destroy_ms, total_ms;
 } j2p_compute_times;

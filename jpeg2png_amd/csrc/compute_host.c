@@ -58,61 +58,65 @@ int j2p_compute_timing(j2p_compute_times *out)
         return J2P_OK;
 }
 
-/* What the host owes the caller besides the solve, done by a helper thread while the GPU iterates: the planes compute()
- * hands back (compute.c:455-461) are allocated and their pages touched, so that the download at the end writes into
- * mapped memory, and the input planes are freed (aux_init frees them as soon as they are up-sampled, compute.c:304-305 —
- * they are on the device since create).  In line, between two chunks of iterations, those ~12 ms for a 64 MiB plane left
- * the GPU idle: it runs 32 iterations in 4.
- * The inputs go only once the main thread says so (`verdict`): after EVERY iteration has been queued without an error —
- * a call that fails before that returns with coefs[c].fdata untouched, so that the caller of j2p_compute() can retry,
- * on another device for instance (tests/test_capi_gpu.py). */
+/* What the host owes the caller besides the solve: the planes compute() hands back (compute.c:455-461) allocated with
+ * their pages in place, so that the download writes into mapped memory (faulted in by the download itself, 64 MiB cost
+ * 12 ms), and the input planes freed (compute.c:304-305).
+ * WHEN it does so is dictated by a measurement (round 5, profiles/r05_host_to_host.jsonl): a change to the process's address
+ * space — mmap, munmap, the page faults of a first touch — WHILE the solver's kernels run makes one launch of the loop take
+ * 12-16 ms instead of 53 us (rocprofv3: one k_gradient per call; the GPU waits, not the host), in processes that have
+ * solved before: 80-98 instead of 66 ms per 4096^2 call, whichever thread does it.  So none of it happens while the loop
+ * runs: the output planes are prepared by helper threads BESIDE THE UPLOAD (create), the loop is issued when they are
+ * done, and the inputs are freed behind the download — which also means a call that fails returns with the caller's
+ * planes untouched, whatever failed (tests/test_fineprint_gpu.py). */
+#define J2P_TOUCHERS 4u
+struct toucher {
+        char *base;
+        size_t bytes;
+};
+static void *toucher_main(void *arg)
+{
+        const struct toucher *t = arg;
+        for(size_t off = 0; off < t->bytes; off += 4096) { ((volatile char *)t->base)[off] = 0; }
+        return NULL;
+}
+
 struct housekeeping {
         unsigned nchannel;
-        struct coef *coefs;
         size_t out_bytes;
         float *out[J2P_MAX_CHANNELS];
         int failed;
         double ms;
-        pthread_mutex_t lock;
-        pthread_cond_t cv;
-        int verdict;               /* 0: undecided, 1: the loop is queued, free the inputs, -1: keep them */
 };
-
-static void housekeeping_outputs(struct housekeeping *h)
-{
-        for(unsigned c = 0; c < h->nchannel; c++) {
-                /* alloc_simd (utils.h:89-98) is aligned_alloc(16, ...); 2 MiB alignment + MADV_HUGEPAGE lets a kernel with
-                 * transparent huge pages map the plane with 32 faults per 64 MiB instead of 16384 (free() takes either) */
-                const size_t big = (size_t)2 << 20;
-                h->out[c] = h->out_bytes >= 4 * big ? aligned_alloc(big, (h->out_bytes + big - 1) & ~(big - 1)) : aligned_alloc(16, h->out_bytes);
-                if(!h->out[c]) { h->failed = 1; continue; }
-#ifdef MADV_HUGEPAGE
-                if(h->out_bytes >= 4 * big) { (void)madvise(h->out[c], h->out_bytes, MADV_HUGEPAGE); }
-#endif
-                for(size_t off = 0; off < h->out_bytes; off += 4096) { ((volatile char *)h->out[c])[off] = 0; }
-        }
-}
-
-static void housekeeping_inputs(struct housekeeping *h)
-{
-        for(unsigned c = 0; c < h->nchannel; c++) {
-                free(h->coefs[c].fdata);                                           /* compute.c:304-305 */
-                h->coefs[c].fdata = NULL;
-        }
-}
 
 static void *housekeeping_main(void *arg)
 {
         struct housekeeping *h = arg;
         const double t0 = now_ms();
-        housekeeping_outputs(h);
-        pthread_mutex_lock(&h->lock);
-        while(h->verdict == 0) { pthread_cond_wait(&h->cv, &h->lock); }
-        const int go = h->verdict > 0 && !h->failed;
-        pthread_mutex_unlock(&h->lock);
-        const double t1 = now_ms();
-        if(go) { housekeeping_inputs(h); }
-        h->ms = (t1 - t0) + (now_ms() - t1);        /* (the time spent waiting for the verdict is the main thread's) */
+        const size_t page = 4096;
+        for(unsigned c = 0; c < h->nchannel; c++) {
+                /* alloc_simd (utils.h:89-98) is aligned_alloc(16, ...); page-aligned here, and kept out of transparent huge
+                 * pages (a huge-page fault next to pinned user pages is the most expensive form of the effect above) */
+                h->out[c] = aligned_alloc(page, (h->out_bytes + page - 1) & ~(page - 1));
+                if(!h->out[c]) { h->failed = 1; continue; }
+#ifdef MADV_NOHUGEPAGE
+                (void)madvise(h->out[c], h->out_bytes, MADV_NOHUGEPAGE);
+#endif
+                /* first touch, split over a few threads (page faults of one address space scale that far) */
+                pthread_t th[J2P_TOUCHERS];
+                struct toucher part[J2P_TOUCHERS];
+                unsigned started = 0;
+                const size_t slice = ((h->out_bytes / J2P_TOUCHERS) + page - 1) & ~(page - 1);
+                for(unsigned k = 0; k < J2P_TOUCHERS; k++) {
+                        const size_t lo = (size_t)k * slice;
+                        if(lo >= h->out_bytes) { break; }
+                        part[k].base = (char *)h->out[c] + lo;
+                        part[k].bytes = h->out_bytes - lo < slice ? h->out_bytes - lo : slice;
+                        if(k + 1 < J2P_TOUCHERS && h->out_bytes > (size_t)8 << 20 && pthread_create(&th[started], NULL, toucher_main, &part[k]) == 0) { started++; }
+                        else { toucher_main(&part[k]); }
+                }
+                for(unsigned k = 0; k < started; k++) { pthread_join(th[k], NULL); }
+        }
+        h->ms = now_ms() - t0;
         return NULL;
 }
 
@@ -125,6 +129,7 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
         last_times_valid = 0;
         if(nchannel == 0 || nchannel > J2P_MAX_CHANNELS || !coefs || !pweight || !devices || nband == 0) { return J2P_EINVAL; }
         j2p_plane planes[J2P_MAX_CHANNELS];
+        unsigned W = 0, H = 0;
         for(unsigned c = 0; c < nchannel; c++) {
                 planes[c].w = coefs[c].w;
                 planes[c].h = coefs[c].h;
@@ -133,14 +138,25 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
                 planes[c].data = coefs[c].data;
                 planes[c].fdata = coefs[c].fdata;
                 planes[c].quant_table = coefs[c].quant_table;
+                if(coefs[c].w * coefs[c].w_samp > W) { W = coefs[c].w * coefs[c].w_samp; }     /* compute.c:410-416 */
+                if(coefs[c].h * coefs[c].h_samp > H) { H = coefs[c].h * coefs[c].h_samp; }
         }
         j2p_solver *s = NULL;
         j2p_tiled *t = NULL;
         int rc;
         const char *timing_env = getenv("J2P_COMPUTE_TIMING");
         const int timing = timing_env && atoi(timing_env) != 0;
-        double t_mark[6] = {0., 0., 0., 0., 0., 0.}, t_house = 0.;
+        double t_mark[6] = {0., 0., 0., 0., 0., 0.};
         t_mark[0] = now_ms();
+        /* the output planes, beside the upload */
+        struct housekeeping hk;
+        hk.nchannel = nchannel;
+        hk.out_bytes = (sizeof(float) * (size_t)W * H + 15) & ~(size_t)15;
+        hk.failed = 0;
+        hk.ms = 0.;
+        for(unsigned c = 0; c < J2P_MAX_CHANNELS; c++) { hk.out[c] = NULL; }
+        pthread_t hk_thread;
+        const int hk_started = W && H && pthread_create(&hk_thread, NULL, housekeeping_main, &hk) == 0;
         if(nband > 1) {
                 rc = j2p_tiled_create(&t, nband, devices, NULL, nchannel, planes, weight, pweight, iterations);
                 if((rc == J2P_EDEVICE || rc == J2P_ENOMEM) && !j2p_tiled_exchange_forced()) {
@@ -154,24 +170,18 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
                 j2p_band whole = {0, 0};
                 rc = j2p_solver_create(&s, devices[0], NULL, nchannel, planes, weight, pweight, iterations, whole, 0);
         }
-        if(rc != J2P_OK) { return rc; }
-        t_mark[1] = now_ms();
+        if(hk_started) { pthread_join(hk_thread, NULL); } else if(W && H) { housekeeping_main(&hk); }
+        float **outp = hk.out;
+        if(rc == J2P_OK && hk.failed) { j2p_set_last_error("out of host memory for the output planes"); rc = J2P_ENOMEM; }
+        t_mark[1] = t_mark[2] = t_mark[3] = now_ms();
+        if(rc != J2P_OK) { goto out; }
+        {
+                unsigned cw = 0, ch = 0;
+                if(t) { j2p_tiled_canvas(t, &cw, &ch, NULL); } else { j2p_solver_canvas(s, &cw, &ch); }
+                if(cw != W || ch != H) { j2p_set_last_error("canvas size mismatch between the host and the solver"); rc = J2P_ESTATE; goto out; }
+        }
         const int want_log = log && log->f && logger_log;
         j2p_log_row rows[J2P_CHUNK];
-        unsigned W = 0, H = 0;
-        if(t) { j2p_tiled_canvas(t, &W, &H, NULL); } else { j2p_solver_canvas(s, &W, &H); }
-        struct housekeeping hk;
-        hk.nchannel = nchannel;
-        hk.coefs = coefs;
-        hk.out_bytes = (sizeof(float) * (size_t)W * H + 15) & ~(size_t)15;
-        hk.failed = 0;
-        hk.ms = 0.;
-        hk.verdict = 0;
-        pthread_mutex_init(&hk.lock, NULL);
-        pthread_cond_init(&hk.cv, NULL);
-        for(unsigned c = 0; c < J2P_MAX_CHANNELS; c++) { hk.out[c] = NULL; }
-        pthread_t hk_thread;
-        const int hk_started = pthread_create(&hk_thread, NULL, housekeeping_main, &hk) == 0;
         unsigned done = 0;
         while(done < iterations) {
                 unsigned n = iterations - done;
@@ -191,27 +201,7 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
                 }
                 done += n;
         }
-        /* every iteration is queued (or one failed): the inputs may go (or stay) */
-        if(hk_started) {
-                pthread_mutex_lock(&hk.lock);
-                hk.verdict = rc == J2P_OK ? 1 : -1;
-                pthread_cond_signal(&hk.cv);
-                pthread_mutex_unlock(&hk.lock);
-                t_mark[2] = now_ms();
-                pthread_join(hk_thread, NULL);
-        } else {
-                t_mark[2] = now_ms();
-                const double h0 = now_ms();
-                housekeeping_outputs(&hk);
-                if(rc == J2P_OK && !hk.failed) { housekeeping_inputs(&hk); }
-                hk.ms = now_ms() - h0;
-        }
-        pthread_mutex_destroy(&hk.lock);
-        pthread_cond_destroy(&hk.cv);
-        t_house = hk.ms;
-        float **outp = hk.out;
-        if(rc == J2P_OK && hk.failed) { j2p_set_last_error("out of host memory for the output planes"); rc = J2P_ENOMEM; }
-        t_mark[3] = t_mark[2];
+        t_mark[2] = t_mark[3] = now_ms();
         if(rc != J2P_OK) { goto out; }
         rc = t ? j2p_tiled_sync(t) : j2p_solver_sync(s);
         if(rc != J2P_OK) { goto out; }
@@ -220,14 +210,18 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
                 rc = t ? j2p_tiled_download(t, c, outp[c]) : j2p_solver_download(s, c, outp[c]);
                 if(rc != J2P_OK) { goto out; }
         }
+        t_mark[4] = now_ms();
+        /* everything has succeeded: the inputs go (compute.c:304-305 frees them at aux_init; here nothing frees memory
+         * while kernels run, see above) and the new planes change hands */
         for(unsigned c = 0; c < nchannel; c++) {
+                free(coefs[c].fdata);
                 coefs[c].fdata = outp[c];                                          /* compute.c:458 */
                 outp[c] = NULL;
                 coefs[c].w = W;                                                    /* compute.c:459-460 */
                 coefs[c].h = H;
         }
 out:
-        t_mark[4] = now_ms();
+        if(rc != J2P_OK) { t_mark[4] = now_ms(); }
         for(unsigned c = 0; c < nchannel; c++) { free(hk.out[c]); }
         if(t) { j2p_tiled_destroy(t); }
         if(s) { j2p_solver_destroy(s); }
@@ -235,15 +229,15 @@ out:
         if(rc == J2P_OK) {
                 last_times.create_ms = t_mark[1] - t_mark[0];
                 last_times.issue_ms = t_mark[2] - t_mark[1];
-                last_times.housekeeping_ms = t_house;
+                last_times.housekeeping_ms = hk.ms;
                 last_times.wait_ms = t_mark[3] - t_mark[2];
                 last_times.download_ms = t_mark[4] - t_mark[3];
                 last_times.destroy_ms = t_mark[5] - t_mark[4];
                 last_times.total_ms = t_mark[5] - t_mark[0];
                 last_times_valid = 1;
                 if(timing) {
-                        fprintf(stderr, "j2p compute timing (ms): create %.2f, issue %.2f (beside it, on a helper thread: housekeeping %.2f), wait %.2f, download %.2f, destroy %.2f, total %.2f\n",
-                                last_times.create_ms, last_times.issue_ms, t_house, last_times.wait_ms, last_times.download_ms,
+                        fprintf(stderr, "j2p compute timing (ms): create %.2f (upload + aux_init; beside it the output planes: %.2f), issue %.2f, wait %.2f, download %.2f, free + destroy %.2f, total %.2f\n",
+                                last_times.create_ms, hk.ms, last_times.issue_ms, last_times.wait_ms, last_times.download_ms,
                                 last_times.destroy_ms, last_times.total_ms);
                 }
         }

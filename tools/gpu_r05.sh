@@ -62,4 +62,53 @@ print(json.dumps({'plane': '$1x$2', 'variant': '$v', 'us_per_iteration': round(r
     done
   done | tee $O/r05_ab_hot5_by_size.jsonl
   ;;
+f)
+  # why host-to-host went from 66 to 98 ms: the split per call — as is, without the huge-page output planes, without the arena pool;
+  # then the kernels of that path under rocprofv3
+  timeout 200 python tools/h2h_probe.py 5 2>/dev/null | tee $O/r05_h2h_probe.jsonl
+  J2P_LIBRARY=ab/libj2p_nohuge.so timeout 200 python tools/h2h_probe.py 5 2>/dev/null | tee -a $O/r05_h2h_probe.jsonl
+  J2P_POOL_MIB=0 timeout 200 python tools/h2h_probe.py 4 2>/dev/null | tee -a $O/r05_h2h_probe.jsonl
+  cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/r05_h2h_stats -- python $GRAFT_REPO_ROOT/tools/h2h_probe.py 3 > /dev/null 2>&1; cd $GRAFT_REPO_ROOT
+  find $O/r05_h2h_stats -name '*kernel_stats.csv' -exec head -5 {} \;
+  find $O/r05_h2h_stats -name '*.csv' -size +1M -delete
+  ;;
+g)
+  # host-to-host after the fix, then the default bench line (what the driver runs) for the record
+  timeout 200 python tools/h2h_probe.py 6 2>/dev/null | tee $O/r05_h2h_probe_fixed.jsonl
+  ( timeout 600 python bench.py --gpus 1 --steps 25 --warmup 3 ) 2>/dev/null | line > $O/r05_bench_driver_shape.json; cut -c1-600 $O/r05_bench_driver_shape.json
+  ( timeout 600 python bench.py ) 2>/dev/null | line > $O/r05_bench_n1.json; python -c "
+import json; d=json.load(open('$O/r05_bench_n1.json')); print(d['value'], d['host_to_host']['ms_per_call'], d['host_to_host']['split_ms'])"
+  ;;
+h)
+  # which context makes the stall come back, and which piece of the helper thread's work it follows
+  for ctx in "" "--torch" "--resident" "--torch --resident"; do timeout 200 python tools/h2h_probe.py 4 $ctx 2>/dev/null; done | tee $O/r05_h2h_context.jsonl
+  for v in SKIP_TOUCH SKIP_FREE; do J2P_LIBRARY=ab/libj2p_hk_$v.so timeout 200 python tools/h2h_probe.py 4 --torch --resident 2>/dev/null; done | tee -a $O/r05_h2h_context.jsonl
+  ;;
+i)
+  for ctx in "--resident-nodl" "--resident-small" "--resident"; do timeout 200 python tools/h2h_probe.py 4 $ctx 2>/dev/null; done | tee $O/r05_h2h_context2.jsonl
+  J2P_POOL_MIB=0 timeout 200 python tools/h2h_probe.py 4 --resident 2>/dev/null | sed 's/"--resident"/"--resident, J2P_POOL_MIB=0"/' | tee -a $O/r05_h2h_context2.jsonl
+  timeout 200 python tools/h2h_probe.py 10 2>/dev/null | sed 's/"plain"/"plain, 10 calls"/' | tee -a $O/r05_h2h_context2.jsonl
+  cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/r05_h2h_trace2 -- python $GRAFT_REPO_ROOT/tools/h2h_probe.py 3 --resident > /dev/null 2>&1; cd $GRAFT_REPO_ROOT
+  python - <<PY
+import csv, glob
+f = glob.glob("$O/r05_h2h_trace2/*/*kernel_trace.csv")[0]
+rows = list(csv.DictReader(open(f)))
+ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:30]) for r in rows)
+inits = [i for i, k in enumerate(ks) if "k_init_state" in k[2]]
+for ci, i0 in enumerate(inits):
+    i1 = inits[ci + 1] if ci + 1 < len(inits) else len(ks)
+    g = [k for k in ks[i0:i1] if "k_gradient" in k[2]]
+    print("solve", ci, "gradients", len(g), "long:", [(j, round((k[0] - g[0][0]) / 1e6, 2), round((k[1] - k[0]) / 1e6, 2)) for j, k in enumerate(g) if k[1] - k[0] > 1e6])
+PY
+  find $O/r05_h2h_trace2 -name '*.csv' -delete
+  ;;
+j)
+  for v in BOTH NO_THREAD AFTER_SYNC; do J2P_LIBRARY=ab/libj2p_hk_$v.so timeout 200 python tools/h2h_probe.py 4 --resident-nodl 2>/dev/null; done | tee $O/r05_h2h_context3.jsonl
+  ;;
+k)
+  for ctx in "" "--resident-nodl" "--torch --resident"; do timeout 200 python tools/h2h_probe.py 5 $ctx 2>/dev/null; done | tee $O/r05_h2h_final.jsonl
+  ( timeout 300 python -m pytest tests/test_fineprint_gpu.py tests/test_parity_gpu.py -q --timeout 300 -k "fineprint or drop_in or concurrent" ) 2>&1 | tail -3
+  ( timeout 600 python bench.py ) 2>/dev/null | line > $O/r05_bench_n1.json; python -c "
+import json; d=json.load(open('$O/r05_bench_n1.json')); print(d['value'], d['host_to_host']['ms_per_call'], d['host_to_host']['ms_per_call_all'], d['host_to_host']['split_ms'])"
+  ;;
 esac
