@@ -55,9 +55,9 @@ struct coef {
 #endif
 
 /* compute.h:8 / compute.c:407.  Same contract as the reference:
- *  - frees the incoming coef->fdata (aligned_alloc'd, compute.c:304-305) and hands back a
- *    new 16-byte aligned W*H plane in coef->fdata, rewriting coef->w/h to the canvas size
- *    (compute.c:455-461);
+ *  - consumes the incoming coef->fdata (aligned_alloc'd, compute.c:304-305) and hands back a
+ *    16-byte aligned W*H plane the caller frees in coef->fdata, rewriting coef->w/h to the canvas
+ *    size (compute.c:455-461) — the incoming buffer itself where it already has that size;
  *  - sets log->iteration and calls logger_log() once per iteration (compute.c:428,272),
  *    progressbar_inc() once per iteration when pb != NULL (compute.c:449-452);
  *  - re-entrant and thread-safe (callers: jpeg2png.c:144, :147-152 inside omp parallel);
@@ -71,7 +71,9 @@ void compute(unsigned nchannel, struct coef coefs[], struct logger *log, struct 
 
 /* same, with an explicit device and an error code instead of exit(); 0 on success.
  * On ANY error return the caller still owns its inputs: coefs[c].fdata, w and h are untouched (the inputs are released
- * only behind a successful download), so the call can be retried — on another device, for instance. */
+ * only behind a successful download), so the call can be retried — on another device, for instance.  (A channel whose
+ * plane has the canvas's size keeps its buffer — the result is downloaded into it; only a failing download, a device
+ * fault, can leave such a plane partly overwritten.) */
 int j2p_compute(int device, unsigned nchannel, struct coef coefs[], struct logger *log,
                 struct progressbar *pb, float weight, const float pweight[], unsigned iterations);
 

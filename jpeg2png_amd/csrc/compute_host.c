@@ -67,8 +67,15 @@ int j2p_compute_timing(j2p_compute_times *out)
  * solved before: 80-98 instead of 66 ms per 4096^2 call, whichever thread does it.  So none of it happens while the loop
  * runs: the output planes are prepared by helper threads BESIDE THE UPLOAD (create), the loop is issued when they are
  * done, and the inputs are freed behind the download — which also means a call that fails returns with the caller's
- * planes untouched, whatever failed (tests/test_fineprint_gpu.py). */
-#define J2P_TOUCHERS 4u
+ * planes still the caller's (tests/test_fineprint_gpu.py).
+ * And most of it does not happen at all: a full-resolution channel's input plane (w x h floats from alloc_simd,
+ * jpeg.c:83-92) has exactly the size of the canvas plane compute() hands back (compute.c:455-461) whenever the channel
+ * covers the canvas — every Y-only call, the luma of unpadded images, all of 4:4:4 — and its content is on the device
+ * since create: the download goes INTO it and the pointer stays.  To the caller that is the contract to the letter (the
+ * incoming plane is gone, an aligned W x H plane it must free is there); to the process it is 64 MiB less to map, fault,
+ * copy around and unmap per 4096^2 call.  (Only a failing download — a device fault — can then leave such a plane with
+ * part of its old content overwritten.) */
+#define J2P_TOUCHERS 8u
 struct toucher {
         char *base;
         size_t bytes;
@@ -84,6 +91,7 @@ struct housekeeping {
         unsigned nchannel;
         size_t out_bytes;
         float *out[J2P_MAX_CHANNELS];
+        int reuse[J2P_MAX_CHANNELS];    /* the channel's INPUT plane has the canvas's size: it becomes the output plane */
         int failed;
         double ms;
 };
@@ -94,6 +102,7 @@ static void *housekeeping_main(void *arg)
         const double t0 = now_ms();
         const size_t page = 4096;
         for(unsigned c = 0; c < h->nchannel; c++) {
+                if(h->reuse[c]) { continue; }
                 /* alloc_simd (utils.h:89-98) is aligned_alloc(16, ...); page-aligned here, and kept out of transparent huge
                  * pages (a huge-page fault next to pinned user pages is the most expensive form of the effect above) */
                 h->out[c] = aligned_alloc(page, (h->out_bytes + page - 1) & ~(page - 1));
@@ -154,9 +163,14 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
         hk.out_bytes = (sizeof(float) * (size_t)W * H + 15) & ~(size_t)15;
         hk.failed = 0;
         hk.ms = 0.;
-        for(unsigned c = 0; c < J2P_MAX_CHANNELS; c++) { hk.out[c] = NULL; }
+        unsigned fresh = 0;
+        for(unsigned c = 0; c < J2P_MAX_CHANNELS; c++) {
+                hk.out[c] = NULL;
+                hk.reuse[c] = c < nchannel && coefs[c].fdata && (size_t)coefs[c].w * coefs[c].h == (size_t)W * H;
+                if(c < nchannel && !hk.reuse[c]) { fresh++; }
+        }
         pthread_t hk_thread;
-        const int hk_started = W && H && pthread_create(&hk_thread, NULL, housekeeping_main, &hk) == 0;
+        const int hk_started = fresh && W && H && pthread_create(&hk_thread, NULL, housekeeping_main, &hk) == 0;
         if(nband > 1) {
                 rc = j2p_tiled_create(&t, nband, devices, NULL, nchannel, planes, weight, pweight, iterations);
                 if((rc == J2P_EDEVICE || rc == J2P_ENOMEM) && !j2p_tiled_exchange_forced()) {
@@ -170,7 +184,7 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
                 j2p_band whole = {0, 0};
                 rc = j2p_solver_create(&s, devices[0], NULL, nchannel, planes, weight, pweight, iterations, whole, 0);
         }
-        if(hk_started) { pthread_join(hk_thread, NULL); } else if(W && H) { housekeeping_main(&hk); }
+        if(hk_started) { pthread_join(hk_thread, NULL); } else if(fresh && W && H) { housekeeping_main(&hk); }
         float **outp = hk.out;
         if(rc == J2P_OK && hk.failed) { j2p_set_last_error("out of host memory for the output planes"); rc = J2P_ENOMEM; }
         t_mark[1] = t_mark[2] = t_mark[3] = now_ms();
@@ -207,16 +221,19 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
         if(rc != J2P_OK) { goto out; }
         t_mark[3] = now_ms();
         for(unsigned c = 0; c < nchannel; c++) {
-                rc = t ? j2p_tiled_download(t, c, outp[c]) : j2p_solver_download(s, c, outp[c]);
+                float *dst = hk.reuse[c] ? coefs[c].fdata : outp[c];
+                rc = t ? j2p_tiled_download(t, c, dst) : j2p_solver_download(s, c, dst);
                 if(rc != J2P_OK) { goto out; }
         }
         t_mark[4] = now_ms();
         /* everything has succeeded: the inputs go (compute.c:304-305 frees them at aux_init; here nothing frees memory
          * while kernels run, see above) and the new planes change hands */
         for(unsigned c = 0; c < nchannel; c++) {
-                free(coefs[c].fdata);
-                coefs[c].fdata = outp[c];                                          /* compute.c:458 */
-                outp[c] = NULL;
+                if(!hk.reuse[c]) {
+                        free(coefs[c].fdata);
+                        coefs[c].fdata = outp[c];                                  /* compute.c:458 */
+                        outp[c] = NULL;
+                }
                 coefs[c].w = W;                                                    /* compute.c:459-460 */
                 coefs[c].h = H;
         }

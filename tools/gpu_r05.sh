@@ -111,4 +111,12 @@ k)
   ( timeout 600 python bench.py ) 2>/dev/null | line > $O/r05_bench_n1.json; python -c "
 import json; d=json.load(open('$O/r05_bench_n1.json')); print(d['value'], d['host_to_host']['ms_per_call'], d['host_to_host']['ms_per_call_all'], d['host_to_host']['split_ms'])"
   ;;
+l)
+  for ctx in "" "--torch --resident"; do timeout 200 python tools/h2h_probe.py 5 $ctx 2>/dev/null; done | tee $O/r05_h2h_final.jsonl
+  ( timeout 900 python -m pytest tests/test_fineprint_gpu.py tests/test_parity_gpu.py tests/test_cli.py tests/test_capi.py -q --timeout 600 -k "fineprint or drop_in or concurrent or cli or reference_program or capi" -m gpu ) 2>&1 | tail -4
+  ( timeout 600 python bench.py ) 2>/dev/null | line > $O/r05_bench_n1.json; python -c "
+import json; d=json.load(open('$O/r05_bench_n1.json')); print(d['value'], d['host_to_host']['ms_per_call'], d['host_to_host']['ms_per_call_all'], d['host_to_host']['split_ms'])"
+  ( timeout 600 python bench.py --gpus 1 --steps 25 --warmup 3 ) 2>/dev/null | line > $O/r05_bench_driver_shape.json; python -c "
+import json; d=json.load(open('$O/r05_bench_driver_shape.json')); print('driver shape', d['value'], d['ms_per_step'], d['roofline']['frac'], d['parity']['bit_identical'], d['host_to_host']['ms_per_call'])"
+  ;;
 esac
