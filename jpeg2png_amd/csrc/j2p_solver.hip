@@ -1318,6 +1318,8 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
 #ifndef J2P_EXPERIMENTS
                 if(value == 2) { return fail(J2P_ESTATE, "J2P_OPT_NORM_FOLD 2 (the launch's last workgroup reduces) exists in the experiments build only"); }
 #endif
+                // (the reducer workgroup sums a WHOLE canvas's partials: a band solver would reduce ||g|| from stale global arrays)
+                if(value == 2 && !s->whole) { return fail(J2P_ESTATE, "J2P_OPT_NORM_FOLD 2 is for whole-canvas solvers"); }
                 s->fold = value == 1;
                 s->reducer = value == 2;
                 if(!s->fold) { s->fuse = false; }          // (the single-launch iteration folds: J2P_OPT_FUSE 1 turns both on again)

@@ -94,10 +94,13 @@ def _libc_coefs(planes):
 
 @pytest.mark.parametrize("tiled", [False, True])
 def test_j2p_compute_keeps_the_callers_planes_when_the_solve_fails(lib, tiled):
-    """j2p_compute() promises an error code instead of exit() (include/jpeg2png_amd_compute.h): a call that fails before
-    every iteration is queued must hand the caller's planes back untouched — pointer, size and content — so that the
-    caller can retry (on another device, say); the retry then gives the right answer.  The failure is injected behind a
-    successful create (j2p_debug_fail_run_after), where the helper thread that frees the inputs is already running."""
+    """j2p_compute() promises an error code instead of exit() (include/jpeg2png_amd_compute.h): a failing call must hand
+    the caller's planes back untouched — pointer, size and content — so that the caller can retry (on another device,
+    say); the retry then gives the right answer.  The failure is injected behind a successful create
+    (j2p_debug_fail_run_after): the upload has happened, the output planes exist, nothing may have been released.
+    And what a successful call does with the planes (compute.c:304-305, 455-461 as the caller sees them): a plane that
+    already has the canvas's size — the luma of this unpadded 4:2:0 image — keeps its buffer, the result is downloaded
+    into it; planes that must grow (chroma) are replaced."""
     import jpeg2png_amd as j
     planes = make_case(200, 176, "420", 10, seed=31)
     want = copy.deepcopy(planes)
@@ -129,8 +132,9 @@ def test_j2p_compute_keeps_the_callers_planes_when_the_solve_fails(lib, tiled):
         assert bit_equal(a, planes[c].fdata), f"channel {c}: input plane damaged"
     # the retry
     assert call() == 0, lib.j2p_last_error()
+    assert coefs[0].fdata == before[0][0], "a full-resolution plane of the canvas's size should have been reused"
     for c in range(3):
-        assert coefs[c].fdata != before[c][0] or True      # (malloc may hand the same address out again)
+        assert (coefs[c].w, coefs[c].h) == (want[0].fdata.shape[1], want[0].fdata.shape[0])
         a = np.ctypeslib.as_array(ctypes.cast(coefs[c].fdata, ctypes.POINTER(ctypes.c_float)), shape=(coefs[c].h, coefs[c].w))
         assert bit_equal(a, want[c].fdata), f"channel {c} after the retry"
         libc.free(coefs[c].fdata)

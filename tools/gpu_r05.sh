@@ -119,4 +119,13 @@ import json; d=json.load(open('$O/r05_bench_n1.json')); print(d['value'], d['hos
   ( timeout 600 python bench.py --gpus 1 --steps 25 --warmup 3 ) 2>/dev/null | line > $O/r05_bench_driver_shape.json; python -c "
 import json; d=json.load(open('$O/r05_bench_driver_shape.json')); print('driver shape', d['value'], d['ms_per_step'], d['roofline']['frac'], d['parity']['bit_identical'], d['host_to_host']['ms_per_call'])"
   ;;
+m)
+  # the round's last word: the whole suite, smoke, and the bench as the driver runs it, on the final tree
+  ( timeout 1500 python -m pytest tests -m gpu -q --durations=6 --timeout 900 ) > $O/r05_m_suite.log 2>&1; echo "suite rc=$?"; tail -50 $O/r05_m_suite.log
+  ( timeout 300 python __graft_entry__.py --smoke ) 2>&1 | tail -1
+  ( timeout 600 python bench.py --gpus 1 --steps 25 --warmup 3 ) 2>/dev/null | line > $O/r05_bench_driver_shape.json; python -c "
+import json; d=json.load(open('$O/r05_bench_driver_shape.json')); print('driver shape', d['value'], d['ms_per_step'], d['roofline']['frac'], d['parity']['bit_identical'], d['host_to_host']['ms_per_call'], d['host_to_host']['split_ms'])"
+  ( timeout 600 python bench.py ) 2>/dev/null | line > $O/r05_bench_n1.json; python -c "
+import json; d=json.load(open('$O/r05_bench_n1.json')); print('default', d['value'], d['host_to_host']['ms_per_call'])"
+  ;;
 esac
