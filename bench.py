@@ -65,6 +65,7 @@ BYTES_GRADIENT = 16              # per canvas pixel per launch (SURVEY.md §8d, 
 BYTES_PROJECT = 22               # phase B
 BYTES_ITERATION = BYTES_GRADIENT + BYTES_PROJECT
 WEIGHT, PWEIGHT = 0.3, 0.001     # jpeg2png.c:22-23 defaults
+EVENT_PAIR_US = None             # what a bracket of two HIP event records costs by itself (calibrated by the solver)
 RCCL_LEG_TIMEOUT_S = 180         # watchdog of the Python RCCL harness leg of an N > 1 run
 C_LEG_TIMEOUT_S = 120            # ... and of each child process that runs one leg of the C row tiling
 
@@ -455,6 +456,8 @@ def time_steps(ranks, reset, solve, sync, warmup, steps, eng, timing_every):
     elapsed = ranks.max(time.perf_counter() - t0)
     g_ms, p_ms, samples = eng.kernel_times() if eng is not None else (0.0, 0.0, 0)
     if eng is not None:
+        global EVENT_PAIR_US
+        EVENT_PAIR_US = round(eng.timing_overhead_ms() * 1e3, 3)
         eng.enable_timing(0)
     return elapsed, g_ms, p_ms, samples
 
@@ -471,7 +474,7 @@ def per_kernel_roofline(px_gradient, px_project, g_ms, p_ms):
 def pmc_traffic():
     """HBM bytes per iteration from the rocprofv3 PMC passes of the N = 1 workload (profiles/, corrected as
     MI355X_MICROARCH.md prescribes)"""
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json")
         if not os.path.exists(pmc):
             continue
@@ -499,10 +502,11 @@ def roofline_object(value_mpx, gpus_used, its, elapsed, steps, band_px, per_kern
             "iteration_ms": round(elapsed / steps / its * 1e3, 5),
             "kernel_frac": per_kernel[kern]["frac"],
             "per_kernel": per_kernel,
-            "event_samples": samples,
+            "event_samples": samples, "event_pair_overhead_us": EVENT_PAIR_US,
             "note": "per-kernel durations come from HIP events around every "
-                    f"{timing_every}th iteration; the event records themselves cost time on those "
-                    "iterations, so the two durations can add up to more than iteration_ms",
+                    f"{timing_every}th iteration, minus what a bracket of two records measures with nothing in between "
+                    "(event_pair_overhead_us, calibrated on the same stream); the dispatch itself stays in, so they read "
+                    "slightly above rocprofv3's kernel durations (profiles/), and the records cost time on those iterations",
             "what_limits_it": "both limits at once: k_project moves its bytes at about the achievable HBM rate of this part (6.29 TB/s "
                               "float4 copy, MI355X_MICROARCH.md; peak above is the 8 TB/s spec the contract asks for); k_gradient moves "
                               "its real traffic (1.15 x algorithmic: halo rows) at 0.9 of that rate while its vector ALUs are about "

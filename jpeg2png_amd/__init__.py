@@ -82,7 +82,7 @@ C_ABI_SYMBOLS = [
     "j2p_tiled_download", "j2p_tiled_host_cpu_seconds", "j2p_solver_norm_ptr", "j2p_solver_norm_external",
     "j2p_solver_global_rowsums", "j2p_solver_link_bands", "j2p_tiled_exchange",
     "j2p_batch_create", "j2p_batch_destroy", "j2p_batch_submit", "j2p_batch_wait",
-    "compute", "j2p_compute", "j2p_compute_tiled", "j2p_compute_timing", "j2p_debug_fail_run_after", "j2p_solver_launches_per_iteration",
+    "compute", "j2p_compute", "j2p_compute_tiled", "j2p_compute_timing", "j2p_debug_fail_run_after", "j2p_solver_launches_per_iteration", "j2p_solver_timing_overhead",
     "j2p_debug_build", "j2p_solver_debug_violations", "j2p_solver_trace", "j2p_division_exhaustive",
 ]
 J2P_OPT_NORM_FOLD, J2P_OPT_JOINT_INWAVE, J2P_OPT_NORM_IN_PROJECT, J2P_OPT_NT_GRADIENT, J2P_OPT_MIXED_PROJECT, J2P_OPT_FUSE = 1, 2, 4, 5, 6, 7
@@ -426,6 +426,12 @@ class Solver:
     def enable_timing(self, every=1):
         """record HIP events around the two phase kernels of every `every`-th iteration (0 = off)."""
         _check(self._lib.j2p_solver_enable_timing(self._h, int(every)))
+
+    def timing_overhead_ms(self):
+        """what a bracket of two event records costs by itself on this solver's stream (already taken off kernel_times())"""
+        v = ctypes.c_double()
+        _check(self._lib.j2p_solver_timing_overhead(self._h, ctypes.byref(v)))
+        return v.value
 
     def kernel_times(self):
         g, p, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint()

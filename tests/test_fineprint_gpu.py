@@ -102,7 +102,7 @@ def test_j2p_compute_keeps_the_callers_planes_when_the_solve_fails(lib, tiled):
     already has the canvas's size — the luma of this unpadded 4:2:0 image — keeps its buffer, the result is downloaded
     into it; planes that must grow (chroma) are replaced."""
     import jpeg2png_amd as j
-    planes = make_case(200, 176, "420", 10, seed=31)
+    planes = make_case(208, 176, "420", 10, seed=31)          # (a multiple of 16 each way: chroma pads no further than luma)
     want = copy.deepcopy(planes)
     j.compute(want, 0.3, [0.001] * 3, 7)
     libc, coefs = _libc_coefs(planes)

@@ -128,4 +128,9 @@ import json; d=json.load(open('$O/r05_bench_driver_shape.json')); print('driver 
   ( timeout 600 python bench.py ) 2>/dev/null | line > $O/r05_bench_n1.json; python -c "
 import json; d=json.load(open('$O/r05_bench_n1.json')); print('default', d['value'], d['host_to_host']['ms_per_call'])"
   ;;
+n)
+  ( timeout 600 python -m pytest tests/test_fineprint_gpu.py tests/test_capi.py -q --timeout 300 -m gpu ) 2>&1 | tail -3
+  ( timeout 600 python bench.py --gpus 1 --steps 25 --warmup 3 ) 2>/dev/null | line > $O/r05_bench_driver_shape.json; python -c "
+import json; d=json.load(open('$O/r05_bench_driver_shape.json')); r=d['roofline']; print('driver shape', d['value'], d['ms_per_step'], r['frac'], r['event_pair_overhead_us'], {k: (v['avg_launch_ms'], v['frac']) for k, v in r['per_kernel'].items()}, d['parity']['bit_identical'], d['host_to_host']['ms_per_call'])"
+  ;;
 esac
