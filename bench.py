@@ -504,9 +504,9 @@ def roofline_object(value_mpx, gpus_used, its, elapsed, steps, band_px, per_kern
             "per_kernel": per_kernel,
             "event_samples": samples, "event_pair_overhead_us": EVENT_PAIR_US,
             "note": "per-kernel durations come from HIP events around every "
-                    f"{timing_every}th iteration, minus what a bracket of two records measures with nothing in between "
-                    "(event_pair_overhead_us, calibrated on the same stream); the dispatch itself stays in, so they read "
-                    "slightly above rocprofv3's kernel durations (profiles/), and the records cost time on those iterations",
+                    f"{timing_every}th iteration; the brackets themselves are in the figures (event_pair_overhead_us = what an EMPTY "
+                    "bracket measures on the same stream: the scale of it; not subtracted, because with a kernel in between part of it "
+                    "overlaps), so per-kernel durations read 2-3 us above rocprofv3's (profiles/), which are the reproducible ones",
             "what_limits_it": "both limits at once: k_project moves its bytes at about the achievable HBM rate of this part (6.29 TB/s "
                               "float4 copy, MI355X_MICROARCH.md; peak above is the 8 TB/s spec the contract asks for); k_gradient moves "
                               "its real traffic (1.15 x algorithmic: halo rows) at 0.9 of that rate while its vector ALUs are about "

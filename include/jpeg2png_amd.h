@@ -322,7 +322,7 @@ int j2p_solver_sync(j2p_solver *s);
 int j2p_solver_kernel_times(j2p_solver *s, double *gradient_ms, double *project_ms, unsigned *samples);
 int j2p_solver_enable_timing(j2p_solver *s, int every);   /* 0 = off, k = sample every k-th iteration */
 /* what a bracket of two event records measures with nothing in between on the solver's stream (calibrated when timing is
- * switched on; already taken off the figures j2p_solver_kernel_times() returns) */
+ * switched on): the scale of what the event brackets add to j2p_solver_kernel_times() — reported, not subtracted */
 int j2p_solver_timing_overhead(j2p_solver *s, double *event_pair_ms);
 
 /* decode_coefficients + unbox (jpeg.c:83-92, box.c:5-19) on the device:

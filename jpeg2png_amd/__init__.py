@@ -428,7 +428,7 @@ class Solver:
         _check(self._lib.j2p_solver_enable_timing(self._h, int(every)))
 
     def timing_overhead_ms(self):
-        """what a bracket of two event records costs by itself on this solver's stream (already taken off kernel_times())"""
+        """what a bracket of two event records measures by itself on this solver's stream (the scale of what the brackets add to kernel_times())"""
         v = ctypes.c_double()
         _check(self._lib.j2p_solver_timing_overhead(self._h, ctypes.byref(v)))
         return v.value

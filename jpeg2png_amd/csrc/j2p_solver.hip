@@ -476,10 +476,12 @@ int flush_timing(j2p_solver *s)
                 float g = 0.f, p = 0.f;
                 HIP_TRY(hipEventElapsedTime(&g, s->ev[i], s->ev[i + 1]));
                 HIP_TRY(hipEventElapsedTime(&p, s->ev[i + 2], s->ev[i + 3]));
-                // (a pair of records brackets the kernel AND the second record's own packet: that part is measured when
-                // timing is switched on and taken off here; what remains above rocprofv3's figure is the dispatch itself)
-                s->acc_grad_ms += g > s->ev_pair_ms ? g - s->ev_pair_ms : 0.;
-                s->acc_proj_ms += p > s->ev_pair_ms ? p - s->ev_pair_ms : 0.;
+                // (a pair of records brackets the kernel AND the records' own packets.  What an EMPTY bracket measures is
+                // calibrated when timing is switched on (ev_pair_ms, 4.8 us on MI355X) and reported, but NOT taken off: with
+                // a kernel in between part of it overlaps, and the corrected figures came out below rocprofv3's — 50.5 vs
+                // 53.2 us — which is the wrong side to err on)
+                s->acc_grad_ms += g;
+                s->acc_proj_ms += p;
                 s->acc_samples++;
         }
         s->ev_used = 0;
