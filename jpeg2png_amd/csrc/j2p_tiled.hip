@@ -546,13 +546,14 @@ void j2p_tiled_destroy(j2p_tiled *t)
                         }
                 }
         }
-        const bool undrainable = t->abort.load() && t->exchange == kRccl && !(t->rccl && t->rccl->CommAbort);
+        bool stuck = false;
         if(t->abort.load() && t->signals) {
                 // the release has to be REPEATED until every band stream is idle: the streams still hold hipStreamWriteValue64
                 // operations of the iterations that were queued before the failure, and each of them puts a small value back
                 // over the released one (seen: the failed band's own flag fell back to its last iteration and the other
                 // band's stream sat in front of it for ever).  Finitely many are queued, every pass lets the streams get
                 // further: this terminates.
+                const auto t0 = std::chrono::steady_clock::now();
                 for(;;) {
                         release_value_waiters(t);
                         bool idle = true;
@@ -562,29 +563,35 @@ void j2p_tiled_destroy(j2p_tiled *t)
                         }
                         (void)hipGetLastError();
                         if(idle) { break; }
+                        // (streams that do not drain although every value has been released are stuck on something else:
+                        // better a leak than a process that never returns)
+                        if(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.) { stuck = true; break; }
                         std::this_thread::sleep_for(std::chrono::microseconds(200));
                 }
         }
+        const bool undrainable = stuck || (t->abort.load() && t->exchange == kRccl && !(t->rccl && t->rccl->CommAbort));
         for(Band *b : t->bands) {
                 (void)hipSetDevice(b->device);
                 if(b->stream && !undrainable) { (void)hipStreamSynchronize(b->stream); }
-                if(b->comm && t->rccl) { (void)t->rccl->CommDestroy(b->comm); }
+                if(b->comm && t->rccl && !undrainable) { (void)t->rccl->CommDestroy(b->comm); }
         }
         for(Band *b : t->bands) {
                 (void)hipSetDevice(b->device);
-                if(b->solver && !undrainable) { j2p_solver_destroy(b->solver); }        // synchronises the band's stream first (undrainable: leaked rather than hung)
-                for(int k = 0; k < 2; k++) {
+                // (undrainable: what the stuck streams may still touch — solvers, events, the collector, pinned buffers — is
+                // leaked rather than waited for or pulled from under them)
+                if(b->solver && !undrainable) { j2p_solver_destroy(b->solver); }        // synchronises the band's stream first
+                for(int k = 0; k < 2 && !undrainable; k++) {
                         if(b->ev_grad[k]) { (void)hipEventDestroy(b->ev_grad[k]); }
                         if(b->ev_edge[k]) { (void)hipEventDestroy(b->ev_edge[k]); }
                         if(b->ev_norm[k]) { (void)hipEventDestroy(b->ev_norm[k]); }
                         if(b->ev_all[k]) { (void)hipEventDestroy(b->ev_all[k]); }
                 }
-                if(b->collector) { (void)hipStreamSynchronize(b->collector); (void)hipStreamDestroy(b->collector); }
-                if(b->log_host) { (void)hipHostFree(b->log_host); }
+                if(b->collector && !undrainable) { (void)hipStreamSynchronize(b->collector); (void)hipStreamDestroy(b->collector); }
+                if(b->log_host && !undrainable) { (void)hipHostFree(b->log_host); }
                 delete b;
         }
         if(prev >= 0) { (void)hipSetDevice(prev); }
-        if(t->signals) { (void)hipHostFree(t->signals); }
+        if(t->signals && !undrainable) { (void)hipHostFree(t->signals); }
         delete t;
         j2p_pool_trim();        // band arenas are large and rarely reused at the same size: back to the device
 }
@@ -841,6 +848,36 @@ struct Candidate {
         const char *name;
 };
 
+// j2p_tiled_sync with a deadline: a candidate exchange that never completes on this hardware (a value that is never
+// counted up, a collective that never matches) must cost its candidacy, not the process.  On time-out the solver is marked
+// failed — which releases value waiters and lets the destroy abort RCCL communicators — and J2P_EDEVICE comes back.
+int sync_within(j2p_tiled *t, double seconds)
+{
+        const auto t0 = std::chrono::steady_clock::now();
+        for(;;) {
+                bool idle = true;
+                for(Band *b : t->bands) {
+                        if(hipSetDevice(b->device) != hipSuccess) { return j2p_fail(J2P_EDEVICE, "hipSetDevice(%d) failed", b->device); }
+                        const hipError_t e = b->stream ? hipStreamQuery(b->stream) : hipSuccess;
+                        if(e == hipErrorNotReady) { idle = false; }
+                        else if(e != hipSuccess) { (void)hipGetLastError(); return j2p_fail(J2P_EDEVICE, "band stream on device %d: %s", b->device, hipGetErrorString(e)); }
+                }
+                (void)hipGetLastError();
+                if(idle) { return J2P_OK; }
+                if(std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds) {
+                        {
+                                std::lock_guard<std::mutex> g(t->seq_lock);
+                                t->abort.store(true);
+                        }
+                        t->seq_cv.notify_all();
+                        release_value_waiters(t);
+                        return j2p_fail(J2P_EDEVICE, "the bands did not finish within %.0f s", seconds);
+                }
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+}
+constexpr double kVerifyDeadlineSeconds = 20.;
+
 // one scratch run: 0 = matches `truth` (seconds per timed iteration in *secs), 1 = ran and differs, 2 = could not run
 int verify_candidate(const Candidate &cand, unsigned nband, const int devices[], const unsigned cuts[], unsigned nchannel,
                      const j2p_plane planes[], float weight, const float pweight[], size_t canvas_floats,
@@ -851,7 +888,7 @@ int verify_candidate(const Candidate &cand, unsigned nband, const int devices[],
         int verdict = 2;
         std::vector<float> got(canvas_floats);
         if(rc == J2P_OK) { rc = j2p_tiled_run(t, kVerifyIterations, nullptr); }
-        if(rc == J2P_OK) { rc = j2p_tiled_sync(t); }
+        if(rc == J2P_OK) { rc = sync_within(t, kVerifyDeadlineSeconds); }
         if(rc == J2P_OK) {
                 verdict = 0;
                 for(unsigned c = 0; c < nchannel && rc == J2P_OK; c++) {
@@ -873,7 +910,7 @@ int verify_candidate(const Candidate &cand, unsigned nband, const int devices[],
                 rc = j2p_tiled_reset(t);
                 const auto t0 = std::chrono::steady_clock::now();
                 if(rc == J2P_OK) { rc = j2p_tiled_run(t, kVerifyTimedIterations, nullptr); }
-                if(rc == J2P_OK) { rc = j2p_tiled_sync(t); }
+                if(rc == J2P_OK) { rc = sync_within(t, kVerifyDeadlineSeconds); }
                 *secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / kVerifyTimedIterations;
         }
         if(rc != J2P_OK) {

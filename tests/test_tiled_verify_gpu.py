@@ -78,7 +78,8 @@ def test_a_broken_exchange_is_found_and_demoted(lib):
     scratch canvases differ from the one-GPU solve — `copy`, which pulls the rows with a kernel of its own, must be what
     the job then runs on, and the job's planes must be right."""
     lib_path = os.path.join(ROOT, "ab", "libj2p_drop_halo_push.so")
-    if not os.path.exists(lib_path):
+    sources = [os.path.join(ROOT, "jpeg2png_amd", "csrc", f) for f in ("j2p_kernels.hip.h", "j2p_solver.hip", "j2p_tiled.hip", "j2p_batch.hip", "compute_host.c")]
+    if not os.path.exists(lib_path) or any(os.path.getmtime(f) > os.path.getmtime(lib_path) for f in sources):
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), "drop_halo_push", "-DJ2P_EXP_DROP_HALO_PUSH"],
                        check=True, cwd=ROOT, timeout=600)
     devices = band_devices(2)
