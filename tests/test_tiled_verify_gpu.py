@@ -77,11 +77,7 @@ def test_a_broken_exchange_is_found_and_demoted(lib):
     (-DJ2P_EXP_DROP_HALO_PUSH, built here by tools/build_variant.py).  Both `direct` candidates must be demoted — their
     scratch canvases differ from the one-GPU solve — `copy`, which pulls the rows with a kernel of its own, must be what
     the job then runs on, and the job's planes must be right."""
-    lib_path = os.path.join(ROOT, "ab", "libj2p_drop_halo_push.so")
-    sources = [os.path.join(ROOT, "jpeg2png_amd", "csrc", f) for f in ("j2p_kernels.hip.h", "j2p_solver.hip", "j2p_tiled.hip", "j2p_batch.hip", "compute_host.c")]
-    if not os.path.exists(lib_path) or any(os.path.getmtime(f) > os.path.getmtime(lib_path) for f in sources):
-        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), "drop_halo_push", "-DJ2P_EXP_DROP_HALO_PUSH"],
-                       check=True, cwd=ROOT, timeout=600)
+    lib_path = _variant("drop_halo_push", "-DJ2P_EXP_DROP_HALO_PUSH")
     devices = band_devices(2)
     own_gpus = len(set(devices)) == len(devices)
     env = {"J2P_LIBRARY": lib_path, "J2P_TILED_VERIFY": "2"}
@@ -94,6 +90,28 @@ def test_a_broken_exchange_is_found_and_demoted(lib):
     if not own_gpus:
         out2, _ = run_child({"J2P_LIBRARY": lib_path, "J2P_TILED_VERIFY": "0"}, devices)
         assert out2["exchange"] == "direct" and not all(out2["equal"])
+
+
+def _variant(name, flag):
+    lib_path = os.path.join(ROOT, "ab", f"libj2p_{name}.so")
+    sources = [os.path.join(ROOT, "jpeg2png_amd", "csrc", f) for f in ("j2p_kernels.hip.h", "j2p_solver.hip", "j2p_tiled.hip", "j2p_batch.hip", "compute_host.c")]
+    if not os.path.exists(lib_path) or any(os.path.getmtime(f) > os.path.getmtime(lib_path) for f in sources):
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), name, flag], check=True, cwd=ROOT, timeout=600)
+    return lib_path
+
+
+@pytest.mark.timeout(900)
+def test_an_exchange_that_never_finishes_costs_its_candidacy_not_the_process(lib):
+    """fault injection no. 2: a library whose k_gradient never counts up the values the `counter` form waits for
+    (-DJ2P_EXP_DROP_COUNTS) — on hardware this code has not met, THAT is what a wrong assumption about stream memory
+    operations would look like: the candidate does not fail, it never finishes.  The verification runs every candidate
+    against a deadline: `direct, wait counter` must be reported as not finishing, its stuck streams released and torn
+    down, another exchange picked, and the job's planes right."""
+    devices = band_devices(2)
+    out, err = run_child({"J2P_LIBRARY": _variant("drop_counts", "-DJ2P_EXP_DROP_COUNTS"), "J2P_TILED_VERIFY": "2"}, devices)
+    assert "exchange 'direct, wait counter' not available" in err and "did not finish" in err, err
+    assert out["exchange"] in ("direct", "copy") and out["exchange_again"] == out["exchange"]
+    assert all(out["equal"]), out
 
 
 @pytest.mark.timeout(120)
