@@ -134,6 +134,6 @@ n)
 import json; d=json.load(open('$O/r05_bench_driver_shape.json')); r=d['roofline']; print('driver shape', d['value'], d['ms_per_step'], r['frac'], r['event_pair_overhead_us'], {k: (v['avg_launch_ms'], v['frac']) for k, v in r['per_kernel'].items()}, d['parity']['bit_identical'], d['host_to_host']['ms_per_call'])"
   ;;
 o)
-  ( timeout 1200 python -m pytest tests/test_tiled_verify_gpu.py tests/test_tiled_c_gpu.py tests/test_batch_gpu.py -q --timeout 600 -m gpu ) 2>&1 | tail -5
+  ( timeout 1200 python -m pytest tests/test_tiled_verify_gpu.py tests/test_tiled_c_gpu.py tests/test_batch_gpu.py -q --timeout 600 -m gpu ) > $O/r05_o_tiled_tests.log 2>&1; echo "tiled tests rc=$?"; grep -E "passed|failed|Error" $O/r05_o_tiled_tests.log | tail -8
   ;;
 esac
