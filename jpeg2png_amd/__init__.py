@@ -551,7 +551,7 @@ class Batch:
         self._pending = {}
 
     def submit(self, planes, weight, pweight, iterations, separate=False, width=None, height=None, bits=0, tile=False,
-               tile_devices=None, tile_min_band_pixels=None):
+               tile_devices=None, tile_min_band_pixels=None, out=None):
         """tile=True: the image is row-tiled over the batch's devices instead of solved on one of them;
         tile_devices=(first, count): over that slice of the batch's device list only"""
         n = len(planes)
@@ -576,7 +576,11 @@ class Batch:
         H = max(p.h * p.h_samp for p in planes)
         shapes = [(p.h * p.h_samp, p.w * p.w_samp) if separate else (H, W) for p in planes]
         if bits:
-            out = np.empty((height, width, 3), dtype=np.uint8 if bits == 8 else ">u2")
+            # (out: a caller's own RGB array, reused between jobs — nothing is then mapped or faulted in while other jobs'
+            # kernels run, which costs those a stalled launch each time)
+            if out is None:
+                out = np.empty((height, width, 3), dtype=np.uint8 if bits == 8 else ">u2")
+            assert out.shape == (height, width, 3) and out.flags["C_CONTIGUOUS"]
             job.out_bits, job.out_w, job.out_h = bits, width, height
             job.out_rgb = out.ctypes.data
         else:

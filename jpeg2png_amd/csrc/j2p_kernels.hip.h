@@ -1255,6 +1255,16 @@ constexpr int kGradWaves1 = J2P_GRAD_WAVES;    // waves per SIMD the 1-channel g
 #define J2P_HOT_RING 4
 #endif
 constexpr int kHotWaves = J2P_HOT_WAVES, kHotRing = J2P_HOT_RING;
+// ... separately for the planes whose working set exceeds the Infinity Cache (NT >= 1: from ~15 Mpixel; no instantiation
+// more).  Measured with 5 / 3 there (profiles/r05_ab_five_wavefronts.jsonl): 4096^2 -0.2 %, 8192x4096 and 16384x2048
+// -1.0 %, 8192^2 +1.2 % — a percent either way again; stays 4 / 4
+#ifndef J2P_BIG_WAVES
+#define J2P_BIG_WAVES 4
+#endif
+#ifndef J2P_BIG_RING
+#define J2P_BIG_RING 4
+#endif
+constexpr int kBigWaves = J2P_BIG_WAVES, kBigRing = J2P_BIG_RING;
 constexpr int kGradWaves3 = 2;    // ... the three-channels-in-one-wavefront schedule
 // NCH channels are handled inside one wavefront (J == 1, workgroup = 4 strips), or — for a
 // jointly optimised image — J wavefronts of a workgroup take one channel each of the same strip
@@ -1486,7 +1496,7 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
         for(int c = 0; c < NCH; c++) { g2[c] = 0.; }
         const size_t ntiles_row = a.geo.ntx;
         const size_t nparts = (size_t)((rows + (int)a.geo.rpw - 1) / (int)a.geo.rpw) * ntiles_row;
-        constexpr int R = NCH == 1 ? (J == 1 && !LOG && PX == 2 ? kHotRing : kRing) : 3;
+        constexpr int R = NCH == 1 ? (J == 1 && !LOG && PX == 2 ? (NT >= 1 ? kBigRing : kHotRing) : kRing) : 3;
 
         // The march over the strip's rows, compiled twice: once general, once for strips that touch neither an
         // image edge, a band edge nor a channel's coverage limit (all but the outermost strips and segments).
@@ -1679,7 +1689,7 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
 __device__ __forceinline__ unsigned chunk_base(unsigned n, unsigned q) { return q * (n >> 3) + (q < (n & 7) ? q : (n & 7)); }
 
 template <int NCH, bool TGV, bool LOG, int J = 1, int NT = 0, int PX = 2>
-__global__ __launch_bounds__((J == 1 ? 256 : 64 * J), (PX == 1 ? (J == 1 && !LOG ? 6 : 2) : NCH == 1 ? (J == 1 && !LOG ? kHotWaves : kGradWaves1) : NCH == 2 ? 3 : kGradWaves3))
+__global__ __launch_bounds__((J == 1 ? 256 : 64 * J), (PX == 1 ? (J == 1 && !LOG ? 6 : 2) : NCH == 1 ? (J == 1 && !LOG ? (NT >= 1 ? kBigWaves : kHotWaves) : kGradWaves1) : NCH == 2 ? 3 : kGradWaves3))
 void k_gradient(GradArgs a)
 {
         static_assert(J == 1 || NCH == 1, "channel-per-wavefront mode keeps one channel per wavefront");

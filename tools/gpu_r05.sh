@@ -136,4 +136,20 @@ import json; d=json.load(open('$O/r05_bench_driver_shape.json')); r=d['roofline'
 o)
   ( timeout 1200 python -m pytest tests/test_tiled_verify_gpu.py tests/test_tiled_c_gpu.py tests/test_batch_gpu.py -q --timeout 600 -m gpu ) > $O/r05_o_tiled_tests.log 2>&1; echo "tiled tests rc=$?"; grep -E "passed|failed|Error" $O/r05_o_tiled_tests.log | tail -8
   ;;
+p)
+  timeout 300 python tools/batch_prealloc.py 128 8 2>/dev/null | tee $O/r05_batch_prealloc.jsonl
+  ;;
+q)
+  # planes beyond the Infinity Cache (NT >= 1): five wavefronts + ring of three (the library now) against four + four (big4), same box
+  for sz in "4096 4096 500" "8192 4096 100" "16384 2048 100" "8192 8192 100"; do
+    set -- $sz
+    for v in new big4 new big4; do
+      L=""; [ $v = big4 ] && L=ab/libj2p_big4.so
+      ( J2P_LIBRARY=$L timeout 300 python bench.py --size $1 --height $2 --iterations $3 --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs --no-host-to-host ) 2>/dev/null | line | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print(json.dumps({'plane': '$1x$2 -i $3', 'variant': '$v', 'us_per_iteration': round(r['iteration_ms']*1e3,2), 'k_gradient_us': round(r['per_kernel']['k_gradient']['avg_launch_ms']*1e3,1), 'parity': (d.get('parity') or {}).get('bit_identical')}))"
+    done
+  done | tee $O/r05_ab_big_planes.jsonl
+  ;;
 esac
