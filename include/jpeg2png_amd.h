@@ -367,6 +367,9 @@ typedef struct j2p_job {
          * out_w x out_h, into out_rgb (h*w*3 or h*w*6 bytes); out_bits 0 = the float canvas planes into
          * out_planes[c] (NULL entries are skipped): W*H floats of the joint canvas, or — separate — of component
          * c's own canvas, w*w_samp x h*h_samp (compute.c:410-416 per call) */
+        /* (hand over output memory that is already MAPPED — arrays reused between jobs: mapping or first-touching host memory
+         * while other jobs' kernels run stalls a launch of theirs each time; 229 against 196-201 images/s at 1080p on one GPU,
+         * profiles/r05_batch_prealloc.jsonl) */
         unsigned out_bits, out_w, out_h;
         uint8_t *out_rgb;
         float *out_planes[J2P_MAX_CHANNELS];

@@ -152,4 +152,9 @@ print(json.dumps({'plane': '$1x$2 -i $3', 'variant': '$v', 'us_per_iteration': r
     done
   done | tee $O/r05_ab_big_planes.jsonl
   ;;
+r)
+  ( timeout 300 python bench.py --config batch --steps 2 --warmup 1 --batch 64 ) 2>&1 | line | tee $O/r05_bench_batch.json | cut -c1-300
+  ( timeout 600 python bench.py --force-tiled --bands 8 --steps 2 --warmup 1 --no-cpu-baseline ) 2>&1 | line > $O/r05_bench_tiled_8bands_1gpu.json; python -c "
+import json; d=json.load(open('$O/r05_bench_tiled_8bands_1gpu.json')); print(d['value'], d['config']['engine'], d['parity']['bit_identical']); [print(o.get('config','')[:50], o.get('Mpx_it_per_s'), o.get('images_per_s')) for o in d['other_configs']]"
+  ;;
 esac
