@@ -157,4 +157,12 @@ r)
   ( timeout 600 python bench.py --force-tiled --bands 8 --steps 2 --warmup 1 --no-cpu-baseline ) 2>&1 | line > $O/r05_bench_tiled_8bands_1gpu.json; python -c "
 import json; d=json.load(open('$O/r05_bench_tiled_8bands_1gpu.json')); print(d['value'], d['config']['engine'], d['parity']['bit_identical']); [print(o.get('config','')[:50], o.get('Mpx_it_per_s'), o.get('images_per_s')) for o in d['other_configs']]"
   ;;
+s)
+  # randomised parity sweeps on the round's final library, new seeds
+  ( timeout 900 python tools/sweep_vs_ref.py 800 71 ) 2>&1 | tail -1 | tee $O/r05_final_sweeps.txt
+  ( timeout 600 python tools/sweep_wide.py 300 72 ) 2>&1 | tail -1 | tee -a $O/r05_final_sweeps.txt
+  ( timeout 900 python tools/sweep_tiled.py 250 73 ) 2>&1 | tail -1 | tee -a $O/r05_final_sweeps.txt
+  ( timeout 600 python tools/sweep_bands.py 120 74 ) 2>&1 | tail -1 | tee -a $O/r05_final_sweeps.txt
+  ( timeout 900 python tools/sweep_cli.py 60 75 ) 2>&1 | tail -1 | tee -a $O/r05_final_sweeps.txt
+  ;;
 esac
