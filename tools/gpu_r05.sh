@@ -165,4 +165,12 @@ s)
   ( timeout 600 python tools/sweep_bands.py 120 74 ) 2>&1 | tail -1 | tee -a $O/r05_final_sweeps.txt
   ( timeout 900 python tools/sweep_cli.py 60 75 ) 2>&1 | tail -1 | tee -a $O/r05_final_sweeps.txt
   ;;
+t)
+  # batch engine: a stream per image (old) against the worker's own streams (new), outputs in a ring; same box, alternating
+  for v in new old new old; do
+    L=""; [ $v = old ] && L=ab/libj2p_batch_old.so
+    J2P_LIBRARY=$L timeout 300 python tools/batch_prealloc.py 192 8 2>/dev/null | grep ring | sed "s/\"outputs\"/\"streams\": \"$v\", \"outputs\"/"
+  done | tee $O/r05_batch_streams.jsonl
+  ( timeout 600 python -m pytest tests/test_batch_gpu.py tests/test_baseline_configs_gpu.py -q --timeout 600 -m gpu -k "batch" ) 2>&1 | grep -E "passed|failed"
+  ;;
 esac
