@@ -542,22 +542,14 @@ def single_gpu(a, j, synth, local_rank):
         solver.debug_option(j.J2P_OPT_NORM_IN_PROJECT, a.norm_in_project)
     del planes
     ranks = Ranks(0, 1, local_rank, False)
-    # (a solver that iterates with ONE launch per iteration — k_iterate, one-channel planes up to 8 Mpixel — has no two
-    # phase kernels to bracket with events, and the events would put it back into the two-launch form)
     launches = solver.launches_per_iteration()
     elapsed, g_ms, p_ms, samples = time_steps(ranks, solver.reset, lambda: solver.run(its), solver.sync, a.warmup, a.steps,
-                                              solver if launches > 1 else None, a.timing_every)
+                                              solver, a.timing_every)
     px = W * H
     value = px * its * a.steps / elapsed / 1e6
     # the plane the LAST timed step left behind (every step is a whole solve from iteration 0), against the reference's
     parity = parity_object(plane_digest(solver.download(0)), W, H, its, seed)
     per_kernel = per_kernel_roofline(px, px, g_ms, p_ms)
-    if launches == 1:
-        it_ms = elapsed / a.steps / its * 1e3
-        gbs = px * BYTES_ITERATION / (it_ms * 1e-3) / 1e9
-        per_kernel = {"k_iterate": {"avg_launch_ms": round(it_ms, 4), "algorithmic_bytes_per_launch": px * BYTES_ITERATION,
-                                    "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                    "what": "projection(k) + gradient(k + 1) in one launch; duration = wall clock per iteration"}}
     traffic, traffic_src = pmc_traffic() if not a.size else (None, None)
     out = {
         "metric": "Mpixel-iterations/sec on 4K Y-plane", "value": round(value, 1),

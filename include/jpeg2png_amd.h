@@ -103,8 +103,7 @@ void j2p_pool_trim(void);
  * schedules).  Only between iterations. */
 #define J2P_OPT_NORM_FOLD     1   /* 1 (default for band solvers and for whole canvases up to 2.5 Mpixel): level 1 of the
                                      ||g|| reduction runs inside the gradient kernel (its last-arriving wavefronts);
-                                     0: separate reduction kernel; 2 (whole canvases): the gradient launch's last
-                                     workgroup reduces the partials as they arrive — same bits */
+                                     0: separate reduction kernel — same bits */
 #define J2P_OPT_JOINT_INWAVE  2   /* 1: all channels of a joint image in one wavefront; 0 (default): one wavefront
                                      per channel.  Environment J2P_JOINT_INWAVE sets the default at create time */
 #define J2P_OPT_NORM_IN_PROJECT 4 /* 1 (needs NORM_FOLD): the gradient kernel leaves per-tile-row sums and every wavefront of
@@ -115,9 +114,6 @@ void j2p_pool_trim(void);
                                      create and reset (environment J2P_NT_SCOPE=solver: this solver's own only) */
 #define J2P_OPT_MIXED_PROJECT 6   /* 1 (default): canvases up to 1 Mpixel project all channels in ONE launch whatever their
                                      sampling; 0: one launch per sampling class, as large canvases do */
-#define J2P_OPT_FUSE 7             /* 1 (experiments build only; measured slower everywhere, profiles/r05_single_launch.jsonl): one launch per
-                                     iteration — projection(k) and gradient(k + 1) in one grid, ordered by per-block-row counters
-                                     (one full-resolution channel covering a whole canvas); 0 (default): two launches */
 int j2p_solver_debug_option(j2p_solver *s, int option, int value);
 
 /* The checked build (the analogue of the reference's DEBUG=1, whose pixel indexer p() asserts every access,
@@ -138,8 +134,8 @@ int j2p_solver_trace(j2p_solver *s, int on, unsigned long long *host_out, unsign
 int j2p_solver_canvas(const j2p_solver *s, unsigned *W, unsigned *H);
 int j2p_solver_band(const j2p_solver *s, unsigned *row_begin, unsigned *row_end);
 
-/* kernel launches per iteration of an unlogged j2p_solver_run(): 1 = projection(k) and gradient(k + 1) share a launch
- * (J2P_OPT_FUSE), 2 = gradient and projection with ||g|| reduced inside them, 3 = with a reduction launch in between */
+/* kernel launches per iteration of an unlogged j2p_solver_run(): 2 = gradient and projection with ||g|| reduced inside
+ * them, 3 = with a reduction launch in between */
 int j2p_solver_launches_per_iteration(const j2p_solver *s, unsigned *n);
 
 /* back to iteration 0 from the inputs that are already resident in HBM */
@@ -169,6 +165,9 @@ int j2p_solver_phase_project(j2p_solver *s);
  * straight after phase_project; the EDGES part needs the neighbours' rows and may go to another
  * stream (NULL = the solver's).  Once the solver's stream has been made to wait for the EDGES
  * part, j2p_solver_phase_rowsums() finishes the phase (partials_local is valid after it). */
+/* (Both split forms measured slower than whole phases wherever tried — DESIGN.md section 10 — and answer only in the
+ * experiments build, -DJ2P_EXPERIMENTS: j2p_experiments_build() == 1; the release library returns J2P_ESTATE.) */
+int j2p_experiments_build(void);
 #define J2P_GRADIENT_INTERIOR 1
 #define J2P_GRADIENT_EDGES    2
 int j2p_solver_phase_gradient_part(j2p_solver *s, int part, void *stream);
@@ -271,7 +270,7 @@ int j2p_solver_link_bands(j2p_solver *s, const j2p_band_links *links);   /* NULL
  *            (default) | root | collector | counter: how a band's projection learns that every band's gradient has
  *            finished (events, or — counter — a value in host memory the kernels count up, hipStreamWaitValue64);
  *   "copy"   round 3's schedule — a copy kernel pulls the neighbours' edge rows, one band reduces ||g|| for all
- *            (J2P_TILED_NORM=all: every band for itself) — kept as the cross-check of "direct" and for canvases taller
+ *            (experiments build only, J2P_TILED_NORM=all: every band for itself) — kept as the cross-check of "direct" and for canvases taller
  *            than 16384 rows;
  *   "rccl"   (the candidate without peer access) ncclAllGather + grouped ncclSend / ncclRecv on the band's own stream, one
  *            communicator per band from ncclCommInitAll, librccl loaded with dlopen (J2P_RCCL_LIBRARY names another

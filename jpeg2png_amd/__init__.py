@@ -83,9 +83,9 @@ C_ABI_SYMBOLS = [
     "j2p_solver_global_rowsums", "j2p_solver_link_bands", "j2p_tiled_exchange",
     "j2p_batch_create", "j2p_batch_destroy", "j2p_batch_submit", "j2p_batch_wait",
     "compute", "j2p_compute", "j2p_compute_tiled", "j2p_compute_timing", "j2p_debug_fail_run_after", "j2p_solver_launches_per_iteration", "j2p_solver_timing_overhead",
-    "j2p_debug_build", "j2p_solver_debug_violations", "j2p_solver_trace", "j2p_division_exhaustive",
+    "j2p_debug_build", "j2p_experiments_build", "j2p_solver_debug_violations", "j2p_solver_trace", "j2p_division_exhaustive",
 ]
-J2P_OPT_NORM_FOLD, J2P_OPT_JOINT_INWAVE, J2P_OPT_NORM_IN_PROJECT, J2P_OPT_NT_GRADIENT, J2P_OPT_MIXED_PROJECT, J2P_OPT_FUSE = 1, 2, 4, 5, 6, 7
+J2P_OPT_NORM_FOLD, J2P_OPT_JOINT_INWAVE, J2P_OPT_NORM_IN_PROJECT, J2P_OPT_NT_GRADIENT, J2P_OPT_MIXED_PROJECT = 1, 2, 4, 5, 6
 
 _lib = None
 
@@ -236,6 +236,12 @@ def _check(rc):
 def debug_build():
     """True when the loaded library was compiled with -DJ2P_DEBUG (address checks in the phase kernels)"""
     return bool(load_library().j2p_debug_build())
+
+
+def experiments_build():
+    """True when the loaded library is the experiments build (-DJ2P_EXPERIMENTS): the schedules that lost their
+    measurements — split phases among them — answer only there"""
+    return bool(load_library().j2p_experiments_build())
 
 
 def device_count():
@@ -395,7 +401,7 @@ class Solver:
         return p.value
 
     def launches_per_iteration(self):
-        """kernel launches per iteration of an unlogged run (1: the single-launch iteration, k_iterate)"""
+        """kernel launches per iteration of an unlogged run (2, or 3 with a reduction launch between the phases)"""
         n = ctypes.c_uint()
         _check(self._lib.j2p_solver_launches_per_iteration(self._h, ctypes.byref(n)))
         return n.value
@@ -578,9 +584,16 @@ class Batch:
         if bits:
             # (out: a caller's own RGB array, reused between jobs — nothing is then mapped or faulted in while other jobs'
             # kernels run, which costs those a stalled launch each time)
+            # (the C side writes height * width * 3 samples of bits / 8 bytes: anything else is a heap overflow or a
+            # half-written array, so it is an error here, not an assert that -O strips)
+            if bits not in (8, 16):
+                raise J2PError("bits must be 8 or 16")
             if out is None:
                 out = np.empty((height, width, 3), dtype=np.uint8 if bits == 8 else ">u2")
-            assert out.shape == (height, width, 3) and out.flags["C_CONTIGUOUS"]
+            if not (isinstance(out, np.ndarray) and out.shape == (height, width, 3) and out.flags["C_CONTIGUOUS"]
+                    and out.flags["WRITEABLE"] and out.dtype.itemsize == bits // 8 and out.dtype.kind in "ui"):
+                raise J2PError(f"out must be a writeable C-contiguous ({height}, {width}, 3) array of "
+                                           f"{bits // 8}-byte integers for bits = {bits}")
             job.out_bits, job.out_w, job.out_h = bits, width, height
             job.out_rgb = out.ctypes.data
         else:

@@ -17,9 +17,14 @@
 #include "jpeg2png_amd.h"
 #include "jpeg2png_amd_compute.h"
 
-/* iterations per device round-trip: keeps the progress bar and the CSV log moving
- * without a host sync per iteration (SURVEY.md §7 hard part 8) */
-#define J2P_CHUNK 32u
+/* Iterations per device round trip WHEN SOMEBODY IS WATCHING (a progress bar or a CSV log: compute.c:428,449-452 tick
+ * once per iteration, in real time).  A host sync per iteration would cost a small image most of its speed and a
+ * fixed chunk moves the bar of the default `-i 50` twice; so chunks follow the clock: one iteration each at first,
+ * then a sixth of the iterations done so far (every chunk ~1/6 of the time elapsed: the bar of `-i 50` moves ~24
+ * times, 4096^2 `-i 500` syncs ~36 times = under 1 % of its 60 ms), never more than ~50 ms worth or J2P_CHUNK_MAX
+ * (the row buffer).  With neither a bar nor a log the whole loop goes to the device queue at once. */
+#define J2P_CHUNK_MAX 256u
+#define J2P_CHUNK_MS 50.0
 
 /* stands in for `omp critical(progressbar)` (compute.c:450): compute() may be entered from
  * several host threads at once (jpeg2png.c:147,330) and they share one progress bar */
@@ -195,18 +200,29 @@ static int compute_on(unsigned nband, const int devices[], unsigned nchannel, st
                 if(cw != W || ch != H) { j2p_set_last_error("canvas size mismatch between the host and the solver"); rc = J2P_ESTATE; goto out; }
         }
         const int want_log = log && log->f && logger_log;
-        j2p_log_row rows[J2P_CHUNK];
+        j2p_log_row rows[J2P_CHUNK_MAX];
         unsigned done = 0;
+        const double t_loop = now_ms();
         while(done < iterations) {
                 unsigned n = iterations - done;
                 /* nothing to report between chunks: the whole loop goes to the device queue at once */
-                if(n > J2P_CHUNK && (want_log || pb)) { n = J2P_CHUNK; }
+                if(want_log || pb) {
+                        unsigned chunk = done / 6;
+                        if(done) {
+                                const double per_it = (now_ms() - t_loop) / (double)done;
+                                const double most = per_it > 0. ? J2P_CHUNK_MS / per_it : (double)J2P_CHUNK_MAX;
+                                if((double)chunk > most) { chunk = (unsigned)most; }
+                        }
+                        if(chunk > J2P_CHUNK_MAX) { chunk = J2P_CHUNK_MAX; }
+                        if(chunk < 1) { chunk = 1; }
+                        if(n > chunk) { n = chunk; }
+                }
                 rc = t ? j2p_tiled_run(t, n, want_log ? rows : NULL) : j2p_solver_run(s, n, want_log ? rows : NULL);
                 if(rc == J2P_OK && !want_log && pb) { rc = t ? j2p_tiled_sync(t) : j2p_solver_sync(s); }
                 if(rc != J2P_OK) { break; }
                 for(unsigned i = 0; i < n && (log || pb); i++) {
                         if(log) { log->iteration = done + i; }                     /* compute.c:428 */
-                        if(want_log) { logger_log(log, rows[i % J2P_CHUNK].objective, rows[i % J2P_CHUNK].prob_dist, rows[i % J2P_CHUNK].tv, rows[i % J2P_CHUNK].tv2); }
+                        if(want_log) { logger_log(log, rows[i].objective, rows[i].prob_dist, rows[i].tv, rows[i].tv2); }
                         if(pb && progressbar_inc) {
                                 pthread_mutex_lock(&progress_lock);
                                 progressbar_inc(pb);                               /* compute.c:449-452 */

@@ -250,6 +250,10 @@ struct Geo {
         // edge ones: 0, nseg - 1).  Plain arithmetic on kernel arguments: a table in memory would put two dependent
         // loads in front of every wavefront's first row fetch
         unsigned seg_off, seg_mul;
+        // how a gradient launch's workgroups map to strips and rows (grad_item): units (workgroups' worth of whole tile
+        // rows) and tile rows of the launch, and the shares (in 1/256) of every XCD's run that are dealt as half and as
+        // quarter tile rows
+        unsigned units, ntr_launch, zone_b, zone_c;
 #ifdef J2P_TRACE
         unsigned long long *trace;   // TraceRec buffer (record 0 unused) or NULL
         unsigned trace_cap, trace_seq, trace_base;
@@ -290,11 +294,6 @@ struct GradArgs {
         unsigned fold_phase;    // 0 / 1: the iteration's parity, carried in the SIGN BIT of every partial of a folding launch (fold_tile_row)
         unsigned fold_rows;     // tile rows this launch completes
         unsigned ntr_global;    // tile rows of the whole canvas (length of the tree's input)
-        // whole canvases: non-NULL = no reduction launch between the phases and no tickets either: the grid has one more row
-        // of workgroups whose first workgroup — dispatched last, so every strip is at least on its way — waits for the
-        // partials to land (their sign bits carry the iteration's parity, see fold_tile_row), sums them exactly as
-        // k_norm_whole would and writes ||g|| here (norm_reducer)
-        float *reduce_norm;     // [channel]
         // linked bands: where every tile row's sum also goes, in DEVICE memory (one wavefront per tile row reads it; as
         // 272 bytes of kernel arguments it cost every launch of every solver 0.5 us, same-box A/B); NULL = no push
         const RowsumPush *push;
@@ -325,28 +324,6 @@ struct ProjArgs {
         // band's gradient launch has finished, it needs ||g||.)  NULL = nobody to tell.
         float *halo_up[kMaxCh];      // row 0 of the lower halo rows of the band above
         float *halo_down[kMaxCh];    // row 0 of the upper halo rows of the band below
-};
-
-// The single-launch iteration (k_iterate): projection(k) and gradient(k + 1) in ONE grid.  ||g|| is the only device-wide
-// dependency of the solver (compute.c:209-211): gradient(k + 1) of a strip needs x_{k+1} — and the prob state — only on
-// the block rows its rows t0 - 2 ... t1 + 1 touch, so a gradient workgroup can start as soon as THOSE block rows have
-// been projected, while the projection's last workgroups are still running; the launch boundary that remains is the one
-// the norm needs.
-//   * Work is CLAIMED, not mapped from blockIdx: a workgroup draws a ticket from the queue of the XCD it runs on (XCC id),
-//     projection items first; it takes a gradient item only after it has seen every queue's projection items handed out —
-//     to workgroups that are running, hence finish, since projection waits for nothing.  So a waiting gradient wavefront
-//     can never keep the workgroup it waits for from starting: no assumption about dispatch order or placement
-//     (MI355X_MICROARCH.md: "HIP promises nothing about dispatch order ... placement-independent protocols only").
-//   * Hand-over: projection stores x_{k+1} and the prob state write-through (sc1), waits for the stores' acknowledgement and
-//     adds one to its block row's counter; a gradient wavefront polls the counters of its block rows (monotonic over
-//     launches: target = wavefronts per block row x launches so far) and reads x_{k+1} and the prob state with sc1 loads.
-struct FuseArgs {
-        unsigned *head;         // [16]: tickets of THIS launch, [q] projection, [8 + q] gradient queue of XCD q; zero at launch
-        unsigned *head_next;    // [16]: the next launch's; zeroed by this one (nobody else touches it meanwhile)
-        unsigned *row_done;     // [block rows]: projection wavefronts finished, summed over the launches since reset
-        unsigned done_target;   // what a finished block row shows during this launch
-        unsigned np_wg, ng_wg;  // workgroups of the projection part / of the gradient part
-        unsigned g_gx;          // gradient workgroups per row segment
 };
 
 // rows per norm partial on canvases large enough to fill the chip: the granularity of the GPU-count invariant
@@ -455,29 +432,6 @@ __device__ __forceinline__ V buf_load(__amdgpu_buffer_rsrc_t r, unsigned lane_of
 {
         if constexpr(sizeof(V) == 8) { return buf_load2<NT>(r, lane_off, row_off); }
         else { return buf_load1<NT>(r, lane_off, row_off); }
-}
-// The same accesses at AGENT scope (the `sc1` bit, aux = 16): a store is written through to the memory side and leaves
-// nothing dirty in this XCD's L2, a load bypasses the CU's L1 — together the form in which data written by one workgroup
-// of a launch can be read by another workgroup of the SAME launch, whichever XCD either runs on (MI355X_MICROARCH.md,
-// "inter-workgroup visibility": L2s are kept coherent for what has reached the memory side, L1s are not).  Used by the
-// single-launch iteration (k_iterate): projection workgroups hand x_{k+1} and the prob state to gradient workgroups.
-constexpr int kAuxSc1 = 16;
-template <class V>
-__device__ __forceinline__ V buf_load_sc1(__amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned row_off)
-{
-        if constexpr(sizeof(V) == 8) {
-                typedef unsigned v2u __attribute__((ext_vector_type(2)));
-                return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_off, (int)row_off, kAuxSc1));
-        } else {
-                return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)row_off, kAuxSc1));
-        }
-}
-__device__ __forceinline__ void buf_store4_sc1(float a, float b, float c, float d, __amdgpu_buffer_rsrc_t r, unsigned lane_off, unsigned row_off)
-{
-        typedef unsigned v4u __attribute__((ext_vector_type(4)));
-        const v4u raw = v4u{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c),
-                            __builtin_bit_cast(unsigned, d)};
-        __builtin_amdgcn_raw_buffer_store_b128(raw, r, (int)lane_off, (int)row_off, kAuxSc1);
 }
 
 // Everything below is written once for a lane's PIXEL VECTOR V: v2f = two neighbouring columns per lane, the arithmetic
@@ -1193,54 +1147,6 @@ __device__ __forceinline__ void fold_arrive(const GradArgs &a, unsigned tr, unsi
         if(lane == 0) { __hip_atomic_store(a.done_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 
-// ---------------------------------------------------------------------------
-// The norm reduction as the LAST WORKGROUP of the gradient launch (GradArgs::reduce_norm): k_norm_whole's arithmetic —
-// strip_sum per tile row, then the padded pairwise tree — on partials that are still arriving.  No ticket, no
-// acknowledgement wait and no kernel boundary synchronise it: a slot whose sign bit does not carry this iteration's
-// parity has not been written yet and is read again.  Workgroups are dispatched in order, so when this one runs every
-// strip has been dispatched: it cannot keep anybody from starting.  buf: kFoldMaxRows doubles of LDS.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ double strip_sum_arriving(const double *p, unsigned n, unsigned phase)
-{
-        // strip_sum's order: element i belongs to running sum i % 8, the eight combined pairwise
-        double s[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
-        for(unsigned t = 0; t < n; t += 8) {
-                double v[8];
-                bool landed;
-                do {
-                        landed = true;
-#pragma unroll
-                        for(unsigned j = 0; j < 8; j++) {
-                                v[j] = __hip_atomic_load(p + (t + j < n ? t + j : t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                landed = landed && (unsigned)(__builtin_bit_cast(unsigned long long, v[j]) >> 63) == phase;
-                        }
-                } while(!landed);
-#pragma unroll
-                for(unsigned j = 0; j < 8; j++) {
-                        if(t + j < n) { s[j] += __builtin_fabs(v[j]); }
-                }
-        }
-        return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
-}
-
-__device__ __forceinline__ void norm_reducer(const GradArgs &a, double *buf)
-{
-        const unsigned ntr = a.fold_rows, ntx = a.geo.ntx, T = blockDim.x;
-        unsigned P = 1;
-        while(P < ntr) { P <<= 1; }
-        for(unsigned c = 0; c < a.nch_total; c++) {
-                const double *part = a.part_g2 + (size_t)c * ntr * ntx;
-                for(unsigned r = threadIdx.x; r < P; r += T) { buf[r] = r < ntr ? strip_sum_arriving(part + (size_t)r * ntx, ntx, a.fold_phase) : 0.; }
-                for(unsigned st = P >> 1; st > 0; st >>= 1) {            // tree_sum_lds
-                        __syncthreads();
-                        for(unsigned i = threadIdx.x; i < st; i += T) { buf[i] = buf[i] + buf[i + st]; }
-                }
-                __syncthreads();
-                if(threadIdx.x == 0) { a.reduce_norm[c] = sqrtf((float)buf[0]); }   // compute.c:206
-                __syncthreads();
-        }
-}
-
 #ifndef J2P_GRAD_WAVES
 #define J2P_GRAD_WAVES 4
 #endif
@@ -1277,49 +1183,37 @@ constexpr int kGradWaves3 = 2;    // ... the three-channels-in-one-wavefront sch
 // 4096^2 Y (288 MiB): level 1, 137 -> 127 us per iteration; 16384x2048 (576 MiB, the planes x_k, x_{k-1} are exactly
 // 256 MiB): level 3, 292 -> 240 us; when everything fits the hint costs 1-2 %.
 // PX: columns per lane (2: packed arithmetic, 128-column strips; 1: 64-column strips, see the pixel-vector overloads above)
-// The body of the gradient phase for the workgroup's strips: (bx, bseg) = strip group and row segment; xchg / fold_buf = the
-// workgroup's LDS.  FUSED (k_iterate only, one 1x1 channel): x_k — which projection workgroups of the SAME launch are
-// writing — and the prob state are read with sc1 loads, after the block rows they lie in have reported in (FuseArgs).
-template <int NCH, bool TGV, bool LOG, int J, int NT, int PX, bool FUSED, class V>
-__device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, double *fold_buf, unsigned bx, unsigned bseg, const FuseArgs *fz)
+// What one wavefront of a gradient launch works on (wave-uniform; grad_item): strip `wcol`, band-local target rows
+// [t0, t0 + nrows) of tile row `tr` — the whole tile row (kind 0), one of its halves (kind 1) or quarters (kind 2; `sub`
+// says which).  Half and quarter items exist so that the LAST workgroups of a launch are short: a launch is as long as its
+// last wavefront, and a whole tile row is a wavefront life of ~17 us at 4096^2 (profiles/r06_wave_trace.jsonl).
+struct StripItem {
+        int wcol, t0, nrows, tile0;
+        unsigned tr;
+        int kind, sub;
+        bool active;            // false: beyond the last strip / the band's last row — nothing to march, but the wavefront
+                                // still takes part in its workgroup's hand-over
+};
+
+// The march of one wavefront over its item's rows: FISTA point, gradient, g stored; the sums of g^2 come back per lane in
+// the tile row's canonical order — lo = a0 + a1, hi = a2 + a3 with a_i the running sum over the tile row's i-th group of
+// FOUR rows (an item that covers only part of the tile row leaves the others 0) — so that the partial of a tile row,
+// (a0 + a1) + (a2 + a3) summed over the lanes, has the same bits whether one, two or four wavefronts marched it.
+// xchg = the workgroup's LDS (joint images).
+template <int NCH, bool TGV, bool LOG, int J, int NT, int PX, class V>
+__device__ __forceinline__ void march_rows(const GradArgs &a, V *xchg, const StripItem &it, double (&g2_lo)[NCH], double (&g2_hi)[NCH],
+                                           double &tv_acc, double &tv2_acc, unsigned long long &tr_data)
 {
-        static_assert(!FUSED || (NCH == 1 && J == 1 && PX == 2 && !LOG && NT == 0), "the single-launch iteration: one channel, packed strips, no logging");
         constexpr int kCols = 64 * PX - 4;                      // output columns per strip: 2 halo columns on each side
         const int lane = (int)threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);   // uniform: keeps row/strip arithmetic scalar
-        const int wcol = J == 1 ? (int)bx * (int)(blockDim.x >> 6) + wave : (int)bx;   // J == 1: blockDim.x / 64 strips per workgroup
+        const int wcol = it.wcol;
         const int cbase = J == 1 ? 0 : wave;                    // first channel of this wavefront
-        if(wcol >= (int)a.geo.ntx) { return; }
-#ifdef J2P_TRACE
-        const unsigned long long tr_start = trace_now();
-        unsigned long long tr_data = 0;
-#ifdef J2P_TRACE_CLOCK
-        const unsigned long long tr_core = clock64();
-#endif
-#endif
         const int W = (int)a.geo.W, H = (int)a.geo.H;
         const int rows = (int)a.geo.rows, row0 = (int)a.geo.row0;
-        const int t0 = (int)(bseg * a.geo.rpw);                // band-local target rows [t0, t1)
-        const int t1 = t0 + (int)a.geo.rpw < rows ? t0 + (int)a.geo.rpw : rows;
-#ifdef J2P_EXP_FUSE_NOWAIT
-        if constexpr(false) {                                    // (timing experiment: what the waiting costs; results wrong)
-#else
-        if constexpr(FUSED) {
-#endif
-                // rows t0 - 2 ... t1 + 1 of x_{k+1} (and the prob state of rows t0 ... t1 - 1) come from THIS launch's projection
-                // workgroups: wait until the 8-row block rows they lie in have reported in.  Lane i polls block row b_lo + i
-                // (a strip of <= 16 rows touches at most 4); relaxed agent-scope loads, a short sleep between polls.
-                const int last_row = rows - 1;
-                const int r_lo = t0 - 2 < 0 ? 0 : t0 - 2, r_hi = t1 + 1 > last_row ? last_row : t1 + 1;
-                const int b_lo = r_lo >> 3, nb = (r_hi >> 3) - b_lo + 1;
-                for(;;) {
-                        bool ok = true;
-                        if(lane < nb) { ok = __hip_atomic_load(fz->row_done + b_lo + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= fz->done_target; }
-                        if(__builtin_amdgcn_ballot_w64(!ok) == 0) { break; }
-                        __builtin_amdgcn_s_sleep(4);
-                }
-                asm volatile("" ::: "memory");                   // (the row loads below stay below)
-        }
+        const int t0 = it.t0;                                   // band-local target rows [t0, t1)
+        const int t1 = t0 + it.nrows < rows ? t0 + it.nrows : rows;
+        const int tile0 = it.tile0;
         // Strip i loads columns [kCols i, kCols i + 64 PX); its two outermost columns on each side are halo — except
         // at the image's left and right edges, where the neighbour beyond the edge contributes nothing anyway, so the
         // first strip also owns its left halo lanes and the last strip its right ones: n strips cover kCols n + 4
@@ -1387,12 +1281,7 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
                 for(int c = 0; c < NCH; c++) {
                         J2P_CHK(a.ch[cbase + c], x_read[0], reinterpret_cast<const char *>(a.ch[cbase + c].xcur + roff) + xoff, 4 * PX, 101);
                         J2P_CHK(a.ch[cbase + c], x_read[1], reinterpret_cast<const char *>(a.ch[cbase + c].xprev + roff) + xoff, 4 * PX, 102);
-#ifdef J2P_EXP_FUSE_PLAINLOAD
-                        if constexpr(false) { }                  // (timing experiment: what the L1-bypassing loads cost)
-#else
-                        if constexpr(FUSED) { rc[c] = buf_load_sc1<V>(res_cur[c], xoff, row_off); }
-#endif
-                        else { rc[c] = buf_load<false, V>(res_cur[c], xoff, row_off); }
+                        rc[c] = buf_load<false, V>(res_cur[c], xoff, row_off);
                         rp[c] = buf_load<false, V>(res_prev[c], xoff, row_off);
                 }
         };
@@ -1460,12 +1349,7 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
                                 const float *prow = k.pg + (size_t)((unsigned)gt - k.crow0) * k.cw;
                                 J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + xoff, 4 * PX, 103);
                                 (void)prow;
-#ifdef J2P_EXP_FUSE_PLAINLOAD
-                                if constexpr(false) { }
-#else
-                                if constexpr(FUSED) { pv[c] = buf_load_sc1<V>(res_pg[c], xoff, (unsigned)(gt - row0 - grad_base) * k.cw * 4u); }
-#endif
-                                else { pv[c] = buf_load<(NT >= 2), V>(res_pg[c], xoff, (unsigned)(gt - row0 - grad_base) * k.cw * 4u); }
+                                pv[c] = buf_load<(NT >= 2), V>(res_pg[c], xoff, (unsigned)(gt - row0 - grad_base) * k.cw * 4u);
                                 continue;
                         }
                         unsigned cr;
@@ -1477,10 +1361,7 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
                         }
                         const float *prow = k.pg + (size_t)(cr - k.crow0) * k.cw;
                         J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][0], 4, 104);
-                        if constexpr(FUSED) {
-                                pv[c] = v2f{__hip_atomic_load(reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                            __hip_atomic_load(reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
-                        } else if constexpr(PX == 2) {
+                        if constexpr(PX == 2) {
                                 J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][1], 4, 105);
                                 pv[c] = v2f{*reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][0]),
                                             *reinterpret_cast<const float *>(reinterpret_cast<const char *>(prow) + (unsigned)p_col[c][1])};   // two dword loads whatever the sampling: no branch
@@ -1490,12 +1371,19 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
                 }
         };
 
-        double tv_acc = 0., tv2_acc = 0.;
-        double g2[NCH];                                  // sum of g*g over the strip's rows (one 16-row tile row)
+        double g2[NCH];                                  // sum of g*g over the running group of four rows
 #pragma unroll
         for(int c = 0; c < NCH; c++) { g2[c] = 0.; }
-        const size_t ntiles_row = a.geo.ntx;
-        const size_t nparts = (size_t)((rows + (int)a.geo.rpw - 1) / (int)a.geo.rpw) * ntiles_row;
+        // a group of four rows is complete (target row t was its last): into the tile row's lower or upper pair sum
+        auto close_group = [&](int t) {
+                const bool upper = ((t - tile0) & 8) != 0;       // (wave-uniform)
+#pragma unroll
+                for(int c = 0; c < NCH; c++) {
+                        if(upper) { g2_hi[c] += g2[c]; }
+                        else { g2_lo[c] += g2[c]; }
+                        g2[c] = 0.;
+                }
+        };
         constexpr int R = NCH == 1 ? (J == 1 && !LOG && PX == 2 ? (NT >= 1 ? kBigRing : kHotRing) : kRing) : 3;
 
         // The march over the strip's rows, compiled twice: once general, once for strips that touch neither an
@@ -1600,6 +1488,13 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
                                                 add_elements(g2[c], g * g);      // compute.c:203
                                         }
                                 }
+                                // t0 is a multiple of 4 and the trip of phase 1 handles t = t0 - 1 + 4 i: with a ring of four
+                                // the place where groups end is known at compile time
+                                if constexpr(R == 4) {
+                                        if constexpr(P == 1) { close_group(t); }
+                                } else {
+                                        if(((t - t0) & 3) == 3) { close_group(t); }
+                                }
                         }
                 };
 
@@ -1643,37 +1538,92 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
                 else if(__builtin_amdgcn_readfirstlane(seg_free ? 1 : 0)) { march(MarchTag<true, false>{}); }
                 else { march(MarchTag<false, false>{}); }
         }
-        // One partial per strip and tile row (16 rows; 8 or 4 on small canvases) — a segment IS one tile row — the granularity of the
-        // GPU-count invariant norm reduction; then the strip reports in (fold_arrive) and, if it is the last
-        // of its tile row / of the launch, finishes the reduction.
-        {
-                const unsigned tr = (unsigned)t0 / a.geo.rpw;
+        // (rows per strip that are no multiple of four — J2P_RPW experiments only — leave a group open)
+        if(((t1 - t0) & 3) != 0) { close_group(t1 - 1); }
+#ifdef J2P_TRACE
+        (void)tr_data;
+#endif
+}
+
+// One wavefront of a gradient launch: march the item's rows, then turn the per-lane sums of g^2 into the partial of
+// (tile row, strip) — one partial per strip and tile row (16 rows; 8 or 4 on small canvases), the granularity of the
+// GPU-count invariant norm reduction — and report in (fold_arrive); the last strip of a tile row / of the launch to do so
+// finishes the reduction.  The wavefronts of a half / quarter item hand their sums to the workgroup's wavefront that
+// marched the tile row's first rows, through LDS (fold_buf).
+template <int NCH, bool TGV, bool LOG, int J, int NT, int PX, class V>
+__device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, double *fold_buf, const StripItem &it)
+{
+        static_assert(NCH == 1 || J == 1, "");
+        const int lane = (int)threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        const int cbase = J == 1 ? 0 : wave;
+#ifdef J2P_TRACE
+        const unsigned long long tr_start = trace_now();
+#ifdef J2P_TRACE_CLOCK
+        const unsigned long long tr_core = clock64();
+#endif
+#endif
+        unsigned long long tr_data = 0;
+        double lo[NCH], hi[NCH], tv_acc = 0., tv2_acc = 0.;
 #pragma unroll
-                for(int c = 0; c < NCH; c++) {
-                        double v = g2[c];
-#pragma unroll
-                        for(int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); }
-                        // (a folding launch marks its partials with the iteration's parity, see fold_tile_row: the sign bit is SET
-                        // to it, whatever it was — a sum of squares is >= +0, and a NaN must not make the reader wait for ever)
-                        if(a.row_ticket || a.reduce_norm) {
-                                const unsigned long long bits = (__builtin_bit_cast(unsigned long long, v) & ~(1ull << 63)) | ((unsigned long long)a.fold_phase << 63);
-                                v = __builtin_bit_cast(double, bits);
-                        }
-                        if(lane == 0) { publish_double(&a.part_g2[(cbase + c) * nparts + (size_t)tr * ntiles_row + wcol], v); }
-                }
-                if(a.row_ticket) { fold_arrive(a, tr, (unsigned)NCH, nparts, fold_buf, lane); }
-        }
+        for(int c = 0; c < NCH; c++) { lo[c] = hi[c] = 0.; }
+        if(it.active) { march_rows<NCH, TGV, LOG, J, NT, PX, V>(a, xchg, it, lo, hi, tv_acc, tv2_acc, tr_data); }
         if(LOG) {
 #pragma unroll
                 for(int off = 32; off > 0; off >>= 1) {
                         tv_acc += __shfl_down(tv_acc, off, 64);
                         tv2_acc += __shfl_down(tv2_acc, off, 64);
                 }
-                if(lane == 0 && cbase == 0) {
-                        const size_t w = (size_t)bseg * ntiles_row + wcol;
+        }
+        bool publisher = it.active;
+        if constexpr(NCH == 1 && J == 1) {
+                if(it.kind != 0) {
+                        // half items: wavefronts (0, 1) and (2, 3) of the workgroup share a strip; quarter items: all four do
+                        const int first = it.kind == 1 ? (wave & ~1) : 0;
+                        if(wave != first) {
+                                fold_buf[wave * 64 + lane] = lo[0] + hi[0];              // (one of the two is 0)
+                                if(LOG && lane == 0) { fold_buf[256 + 2 * wave] = tv_acc; fold_buf[257 + 2 * wave] = tv2_acc; }
+                        }
+                        __syncthreads();
+                        publisher = wave == first && it.active;
+                        if(publisher) {
+                                if(it.kind == 1) {
+                                        hi[0] = fold_buf[(wave + 1) * 64 + lane];
+                                        if(LOG) { tv_acc += fold_buf[256 + 2 * (wave + 1)]; tv2_acc += fold_buf[257 + 2 * (wave + 1)]; }
+                                } else {
+                                        lo[0] = lo[0] + fold_buf[64 + lane];
+                                        hi[0] = fold_buf[128 + lane] + fold_buf[192 + lane];
+                                        if(LOG) {
+#pragma unroll
+                                                for(int w = 1; w < 4; w++) { tv_acc += fold_buf[256 + 2 * w]; tv2_acc += fold_buf[257 + 2 * w]; }
+                                        }
+                                }
+                        }
+                }
+        }
+        if(publisher) {
+                const size_t ntiles_row = a.geo.ntx;
+                const size_t nparts = (size_t)((a.geo.rows + a.geo.rpw - 1) / a.geo.rpw) * ntiles_row;
+                const unsigned tr = it.tr;
+#pragma unroll
+                for(int c = 0; c < NCH; c++) {
+                        double v = lo[c] + hi[c];
+#pragma unroll
+                        for(int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); }
+                        // (a folding launch marks its partials with the iteration's parity, see fold_tile_row: the sign bit is SET
+                        // to it, whatever it was — a sum of squares is >= +0, and a NaN must not make the reader wait for ever)
+                        if(a.row_ticket) {
+                                const unsigned long long bits = (__builtin_bit_cast(unsigned long long, v) & ~(1ull << 63)) | ((unsigned long long)a.fold_phase << 63);
+                                v = __builtin_bit_cast(double, bits);
+                        }
+                        if(lane == 0) { publish_double(&a.part_g2[(cbase + c) * nparts + (size_t)tr * ntiles_row + it.wcol], v); }
+                }
+                if(LOG && lane == 0 && cbase == 0) {
+                        const size_t w = (size_t)tr * ntiles_row + it.wcol;
                         a.part_tv[2 * w] = tv_acc;
                         a.part_tv[2 * w + 1] = tv2_acc;
                 }
+                if(a.row_ticket) { fold_arrive(a, tr, (unsigned)NCH, nparts, fold_buf, lane); }
         }
 #ifdef J2P_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wavefront's stores have been acknowledged
@@ -1686,7 +1636,81 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
 
 // item l of n, dealt to 8 queues in contiguous runs (queue q holds items [chunk_base(n, q), chunk_base(n, q + 1))): what
 // "workgroup b runs on XCD b % 8" turns into when every XCD is to work on one contiguous region of the canvas
-__device__ __forceinline__ unsigned chunk_base(unsigned n, unsigned q) { return q * (n >> 3) + (q < (n & 7) ? q : (n & 7)); }
+__host__ __device__ __forceinline__ unsigned chunk_base(unsigned n, unsigned q) { return q * (n >> 3) + (q < (n & 7) ? q : (n & 7)); }
+
+// The order in which a gradient launch hands out its work.  The launch's (tile row, strip) pairs are numbered row-major;
+// a UNIT is four consecutive ones (J == 1: a workgroup's four wavefronts never idle because a row of strips is no multiple
+// of four — 33 strips at W = 4096 — and every workgroup gives each SIMD of its CU one wavefront) or — joint images, a
+// wavefront per channel — one.  Workgroup b runs on XCD b % 8 and the workgroups
+// of an XCD start in the order of their numbers, so every XCD gets a contiguous, row-major run of units — vertically
+// adjacent strips then meet in one L2 and their shared halo rows are fetched from HBM once — and deals the run in three
+// zones: the first units whole (one workgroup = 4 strips x the tile row's 16 rows), then a share zone_b / 256 as HALVES
+// (two workgroups per unit: 2 strips x 2 halves of 8 rows), the last zone_c / 256 as QUARTERS (four workgroups per unit:
+// 1 strip x 4 quarters of 4 rows).  The launch ends when its last wavefront does, and the wavefronts dispatched last are
+// then the short ones.  Zones change who marches which rows, never a bit of the result (march_rows).
+struct ZoneSplit {
+        unsigned whole, halves, quarters;       // units of the run
+        __host__ __device__ unsigned workgroups() const { return whole + 2 * halves + 4 * quarters; }
+};
+__host__ __device__ __forceinline__ ZoneSplit zone_split(unsigned units, unsigned zone_b, unsigned zone_c)
+{
+        ZoneSplit z;
+        z.quarters = (units * zone_c) >> 8;
+        z.halves = (units * zone_b) >> 8;
+        z.whole = units - z.halves - z.quarters;
+        return z;
+}
+// workgroups a gradient launch needs: 8 x the longest run's
+__host__ __device__ __forceinline__ unsigned grad_grid(unsigned n /* units */, unsigned zone_b, unsigned zone_c)
+{
+        unsigned most = 0;
+        for(unsigned q = 0; q < 8; q++) {
+                const unsigned w = zone_split(chunk_base(n, q + 1) - chunk_base(n, q), zone_b, zone_c).workgroups();
+                most = w > most ? w : most;
+        }
+        return 8 * most;
+}
+
+// workgroup -> item of the calling wavefront (everything wave-uniform); false: the workgroup has nothing to do
+template <int J>
+__device__ __forceinline__ bool grad_item(const Geo &g, unsigned b, int wave, StripItem &it)
+{
+        const unsigned q = b & 7, j = b >> 3;
+        const unsigned n = g.units;
+        const unsigned first = chunk_base(n, q);
+        const ZoneSplit z = zone_split(chunk_base(n, q + 1) - first, g.zone_b, g.zone_c);
+        unsigned u, strip_in_group;
+        int kind = 0, sub = 0;
+        if(j < z.whole) {
+                u = first + j;
+                strip_in_group = (unsigned)wave;
+        } else if(j < z.whole + 2 * z.halves) {
+                const unsigned jj = j - z.whole;
+                u = first + z.whole + (jj >> 1);
+                kind = 1;
+                strip_in_group = 2 * (jj & 1) + ((unsigned)wave >> 1);
+                sub = wave & 1;
+        } else if(j < z.workgroups()) {
+                const unsigned jj = j - z.whole - 2 * z.halves;
+                u = first + z.whole + z.halves + (jj >> 2);
+                kind = 2;
+                strip_in_group = jj & 3;
+                sub = wave;
+        } else {
+                return false;
+        }
+        const unsigned id = J == 1 ? 4 * u + strip_in_group : u;        // (tile row, strip) of the launch, row-major
+        const unsigned tr_launch = id / g.ntx;
+        it.tr = g.seg_off + tr_launch * g.seg_mul;
+        it.wcol = (int)(id - tr_launch * g.ntx);
+        it.kind = kind;
+        it.sub = sub;
+        it.tile0 = (int)(it.tr * g.rpw);
+        it.nrows = (int)(g.rpw >> kind);
+        it.t0 = it.tile0 + sub * it.nrows;
+        it.active = tr_launch < g.ntr_launch && it.t0 < (int)g.rows;
+        return true;
+}
 
 template <int NCH, bool TGV, bool LOG, int J = 1, int NT = 0, int PX = 2>
 __global__ __launch_bounds__((J == 1 ? 256 : 64 * J), (PX == 1 ? (J == 1 && !LOG ? 6 : 2) : NCH == 1 ? (J == 1 && !LOG ? (NT >= 1 ? kBigWaves : kHotWaves) : kGradWaves1) : NCH == 2 ? 3 : kGradWaves3))
@@ -1696,29 +1720,11 @@ void k_gradient(GradArgs a)
         static_assert(PX == 2 || NCH == 1, "one column per lane: one channel per wavefront");
         typedef typename std::conditional<PX == 2, v2f, float>::type V;
         __shared__ __attribute__((aligned(16))) V xchg[J == 1 ? 1 : 2 * J * 64 * 3];
-        __shared__ double fold_buf[kFoldMaxRows];               // the norm tree of the launch's last wavefront
-        // XCD-aware order (speed only): workgroup b runs on XCD b % 8, so give every XCD a contiguous,
-        // row-major run of (segment, strip-group) pairs — vertically adjacent strips then meet in one
-        // L2 and their shared halo rows are fetched from HBM once.  Bijective for any grid size.
-        unsigned bx = blockIdx.x, bseg = blockIdx.y;
-        // (reduce_norm: the grid's last row of workgroups is not strips — its first workgroup reduces ||g||)
-#ifdef J2P_EXPERIMENTS
-        const unsigned strip_rows = a.reduce_norm ? gridDim.y - 1 : gridDim.y;
-        if(blockIdx.y == strip_rows) {
-                if(blockIdx.x == 0) { norm_reducer(a, fold_buf); }
-                return;
-        }
-#else
-        const unsigned strip_rows = gridDim.y;
-#endif
-        {
-                const unsigned nwg = gridDim.x * strip_rows, b = blockIdx.y * gridDim.x + blockIdx.x;
-                const unsigned xcd = b & 7, q = nwg >> 3, rem = nwg & 7;
-                const unsigned l = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
-                bx = l % gridDim.x;
-                bseg = a.geo.seg_off + (l / gridDim.x) * a.geo.seg_mul;
-        }
-        gradient_strip<NCH, TGV, LOG, J, NT, PX, false, V>(a, xchg, fold_buf, bx, bseg, nullptr);
+        __shared__ double fold_buf[kFoldMaxRows];               // the norm tree of the launch's last wavefront; sub-item hand-over
+        StripItem it;
+        const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+        if(!grad_item<J>(a.geo, blockIdx.x, wave, it)) { return; }
+        gradient_strip<NCH, TGV, LOG, J, NT, PX, V>(a, xchg, fold_buf, it);
 }
 
 // ---------------------------------------------------------------------------
@@ -2175,14 +2181,10 @@ struct __attribute__((aligned(16))) ProjShared {
 // 2: by the workgroup's FIRST wavefront, before anything else, and handed to the other three through LDS at the barrier
 // that publishes the quantisation tables anyway (bands of a row-tiled run: up to 1024 row sums, a quarter of the
 // loads and none of the registers of form 1 — the tree's values are dead before the row loads are issued)
-// FUSED (k_iterate only; one 1x1 channel that covers the canvas): `wg` of `nwg` is the workgroup's CLAIMED item — already
-// the position in the XCD-contiguous order — the new iterate and the prob state are stored write-through (sc1) and the
-// wavefront reports its block row in when those stores have been acknowledged (FuseArgs).
-template <bool LOG, int WS, int HS, int NT, int NIP, bool PTR = false, bool FUSED = false>
-__device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh, unsigned wg = blockIdx.x, unsigned nwg = gridDim.x,
-                                              const FuseArgs *fz = nullptr)
+template <bool LOG, int WS, int HS, int NT, int NIP, bool PTR = false>
+__device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
 {
-        static_assert(!FUSED || (WS == 1 && HS == 1 && !LOG && NT == 0), "the single-launch iteration: one full-resolution channel, no logging");
+        const unsigned wg = blockIdx.x, nwg = gridDim.x;
         float *const tp = sh.tp;
         float *const qs = sh.qs, *const qq = sh.qq, *const rqq = sh.rqq, *const rq = sh.rq;
         int &q_fast = sh.q_fast;
@@ -2194,7 +2196,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh,
 #endif
 #endif
 
-        const unsigned zi = FUSED ? 0u : blockIdx.z;
+        const unsigned zi = blockIdx.z;
         const int c = (int)a.chan_of_z[zi];
         const ChanDev &k = a.ch[c];
         const int lane = (int)threadIdx.x & 63;
@@ -2206,8 +2208,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh,
         // workgroup b runs on XCD b % 8: give every XCD a contiguous run of strips (as k_gradient does) — the eight
         // L2s then each stream one region of the planes instead of interleaving at 1 KB (68.8 -> 67.8 us at 4096^2)
         unsigned lstrip;
-        if constexpr(FUSED) { lstrip = wg * 4 + wave; }
-        else {
+        {
                 const unsigned b = wg, xcd = b & 7, q = nwg >> 3, rem = nwg & 7;
                 const unsigned l = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
                 lstrip = l * 4 + wave;                                // index within this launch
@@ -2252,7 +2253,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh,
                           ly0 + 8 <= a.geo.rows;
         // band instantiations: strips of the band's first / last block row also store into the neighbours' halo rows
         // (ProjArgs::halo_up / halo_down).  Wave-uniform pointers; NULL for every other strip.
-        constexpr bool PUSH = NIP == 2 && !FUSED;
+        constexpr bool PUSH = NIP == 2;
         float *push_up = nullptr, *push_down = nullptr;
         if constexpr(PUSH) {
                 if(ly0 < (unsigned)kHalo) { push_up = a.halo_up[c]; }
@@ -2510,20 +2511,8 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh,
                 if(bcov && ly0 + rr < a.geo.rows) {
                         float4 *dst = reinterpret_cast<float4 *>(k.xprev + (size_t)(ly0 + rr) * W + bx * 8);
                         J2P_CHK(k, x_own[1], dst, 32, 212);
-#ifdef J2P_EXP_FUSE_PLAINSTORE
-                        constexpr bool kThrough = false;         // (timing experiment: what the write-through stores cost)
-#else
-                        constexpr bool kThrough = FUSED;
-#endif
-                        if constexpr(kThrough) {
-                                const __amdgpu_buffer_rsrc_t rx = rows_from(k.xprev + (size_t)ly0 * W);
-                                const unsigned off = ((unsigned)rr * W + bx * 8) * 4u;
-                                buf_store4_sc1(v[0], v[1], v[2], v[3], rx, off, 0u);
-                                buf_store4_sc1(v[4], v[5], v[6], v[7], rx, off + 16u, 0u);
-                        } else {
                         dst[0] = make_float4(v[0], v[1], v[2], v[3]);
                         dst[1] = make_float4(v[4], v[5], v[6], v[7]);
-                        }
                         if constexpr(PUSH) {
                                 if(float *h = halo_copy_of(ly0 + rr)) {
 #pragma unroll
@@ -2582,17 +2571,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh,
                         float4 *dst = reinterpret_cast<float4 *>(k.pg + (size_t)(cy0 - k.crow0 + rr) * k.cw + bx * 8);
 #endif
                         J2P_CHK(k, pg, dst, 32, 214);
-#ifdef J2P_EXP_FUSE_PLAINSTORE
-                        constexpr bool kThroughP = false;
-#else
-                        constexpr bool kThroughP = FUSED;
-#endif
-                        if constexpr(kThroughP) {
-                                const __amdgpu_buffer_rsrc_t rpg = rows_from(k.pg + (size_t)(cy0 - k.crow0) * k.cw);
-                                const unsigned off = ((unsigned)rr * k.cw + bx * 8) * 4u;
-                                buf_store4_sc1(e[0], e[1], e[2], e[3], rpg, off, 0u);
-                                buf_store4_sc1(e[4], e[5], e[6], e[7], rpg, off + 16u, 0u);
-                        } else if constexpr(NT >= 2) {
+                        if constexpr(NT >= 2) {
                                 typedef float v4f __attribute__((ext_vector_type(4)));
                                 __builtin_nontemporal_store(v4f{e[0], e[1], e[2], e[3]}, reinterpret_cast<v4f *>(dst));
                                 __builtin_nontemporal_store(v4f{e[4], e[5], e[6], e[7]}, reinterpret_cast<v4f *>(dst) + 1);
@@ -2607,12 +2586,6 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh,
                         for(int off = 32; off > 0; off >>= 1) { dist += __shfl_down(dist, off, 64); }
                         if(lane == 0) { a.part_prob[(size_t)c * a.strips_per_chan + strip] = dist; }
                 }
-        }
-        if constexpr(FUSED) {
-                // this wavefront's part of block row `by` is in place: every store above acknowledged (written through), then
-                // the count the gradient wavefronts of this launch poll (gradient_strip)
-                stores_acknowledged();
-                if(lane == 0) { __hip_atomic_fetch_add(fz->row_done + by, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         }
 #ifdef J2P_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2656,81 +2629,6 @@ __global__ __launch_bounds__(256) void k_project_mixed(ProjArgs a)
         if(k.ws == 1 && k.hs == 1) { project_strip<LOG, 1, 1, 0, (NIP ? 1 : 0)>(a, sh); }
         else if(k.ws == 2 && k.hs == 2) { project_strip<LOG, 2, 2, 0, (NIP ? 1 : 0)>(a, sh); }
         else { project_strip<LOG, 0, 0, 0, (NIP ? 1 : 0)>(a, sh); }
-}
-
-// ---------------------------------------------------------------------------
-// The single-launch iteration (see FuseArgs): projection(k) and gradient(k + 1) of ONE full-resolution channel that covers
-// its canvas (Y-only planes, the components of `-s`: jpeg2png.c:147-152) in one grid; reference loop compute.c:430-448.
-// ||g_k|| is reduced by every projection wavefront from the row sums gradient(k) left (NIP 1); gradient(k + 1) folds its
-// own row sums into the other parity's array.  One workgroup = one claimed item: 4 projection strips or 4 gradient strips.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned xcc_id()
-{
-        unsigned x;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-        return x & 7u;
-}
-constexpr unsigned kNoItem = 0xffffffffu, kGradientItem = 0x80000000u;
-
-// one ticket for the calling workgroup (thread 0): a projection item while any is left ANYWHERE, then a gradient item
-__device__ __forceinline__ unsigned claim_item(const FuseArgs &fz)
-{
-        const unsigned q0 = xcc_id();
-        for(unsigned part = 0; part < 2; part++) {
-                const unsigned n = part == 0 ? fz.np_wg : fz.ng_wg;
-                unsigned *heads = fz.head + 8 * part;
-                for(unsigned d = 0; d < 8; d++) {
-                        const unsigned q = (q0 + d) & 7u;
-                        const unsigned base = chunk_base(n, q), size = chunk_base(n, q + 1) - base;
-                        // (another XCD's queue: look before drawing, so that its counter is not run up by everybody)
-                        if(d != 0 && __hip_atomic_load(heads + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= size) { continue; }
-                        const unsigned t = __hip_atomic_fetch_add(heads + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if(t < size) { return (part ? kGradientItem : 0u) | (base + t); }
-                }
-                // every queue of this part has been seen exhausted: all its items are in the hands of running workgroups
-        }
-        return kNoItem;
-}
-
-struct __attribute__((aligned(16))) IterateShared {
-        union {
-                ProjShared proj;
-                double fold_buf[kFoldMaxRows];
-        };
-        unsigned item;
-};
-
-// NIP: who reduces ||g_k|| from the row sums in the projection part: 1 = every wavefront, 2 = the workgroup's first (see project_strip)
-template <bool TGV, int NIP>
-__global__ __launch_bounds__(256, kGradWaves1) void k_iterate(ProjArgs pa, GradArgs ga, FuseArgs fz)
-{
-        __shared__ IterateShared sh;
-        if(threadIdx.x == 0) {
-#ifdef J2P_EXP_FUSE_STATIC
-                // (timing experiment: what claiming costs — items from blockIdx, XCD-contiguous like the two-launch kernels)
-                const bool grad = blockIdx.x >= fz.np_wg;
-                const unsigned nwg = grad ? fz.ng_wg : fz.np_wg, b = grad ? blockIdx.x - fz.np_wg : blockIdx.x;
-                const unsigned xcd = b & 7, qq = nwg >> 3, rem = nwg & 7;
-                const unsigned it = (grad ? kGradientItem : 0u) | ((xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + (b >> 3));
-#else
-                const unsigned it = claim_item(fz);
-#endif
-                sh.item = it;
-                // the next launch's tickets start from zero (its launch comes after this one has ended)
-                if(it == 0u) {
-                        for(unsigned i = 0; i < 16; i++) { __hip_atomic_store(fz.head_next + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                }
-        }
-        __syncthreads();
-        const unsigned item = sh.item;
-        if(item == kNoItem) { return; }
-        if(!(item & kGradientItem)) {
-                project_strip<false, 1, 1, 0, NIP, false, true>(pa, sh.proj, item, fz.np_wg, &fz);
-        } else {
-                const unsigned l = item & ~kGradientItem;
-                v2f *no_xchg = nullptr;
-                gradient_strip<1, TGV, false, 1, 0, 2, true, v2f>(ga, no_xchg, sh.fold_buf, l % fz.g_gx, l / fz.g_gx, &fz);
-        }
 }
 
 // ---------------------------------------------------------------------------

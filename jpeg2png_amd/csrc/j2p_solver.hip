@@ -96,7 +96,7 @@ struct j2p_solver {
         size_t arena_bytes = 0;
         // reductions
         bool fold = false;       // norm reduction folded into k_gradient (J2P_OPT_NORM_FOLD); default: band solvers only
-        bool reducer = false;    // whole canvases: the gradient launch's last workgroup reduces ||g|| (GradArgs::reduce_norm; J2P_OPT_NORM_FOLD = 2)
+        unsigned zone_b = 0, zone_c = 0;   // shares (1/256) of a gradient launch dealt as half / quarter tile rows (grad_item)
         bool joint_inwave = false;   // J2P_OPT_JOINT_INWAVE
         bool norm_in_project = false;   // J2P_OPT_NORM_IN_PROJECT (with fold): level 2 of the norm inside k_project
         int nip_form = 1;               // ... by every wavefront (1: small canvases) or by the workgroup's first (2), see project_strip
@@ -106,11 +106,6 @@ struct j2p_solver {
         size_t live_ws = 0, live_g = 0, live_planes = 0, live_d = 0;
         bool phase_log = false;         // the gradient phase of the running iteration was issued with logging
         bool mixed_project = true;      // small canvases: all samplings in one projection launch (J2P_OPT_MIXED_PROJECT)
-        // the single-launch iteration (k_iterate: projection(k) + gradient(k + 1) in one grid, see FuseArgs)
-        bool fuse_possible = false;     // one 1x1 channel covering a whole canvas of at most kWaveTreeMax tile rows
-        bool fuse = false;              // ... and in use (policy: canvases up to kFusePixels; J2P_OPT_FUSE)
-        unsigned *fuse_state = nullptr; // device: [2][16] queue heads, then [block rows] row_done
-        unsigned fuse_launches = 0;     // k_iterate launches since reset (row_done counts on)
         unsigned long long *dbg_counters = nullptr;   // J2P_DEBUG builds: [0] address violations, [1] first site, [2] first offset
         unsigned long long *trace = nullptr;          // J2P_TRACE builds: wave records (tools/wave_trace.py)
         unsigned trace_cap = 0, trace_used = 0;      // records reserved by the launches so far
@@ -322,6 +317,10 @@ constexpr unsigned long long kPx1Waves = 0;
 // the batch case, where the chip is full anyway — lose 5.7 %; not taken
 constexpr unsigned long long kHalfStripWaves = 2048;
 constexpr unsigned long long kShortStripWaves = 2048;
+// half / quarter items at the end of a gradient launch (see j2p_solver_create): from this many 16-row strips on, and the
+// shares (1/256) of every XCD's run dealt that way
+constexpr unsigned long long kZoneWaves = 6144;
+constexpr unsigned kZoneB = 32, kZoneC = 10;
 
 unsigned gcd_u(unsigned a, unsigned b) { return b ? gcd_u(b, a % b) : a; }
 unsigned lcm_u(unsigned a, unsigned b) { return a / gcd_u(a, b) * b; }
@@ -402,6 +401,9 @@ Geo geo_of(const j2p_solver *s)
         g.rpw = s->rpw;
         g.seg_off = 0;
         g.seg_mul = 1;
+        g.units = 0;            // (do_phase_gradient fills in the launch's own)
+        g.ntr_launch = 0;
+        g.zone_b = g.zone_c = 0;
 #ifdef J2P_TRACE
         g.trace = s->trace_on ? s->trace : nullptr;
         g.trace_cap = s->trace_cap;
@@ -412,21 +414,26 @@ Geo geo_of(const j2p_solver *s)
 }
 
 // where the gradient phase of iteration `iter` leaves its level-1 row sums [tile row][channel]: band solvers whose sums
-// are read in place by other bands (j2p_solver_alternate_rowsums) and whole-canvas solvers that iterate with one launch
-// (k_iterate: gradient(k + 1) writes while projection(k) still reads) alternate between two arrays
+// are read in place by other bands (j2p_solver_alternate_rowsums) alternate between two arrays
 double *rowsums_of(const j2p_solver *s, unsigned iter)
 {
-        return ((s->rowsum_alternate || s->fuse) && (iter & 1)) ? s->rowsum_odd : s->rowsum_local;
+        return (s->rowsum_alternate && (iter & 1)) ? s->rowsum_odd : s->rowsum_local;
+}
+
+// units of a gradient launch over `ntr` tile rows (grad_item): 4 strips per 256-thread workgroup, or — joint images, one
+// wavefront per channel — one strip per workgroup
+unsigned grad_units(const j2p_solver *s, unsigned ntr)
+{
+        const unsigned strips = s->ntx * ntr;
+        return s->nch == 1 || s->joint_inwave ? (strips + 3) / 4 : strips;
 }
 
 template <int NCH, int J, int PX = 2>
-void launch_gradient_n(const GradArgs &a, unsigned ntx, unsigned nseg, hipStream_t st, bool tgv, bool log, int nt)
+void launch_gradient_n(const GradArgs &a, hipStream_t st, bool tgv, bool log, int nt)
 {
         // J == 1: 4 strips per 256-thread workgroup; J > 1: one strip per workgroup of J wavefronts
-        constexpr unsigned wpb = 4;     // strips per workgroup
-        if(a.reduce_norm) { nseg++; }   // one more row of workgroups: the first of them reduces ||g|| (norm_reducer)
-        const dim3 grid = J == 1 ? dim3((ntx + wpb - 1) / wpb, nseg) : dim3(ntx, nseg);
-        const dim3 block = J == 1 ? dim3(64 * wpb) : dim3(64 * J);
+        const dim3 grid(grad_grid(a.geo.units, a.geo.zone_b, a.geo.zone_c));
+        const dim3 block = J == 1 ? dim3(256) : dim3(64 * J);
         if constexpr(NCH == 1 && PX == 2) {
                 // non-temporal g / prob state (see nt_policy): the one-channel-per-wavefront kernels without logging
                 if(nt >= 1 && !log) {
@@ -537,6 +544,10 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         a.geo = geo_of(s);
         a.geo.seg_off = seg_off;
         a.geo.seg_mul = seg_mul;
+        a.geo.units = grad_units(s, nseg_launch);
+        a.geo.ntr_launch = nseg_launch;
+        // (half / quarter items: whole phases of one channel per workgroup wavefront, see the policy in j2p_solver_create)
+        if(part == 0 && s->nch == 1) { a.geo.zone_b = s->zone_b; a.geo.zone_c = s->zone_c; }
         a.factor = s->factor;
         a.a_tv = (float)(1. / (double)sqrtf((float)s->nch));                    // compute.c:90
         const float alpha = s->weight / sqrtf((float)(4 / 2));                  // compute.c:258
@@ -556,8 +567,6 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
                 a.push = s->push_dev + (s->iter & 1);
         }
         a.norm_out = fold_norm ? s->norm : nullptr;
-        const bool reduce_here = s->reducer && !s->fold && s->whole && part == 0 && s->ntr_global <= kFoldMaxRows;
-        a.reduce_norm = reduce_here ? s->norm : nullptr;
         a.nch_total = s->nch;
         a.fold_phase = s->iter & 1;
         a.fold_rows = s->ntr_local;
@@ -572,26 +581,26 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         const bool inwave = s->joint_inwave;
         switch(s->nch) {
         case 1:
-                if(s->px == 1) { launch_gradient_n<1, 1, 1>(a, s->ntx, nseg_launch, st, tgv, log, 0); }
-                else { launch_gradient_n<1, 1>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); }
+                if(s->px == 1) { launch_gradient_n<1, 1, 1>(a, st, tgv, log, 0); }
+                else { launch_gradient_n<1, 1>(a, st, tgv, log, s->nt); }
                 break;
         case 2:
-                if(inwave) { launch_gradient_n<2, 1>(a, s->ntx, nseg_launch, st, tgv, log, 0); }
-                else if(s->px == 1) { launch_gradient_n<1, 2, 1>(a, s->ntx, nseg_launch, st, tgv, log, 0); }
-                else { launch_gradient_n<1, 2>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); }
+                if(inwave) { launch_gradient_n<2, 1>(a, st, tgv, log, 0); }
+                else if(s->px == 1) { launch_gradient_n<1, 2, 1>(a, st, tgv, log, 0); }
+                else { launch_gradient_n<1, 2>(a, st, tgv, log, s->nt); }
                 break;
         default:
-                if(inwave) { launch_gradient_n<3, 1>(a, s->ntx, nseg_launch, st, tgv, log, 0); }
-                else if(s->px == 1) { launch_gradient_n<1, 3, 1>(a, s->ntx, nseg_launch, st, tgv, log, 0); }
-                else { launch_gradient_n<1, 3>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); }
+                if(inwave) { launch_gradient_n<3, 1>(a, st, tgv, log, 0); }
+                else if(s->px == 1) { launch_gradient_n<1, 3, 1>(a, st, tgv, log, 0); }
+                else { launch_gradient_n<1, 3>(a, st, tgv, log, s->nt); }
                 break;
         }
 #else
         // (release build: one wavefront per channel, two columns per lane — the schedules that won everywhere)
         switch(s->nch) {
-        case 1: launch_gradient_n<1, 1>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); break;
-        case 2: launch_gradient_n<1, 2>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); break;
-        default: launch_gradient_n<1, 3>(a, s->ntx, nseg_launch, st, tgv, log, s->nt); break;
+        case 1: launch_gradient_n<1, 1>(a, st, tgv, log, s->nt); break;
+        case 2: launch_gradient_n<1, 2>(a, st, tgv, log, s->nt); break;
+        default: launch_gradient_n<1, 3>(a, st, tgv, log, s->nt); break;
         }
 #endif
         if(part != 2) { mark(s); }
@@ -599,7 +608,7 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
 #ifdef J2P_TRACE
         if(s->trace_on) {       // one record per wavefront of the launch (J == 1: 4 strips per workgroup; joint: one strip)
                 const bool per_channel = s->nch > 1 && !s->joint_inwave;
-                s->trace_used += (per_channel ? s->ntx * s->nch : (s->ntx + 3) / 4 * 4) * nseg_launch;
+                s->trace_used += grad_grid(a.geo.units, a.geo.zone_b, a.geo.zone_c) * (per_channel ? s->nch : 4u);
         }
 #endif
         if(part == 1) {
@@ -607,7 +616,7 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
                 return J2P_OK;
         }
         s->interior_done = false;
-        s->norm_ready = fold_norm || reduce_here;
+        s->norm_ready = fold_norm;
         s->norm_by_project = nip;
         if(part == 0 && !s->whole && !s->fold) {
                 launch_rowsums(s);
@@ -823,84 +832,6 @@ int do_phase_project(j2p_solver *s, bool log, int part = 0)
         return J2P_OK;
 }
 
-// projection(k) + gradient(k + 1) in ONE launch (k_iterate; reference loop compute.c:430-448).  Entered with gradient(k)
-// issued (grad_done) and leaves gradient(k + 1) issued: the caller opens a run with do_phase_gradient and closes it with
-// do_phase_project.  One 1x1 channel covering a whole canvas, no logging (s->fuse).
-int do_fused_step(j2p_solver *s)
-{
-        if(!s->fuse || !s->grad_done || !s->norm_by_project || s->phase_log) { return fail(J2P_ESTATE, "fused step outside a fused run"); }
-        // ---- projection(k): as do_phase_project sets it up for this case ----
-        ProjArgs pa;
-        pa.ch[0] = chan_dev(s, 0);
-        pa.geo = geo_of(s);
-        pa.factor = s->factor;
-        const float radius = sqrtf((float)s->H * (float)s->W) / 2;             // compute.c:425
-        pa.step = radius / sqrtf((float)(1 + s->iterations));                   // compute.c:443
-        pa.norm = s->norm;
-        pa.part_prob = s->part_prob;
-        pa.strips_per_chan = s->strips_stride;
-        pa.chan_of_z[0] = 0;
-        const unsigned brows = (s->rows + 7) / 8, strips_x = (s->W + 63) / 64;
-        pa.by_offset[0] = 0;
-        pa.by_mul[0] = 1;
-        pa.nby[0] = brows;
-        pa.norm_rowsums = rowsums_of(s, s->iter);
-        pa.norm_rows = s->ntr_global;
-        pa.norm_nch = 1;
-        for(unsigned c = 0; c < kMaxCh; c++) { pa.halo_up[c] = pa.halo_down[c] = nullptr; }
-        // ---- SWAP(fdata, fista), compute.c:438: the buffer the projection part writes is x_{k+1} for the gradient part ----
-        s->cur ^= 1;
-        s->iter++;
-        // ---- gradient(k + 1): as do_phase_gradient sets it up for this case ----
-        const float tnext = (1 + sqrtf(1 + 4 * (s->t * s->t))) / 2;             // compute.c:431-432,440
-        s->factor = (s->t - 1) / tnext;
-        s->t = tnext;
-        GradArgs ga;
-        ga.ch[0] = chan_dev(s, 0);
-        ga.geo = geo_of(s);
-        ga.factor = s->factor;
-        ga.a_tv = (float)(1. / (double)sqrtf((float)s->nch));                   // compute.c:90
-        const float alpha = s->weight / sqrtf((float)(4 / 2));                  // compute.c:258
-        ga.a_tgv = (float)((double)alpha * 1. / (double)sqrtf((float)s->nch));  // compute.c:154
-        ga.part_g2 = s->part_g2;
-        ga.part_tv = s->part_tv;
-        ga.row_ticket = s->tickets;
-        ga.done_ticket = s->tickets + s->ntr_local;
-        ga.rowsum = rowsums_of(s, s->iter);
-        ga.norm_out = nullptr;
-        ga.nch_total = 1;
-        ga.fold_phase = s->iter & 1;
-        ga.fold_rows = s->ntr_local;
-        ga.ntr_global = s->ntr_global;
-        ga.reduce_norm = nullptr;
-        ga.push = nullptr;
-        FuseArgs fz;
-        fz.head = s->fuse_state + 16 * (s->fuse_launches & 1);
-        fz.head_next = s->fuse_state + 16 * ((s->fuse_launches + 1) & 1);
-        fz.row_done = s->fuse_state + 32;
-        fz.done_target = strips_x * (s->fuse_launches + 1);
-        fz.np_wg = (strips_x * brows + 3) / 4;
-        fz.g_gx = (s->ntx + 3) / 4;
-        fz.ng_wg = fz.g_gx * s->nseg;
-        const dim3 grid(fz.np_wg + fz.ng_wg);
-#ifndef J2P_EXPERIMENTS
-        (void)grid;
-        return fail(J2P_ESTATE, "the single-launch iteration exists in the experiments build only");
-#else
-        if(s->nip_form == 2) {
-                if(s->weight != 0.f) { hipLaunchKernelGGL((k_iterate<true, 2>), grid, dim3(256), 0, s->stream, pa, ga, fz); }
-                else { hipLaunchKernelGGL((k_iterate<false, 2>), grid, dim3(256), 0, s->stream, pa, ga, fz); }
-        } else {
-                if(s->weight != 0.f) { hipLaunchKernelGGL((k_iterate<true, 1>), grid, dim3(256), 0, s->stream, pa, ga, fz); }
-                else { hipLaunchKernelGGL((k_iterate<false, 1>), grid, dim3(256), 0, s->stream, pa, ga, fz); }
-        }
-        HIP_TRY(hipGetLastError());
-        s->fuse_launches++;
-#endif
-        // (state as do_phase_gradient leaves it: grad_done, the norm comes from the row sums, no logging)
-        return J2P_OK;
-}
-
 int upload(void *dst, const void *src, size_t bytes, hipStream_t st)
 {
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
@@ -924,8 +855,6 @@ int launch_init(j2p_solver *s)
         // the partials of a folding gradient launch carry the iteration's parity in their sign bit (fold_tile_row): what
         // the slots hold before iteration 0 must carry the other one — all bits set
         HIP_TRY(hipMemsetAsync(s->part_g2, 0xff, (size_t)s->ntx * s->ntr_local * s->nch * sizeof(double), s->stream));
-        if(s->fuse_state) { HIP_TRY(hipMemsetAsync(s->fuse_state, 0, (32 + (size_t)(s->rows + 7) / 8) * sizeof(unsigned), s->stream)); }
-        s->fuse_launches = 0;
         s->iter = 0;
         s->t = 1.f;
         s->cur = 0;
@@ -1146,20 +1075,25 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 s->px = px;
                 s->rpw = g;
                 s->ntx = strips(px);
+                // The LAST wavefronts of a gradient launch march half and quarter tile rows (grad_item): a launch ends with
+                // its last wavefront, and on a canvas of several wavefront generations a whole 16-row item dispatched last
+                // keeps a few SIMDs busy for a wavefront life (17 us of 53 at 4096^2, profiles/r06_wave_trace.jsonl) while
+                // the rest of the chip drains.  Shares in 1/256 of every XCD's run; one channel per workgroup wavefront,
+                // 16-row tile rows, at least kZoneWaves strips.  Who marches a row never changes a bit (march_rows).
+                if(nchannel == 1 && g == kTY && waves(px, g) >= kZoneWaves) {
+                        s->zone_b = kZoneB;
+                        s->zone_c = kZoneC;
+                }
+                // (halves need two groups of four rows per tile row, quarters four: march_rows)
+                if(const char *env = j2p_exp_env("J2P_ZONE_B")) { if(nchannel == 1 && g >= 8) { s->zone_b = (unsigned)atoi(env); } }
+                if(const char *env = j2p_exp_env("J2P_ZONE_C")) { if(nchannel == 1 && g >= 16) { s->zone_c = (unsigned)atoi(env); } }
+                if(s->zone_b > 256) { s->zone_b = 256; }
+                if(s->zone_b + s->zone_c > 256) { s->zone_c = 256 - s->zone_b; }
         }
         s->nseg = (s->rows + s->rpw - 1) / s->rpw;
         s->ntr_local = s->nseg;
         s->ntr_global = (H + s->rpw - 1) / s->rpw;
         s->first_tr = row0 / s->rpw;
-        // the single-launch iteration (k_iterate, J2P_OPT_FUSE): one full-resolution channel that covers the whole canvas,
-        // packed strips, a tree k_project's wavefronts can run themselves.  Experiments build only and never the policy's
-        // choice: measured slower than two launches at every size, and slower even with its synchronisation switched off
-        // (profiles/r05_single_launch.jsonl)
-#if defined(J2P_EXPERIMENTS) && !defined(J2P_DEBUG) && !defined(J2P_TRACE)
-        s->fuse_possible = whole && nchannel == 1 && planes[0].w_samp == 1 && planes[0].h_samp == 1 && s->px == 2 &&
-                           s->ntr_global <= kWaveTreeMax;
-#endif
-        s->fuse = false;
         const size_t ntiles = (size_t)s->ntx * s->ntr_local;
         unsigned max_strips = 0;
         for(unsigned c = 0; c < nchannel; c++) {
@@ -1203,8 +1137,6 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 carve.take(s->rowsum_local, (size_t)s->ntr_local * nchannel);
                 if(whole) {
                         s->rowsum_all = s->rowsum_local;
-                        carve.take(s->rowsum_odd, (size_t)s->ntr_local * nchannel);      // (the single-launch iteration alternates)
-                        carve.take(s->fuse_state, 32 + (size_t)(s->rows + 7) / 8);
                 } else {
                         carve.take(s->rowsum_all, (size_t)s->ntr_global * nchannel);
                         carve.take(s->rowsum_all_odd, (size_t)s->ntr_global * nchannel);
@@ -1313,21 +1245,14 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
         switch(option) {
         case J2P_OPT_NORM_FOLD:
                 if((s->rowsum_alternate || s->linked) && !value) { return fail(J2P_ESTATE, "alternating / pushed row sums need the folded norm reduction"); }
-                if(value && !s->fold && !s->reducer) {
+                if(value && !s->fold) {
                         // (the slots must not carry the coming iteration's parity yet, see launch_init)
                         DeviceGuard guard(s->device);
                         HIP_TRY(hipMemsetAsync(s->part_g2, (s->iter & 1) ? 0x00 : 0xff, (size_t)s->ntx * s->ntr_local * s->nch * sizeof(double), s->stream));
                 }
-                // 0: reduction launch between the phases; 1: folded into k_gradient by tickets; 2 (whole canvases): the
-                // gradient launch's last workgroup reduces
-#ifndef J2P_EXPERIMENTS
-                if(value == 2) { return fail(J2P_ESTATE, "J2P_OPT_NORM_FOLD 2 (the launch's last workgroup reduces) exists in the experiments build only"); }
-#endif
-                // (the reducer workgroup sums a WHOLE canvas's partials: a band solver would reduce ||g|| from stale global arrays)
-                if(value == 2 && !s->whole) { return fail(J2P_ESTATE, "J2P_OPT_NORM_FOLD 2 is for whole-canvas solvers"); }
+                // 0: reduction launch between the phases; 1: folded into k_gradient by tickets
+                if(value != 0 && value != 1) { return fail(J2P_EINVAL, "J2P_OPT_NORM_FOLD is 0 or 1"); }
                 s->fold = value == 1;
-                s->reducer = value == 2;
-                if(!s->fold) { s->fuse = false; }          // (the single-launch iteration folds: J2P_OPT_FUSE 1 turns both on again)
                 break;
         case J2P_OPT_JOINT_INWAVE:
 #ifndef J2P_EXPERIMENTS
@@ -1340,27 +1265,12 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
                 // 0: off; 1: the per-wavefront tree; 2: the per-workgroup tree; (needs NORM_FOLD)
                 s->norm_in_project = value != 0;
                 s->nip_form = value == 2 ? 2 : 1;
-                if(!s->norm_in_project) { s->fuse = false; }
                 break;
         case J2P_OPT_NT_GRADIENT:
                 s->nt_forced = value >= 0;                 // negative: back to the policy
                 s->nt = value < 0 ? nt_policy(s) : (value > 3 ? 3 : value);
                 break;
         case J2P_OPT_MIXED_PROJECT: s->mixed_project = value != 0; break;
-        case J2P_OPT_FUSE:
-                if(value && !s->fuse_possible) { return fail(J2P_ESTATE, "the single-launch iteration needs one full-resolution channel covering a whole canvas of at most %u tile rows", kWaveTreeMax); }
-                if(value && !s->fuse) {
-                        // row sums alternate from now on, ||g|| comes from them inside the projection; the partials' parity marks as at reset
-                        DeviceGuard guard(s->device);
-                        if(!s->fold && !s->reducer) {
-                                HIP_TRY(hipMemsetAsync(s->part_g2, (s->iter & 1) ? 0x00 : 0xff, (size_t)s->ntx * s->ntr_local * s->nch * sizeof(double), s->stream));
-                        }
-                        s->fold = true;
-                        s->reducer = false;
-                        s->norm_in_project = true;
-                }
-                s->fuse = value != 0;
-                break;
         default: return fail(J2P_EINVAL, "unknown option %d", option);
         }
         return J2P_OK;
@@ -1392,6 +1302,15 @@ int j2p_solver_trace(j2p_solver *s, int on, unsigned long long *host_out, unsign
 #else
         (void)on; (void)host_out; (void)max_records; (void)n;
         return fail(J2P_ESTATE, "not a J2P_TRACE build");
+#endif
+}
+
+int j2p_experiments_build(void)
+{
+#ifdef J2P_EXPERIMENTS
+        return 1;
+#else
+        return 0;
 #endif
 }
 
@@ -1443,9 +1362,8 @@ int j2p_solver_launches_per_iteration(const j2p_solver *s, unsigned *n)
 {
         if(!s || !n) { return fail(J2P_EINVAL, "NULL argument"); }
         // (unlogged runs of a whole-canvas solver; logging adds the log kernels and takes the two-launch form)
-        if(s->fuse) { *n = 1; }
-        else if(!s->whole) { *n = 2 + (s->band_nip ? 0u : 1u); }
-        else { *n = (s->fold || s->reducer) ? 2 : 3; }
+        if(!s->whole) { *n = 2 + (s->band_nip ? 0u : 1u); }
+        else { *n = s->fold ? 2 : 3; }
         return J2P_OK;
 }
 
@@ -1596,17 +1514,6 @@ int j2p_solver_run(j2p_solver *s, unsigned n, j2p_log_row *rows)
                 s->logsums_cap = 0;
                 HIP_TRY(dev_malloc((void **)&s->logsums, (size_t)n * kRow * sizeof(double)));
                 s->logsums_cap = n;
-        }
-        // one launch per iteration where that pays (s->fuse): gradient(k0), then n - 1 launches of projection(k) + gradient(k + 1),
-        // then projection(k0 + n - 1).  Timing events bracket the two phases and logging needs their sums: both take the
-        // two-launch form.
-        if(s->fuse && s->fold && s->norm_in_project && !log && !s->timing && n >= 2) {
-                int rc = do_phase_gradient(s, false);
-                for(unsigned i = 1; i < n && rc == J2P_OK; i++) { rc = do_fused_step(s); }
-                if(rc == J2P_OK) { rc = do_phase_project(s, false); }
-                if(rc != J2P_OK) { return rc; }
-                s->carried_valid = false;
-                return J2P_OK;
         }
         for(unsigned i = 0; i < n; i++) {
                 int rc = do_phase_gradient(s, log);
@@ -1909,8 +1816,8 @@ int j2p_solver_enable_timing(j2p_solver *s, int on)
                 for(; made < 33; made++) {
                         if(hipEventCreate(&e[made]) != hipSuccess) { break; }
                 }
-                if(made == 33) {
-                        HIP_TRY(hipStreamSynchronize(s->stream));
+                // (no early return in here: the events are destroyed below whatever happens)
+                if(made == 33 && hipStreamSynchronize(s->stream) == hipSuccess) {
                         for(int i = 0; i < 33; i++) { (void)hipEventRecord(e[i], s->stream); }
                         if(hipStreamSynchronize(s->stream) == hipSuccess) {
                                 float d[32];

@@ -21,7 +21,7 @@
 //           both and compares their results): the neighbours' edge rows are PULLED by a small copy kernel in front of
 //           the gradient launch, and ONE band — the root — waits for the others' gradient events, reduces all bands'
 //           row sums (read in place) and stores the float norm into every band's norm word; the others wait for
-//           that event (J2P_TILED_NORM=all: every band reduces for itself).  Four launches per band and iteration, three
+//           that event (experiments build, J2P_TILED_NORM=all: every band reduces for itself).  Four launches per band and iteration, three
 //           sequential hops.  Also what canvases taller than 16384 rows use (k_project's in-kernel tree holds 1024 rows).
 //   rccl    GPUs without peer access, or on request: ncclAllGather of the bands' row sums between the phases and one
 //           ncclGroupStart/End of ncclSend/ncclRecv for the 2 + 2 edge rows behind the projection, on the band's own
@@ -40,6 +40,7 @@
 #include <condition_variable>
 #include <map>
 #include <mutex>
+#include <string>
 #include <new>
 #include <thread>
 #include <vector>
@@ -547,7 +548,10 @@ void j2p_tiled_destroy(j2p_tiled *t)
                 }
         }
         bool stuck = false;
-        if(t->abort.load() && t->signals) {
+        // (every aborted solver, not only the value form: a candidate of the verification that timed out on event waits or on
+        // copies has no values to release, but its streams may be just as stuck — the polling loop with its limit decides
+        // whether they can be synchronised at all; hipStreamSynchronize on a stream that never drains would hang the process)
+        if(t->abort.load()) {
                 // the release has to be REPEATED until every band stream is idle: the streams still hold hipStreamWriteValue64
                 // operations of the iterations that were queued before the failure, and each of them puts a small value back
                 // over the released one (seen: the failed band's own flag fell back to its last iteration and the other
@@ -555,7 +559,7 @@ void j2p_tiled_destroy(j2p_tiled *t)
                 // further: this terminates.
                 const auto t0 = std::chrono::steady_clock::now();
                 for(;;) {
-                        release_value_waiters(t);
+                        if(t->signals) { release_value_waiters(t); }
                         bool idle = true;
                         for(Band *b : t->bands) {
                                 (void)hipSetDevice(b->device);
@@ -840,8 +844,19 @@ int tiled_create_impl(j2p_tiled **out, unsigned nband, const int devices[], cons
 // there too (tests; =2 also prints what was measured), J2P_TILED_VERIFY=0 never runs it.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr unsigned kVerifyIterations = 8, kVerifyTimedIterations = 24;
+// per device list: the verified plan — or the fact that NOTHING verifies there (kept too: a node on which every candidate
+// fails must not repeat a truth solve, five scratch solvers, an RCCL init and their deadlines for every image of a batch)
+// — or a marker that a thread is at it right now: others asking for the same list wait for that thread instead of
+// verifying beside it on the same GPUs, which would also distort the timings the choice is made from
+struct PlanEntry {
+        bool done = false;      // false: being measured by some thread
+        bool none = false;      // done, and no exchange reproduces the one-GPU solve on these GPUs
+        Plan plan;
+        std::string why;        // none: the error text
+};
 std::mutex g_plan_lock;
-std::map<std::vector<int>, Plan> g_plans;
+std::condition_variable g_plan_cv;
+std::map<std::vector<int>, PlanEntry> g_plans;
 
 struct Candidate {
         Plan plan;
@@ -949,15 +964,11 @@ int plan_from_environment(Plan *plan)
 
 // the plan for this device list: from the cache, or by the procedure above.  Returns J2P_OK with plan->exchange < 0 when
 // there is nothing to decide (the caller takes the defaults), an error when no exchange works on these GPUs.
-int pick_plan(unsigned nband, const int devices[], unsigned nchannel, const j2p_plane planes[], float weight, const float pweight[], bool verbose, Plan *plan)
+// decided: 0 = nothing to decide for THIS job (canvas too short for the exercise, or an error that is the job's own /
+// transient: not remembered), 1 = *plan is the verified choice, 2 = nothing verifies on these GPUs (error returned)
+int measure_plan(unsigned nband, const int devices[], unsigned nchannel, const j2p_plane planes[], float weight, const float pweight[], bool verbose, Plan *plan, int *decided)
 {
-        *plan = Plan();
-        const std::vector<int> key(devices, devices + nband);
-        {
-                std::lock_guard<std::mutex> g(g_plan_lock);
-                auto it = g_plans.find(key);
-                if(it != g_plans.end()) { *plan = it->second; return J2P_OK; }
-        }
+        *decided = 0;
         // ---- the scratch canvas: the job's first rows, three tile rows per band ----
         unsigned align = J2P_TILE_ROWS, H = 0;
         for(unsigned c = 0; c < nchannel; c++) {
@@ -1047,18 +1058,49 @@ int pick_plan(unsigned nband, const int devices[], unsigned nchannel, const j2p_
                 }
         }
         if(best < 0) {
+                *decided = 2;
                 return j2p_fail(J2P_EDEVICE, "row tiling over GPUs %s: no exchange reproduces the one-GPU solve on them (see stderr)%s%s", devtext,
                                 reach ? "" : "; ", reach ? "" : why);
         }
         *plan = cands[(size_t)best].plan;
+        *decided = 1;
         if(verbose) {
                 fprintf(stderr, "jpeg2png_amd: row tiling over GPUs %s: verified per scratch iteration %s -> '%s'\n", devtext, line, cands[(size_t)best].name);
         }
+        return J2P_OK;
+}
+
+int pick_plan(unsigned nband, const int devices[], unsigned nchannel, const j2p_plane planes[], float weight, const float pweight[], bool verbose, Plan *plan)
+{
+        *plan = Plan();
+        const std::vector<int> key(devices, devices + nband);
+        {
+                std::unique_lock<std::mutex> g(g_plan_lock);
+                for(;;) {
+                        auto it = g_plans.find(key);
+                        if(it == g_plans.end()) { break; }
+                        if(!it->second.done) { g_plan_cv.wait(g); continue; }        // (the entry may be gone afterwards: look again)
+                        if(it->second.none) { return j2p_fail(J2P_EDEVICE, "%s", it->second.why.c_str()); }
+                        *plan = it->second.plan;
+                        return J2P_OK;
+                }
+                g_plans[key] = PlanEntry();                    // ours to measure
+        }
+        int decided = 0;
+        const int rc = measure_plan(nband, devices, nchannel, planes, weight, pweight, verbose, plan, &decided);
         {
                 std::lock_guard<std::mutex> g(g_plan_lock);
-                g_plans[key] = *plan;
+                if(decided == 0) { g_plans.erase(key); }
+                else {
+                        PlanEntry &e = g_plans[key];
+                        e.done = true;
+                        e.none = decided == 2;
+                        e.plan = *plan;
+                        if(e.none) { e.why = j2p_last_error(); }
+                }
         }
-        return J2P_OK;
+        g_plan_cv.notify_all();
+        return rc;
 }
 
 }  // namespace

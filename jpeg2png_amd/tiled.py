@@ -123,7 +123,10 @@ class HipBandEngine:
     # -- gradient phase split in two, to overlap the halo exchange with compute ----------------
     @property
     def can_split(self):
-        return (self.solver.row_end - self.solver.row_begin) >= 3 * J2P_TILE_ROWS
+        """the split phases answer only in the experiments build of the library (the release library returns
+        J2P_ESTATE from the *_part calls: measured slower than whole phases)"""
+        import jpeg2png_amd as j
+        return j.experiments_build() and (self.solver.row_end - self.solver.row_begin) >= 3 * J2P_TILE_ROWS
 
     def gradient_interior(self):
         """all segments but the band's first and last: no halo row is read (solver stream)"""

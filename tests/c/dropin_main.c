@@ -3,17 +3,25 @@
  * (logger_log logger.c:20, progressbar_inc progressbar.c:53) and calls compute() with the
  * reference's own struct layout.  Input: a raw dump written by the test; output: raw planes
  * and the CSV log in the reference's format (logger.c:13,23). */
+#define _DEFAULT_SOURCE
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+#include <time.h>
 
 #include "jpeg2png_amd_compute.h"
 
-static unsigned ticks = 0;
+static unsigned ticks = 0, tick_times = 0;      /* tick_times: ticks that came more than 10 us after the one before */
+static double last_tick_us = -1e30;
 
 void progressbar_inc(struct progressbar *pb)
 {
+        struct timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        const double now_us = (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+        if(now_us - last_tick_us > 10.) { tick_times++; }
+        last_tick_us = now_us;
         pb->current++;
         ticks++;
 }
@@ -73,6 +81,7 @@ int main(int argc, char **argv)
         fclose(log.f);
         FILE *out = fopen(argv[2], "wb");
         fwrite(&ticks, 4, 1, out);
+        fwrite(&tick_times, 4, 1, out);
         for(unsigned c = 0; c < nch; c++) {
                 fwrite(&coefs[c].w, 4, 1, out);
                 fwrite(&coefs[c].h, 4, 1, out);

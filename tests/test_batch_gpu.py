@@ -61,6 +61,29 @@ def test_batch_separate_components_and_rgb(lib):
         s.close()
 
 
+def test_batch_refuses_an_output_array_of_the_wrong_kind(lib):
+    """submit(out=...) hands the C side a bare pointer it fills with height x width x 3 samples of bits / 8 bytes: an array
+    of another element size (a uint8 ring reused for a 16-bit job would be overrun by a factor of two), shape, layout or a
+    read-only one is refused before anything is queued — and the right one is filled"""
+    import jpeg2png_amd as j
+    planes = make_case(64, 48, "420", 20, seed=4)
+    with j.Batch(devices=[0], slots_per_device=1) as b:
+        for bits, arr in ((16, np.empty((48, 64, 3), np.uint8)), (8, np.empty((48, 64, 3), np.float32)),
+                          (8, np.empty((48, 64, 4), np.uint8)), (8, np.empty((64, 48, 3), np.uint8).transpose(1, 0, 2)),
+                          (12, np.empty((48, 64, 3), np.uint8))):
+            with pytest.raises(j.J2PError):
+                b.submit(planes, 0.3, [0.001] * 3, 3, width=64, height=48, bits=bits, out=arr)
+        ro = np.empty((48, 64, 3), np.uint8)
+        ro.flags.writeable = False
+        with pytest.raises(j.J2PError):
+            b.submit(planes, 0.3, [0.001] * 3, 3, width=64, height=48, bits=8, out=ro)
+        good8, good16 = np.zeros((48, 64, 3), np.uint8), np.zeros((48, 64, 3), ">u2")
+        t8 = b.submit(planes, 0.3, [0.001] * 3, 3, width=64, height=48, bits=8, out=good8)
+        t16 = b.submit(planes, 0.3, [0.001] * 3, 3, width=64, height=48, bits=16, out=good16)
+        assert b.wait(t8) is good8 and b.wait(t16) is good16
+        assert good8.any() and good16.any()
+
+
 def test_batch_reports_a_bad_job_and_carries_on(lib):
     import jpeg2png_amd as j
     good = make_case(64, 48, "444", 20, seed=3)

@@ -264,9 +264,10 @@ def test_drop_in_compute_from_c(lib, oracle, tmp_path, mode):
     subprocess.run([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(tmp_path / "log.csv"), *extra], check=True)
     want, want_log = oracle.oracle_compute(planes, weight, pw, its, log=True)
     raw = (tmp_path / "out.bin").read_bytes()
-    ticks = struct.unpack_from("<I", raw, 0)[0]
-    assert ticks == its
-    off = 4
+    ticks, tick_times = struct.unpack_from("<II", raw, 0)
+    assert ticks == its                                     # progressbar_inc once per iteration (compute.c:449-452) ...
+    assert tick_times >= min(its, 20)                       # ... and while it runs, not in a few bursts (compute_host.c: chunks follow the clock)
+    off = 8
     cw, ch = oracle.canvas_size(planes)
     for c in range(len(planes)):
         w, h = struct.unpack_from("<II", raw, off)
@@ -577,8 +578,7 @@ def test_every_schedule_switch_leaves_the_bits_alone(exp_lib, oracle, shape, mon
         {},                                                                         # the solver's own choice
         {j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 0},                     # stand-alone norm kernel
         {j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 1},                     # both levels inside k_gradient
-        {j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 2},                     # ... by the launch's last workgroup, no tickets
-        {j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 2, j.J2P_OPT_NT_GRADIENT: 2, j.J2P_OPT_MIXED_PROJECT: 0},
+        {j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 1, j.J2P_OPT_NT_GRADIENT: 2, j.J2P_OPT_MIXED_PROJECT: 0},
         {j.J2P_OPT_NORM_FOLD: 1, j.J2P_OPT_NORM_IN_PROJECT: 1},                     # level 2 inside k_project, every wavefront
         {j.J2P_OPT_NORM_FOLD: 1, j.J2P_OPT_NORM_IN_PROJECT: 2, j.J2P_OPT_MIXED_PROJECT: 0},   # ... the workgroup's first wavefront
         {j.J2P_OPT_NORM_FOLD: 1, j.J2P_OPT_NORM_IN_PROJECT: 2, j.J2P_OPT_MIXED_PROJECT: 0, j.J2P_OPT_NT_GRADIENT: 3},
@@ -589,16 +589,9 @@ def test_every_schedule_switch_leaves_the_bits_alone(exp_lib, oracle, shape, mon
         {j.J2P_OPT_MIXED_PROJECT: 0},                                               # what a > 1 Mpixel canvas gets
         {j.J2P_OPT_MIXED_PROJECT: 0, j.J2P_OPT_NORM_IN_PROJECT: 0, j.J2P_OPT_NORM_FOLD: 0, "J2P_JOINT_INWAVE": "1"},
     ]
-    if n == 1:
-        # one full-resolution channel: projection(k) + gradient(k + 1) in ONE launch (k_iterate) — the solver's own choice at
-        # this size — against the two-launch form, and with ||g|| reduced by the workgroup's first wavefront
-        settings += [{j.J2P_OPT_FUSE: 0}, {j.J2P_OPT_NORM_FOLD: 0, j.J2P_OPT_FUSE: 1}, {j.J2P_OPT_FUSE: 1, j.J2P_OPT_NORM_IN_PROJECT: 2},
-                     {j.J2P_OPT_FUSE: 1, j.J2P_OPT_NT_GRADIENT: 2}]
     for px in ("2", "1"):
         monkeypatch.setenv("J2P_PX", px)
         for opts in settings:
-            if px == "1" and opts.get(j.J2P_OPT_FUSE) == 1:
-                continue                        # the single-launch iteration exists with two columns per lane only
             if "J2P_JOINT_INWAVE" in opts:
                 if px == "1":
                     continue                    # the in-wavefront joint kernel exists with two columns per lane only
@@ -640,6 +633,35 @@ def test_every_schedule_switch_leaves_the_bits_alone(exp_lib, oracle, shape, mon
                 t.run(its)
                 for c in range(n):
                     assert bit_equal(t.download(c), want[c]), f"rpw {rpw} (ignored by band solvers), two bands: channel {c}"
+
+
+@pytest.mark.parametrize("shape", [(700, 328, 0.3), (1000, 96, 0.3), (264, 200, 0.0), (4096, 48, 0.3)])
+def test_half_and_quarter_items_leave_the_bits_alone(exp_lib, oracle, shape, monkeypatch):
+    """the last workgroups of a large gradient launch march half and quarter tile rows (grad_item / march_rows in
+    j2p_kernels.hip.h; the solver's own choice from 6144 strips on): who marches a row must not change a bit — every
+    share of halves and quarters (in 1/256 of an XCD's run), on canvases whose last tile row is short (328 = 20 x 16 + 8),
+    whole and as bands, with the CSV sums, against the reference's bits"""
+    import jpeg2png_amd as j
+    w, h, weight = shape
+    planes = make_case(w, h, "444", 10, seed=97, y_only=True)
+    its = 9
+    want, want_rows = oracle.oracle_compute(planes, weight, [0.001], its, log=True)
+    monkeypatch.setenv("J2P_PX", "2")
+    monkeypatch.setenv("J2P_RPW", "16")
+    for zb, zc in ((0, 0), (256, 0), (0, 256), (100, 100), (64, 32), (26, 10), (1, 255)):
+        monkeypatch.setenv("J2P_ZONE_B", str(zb))
+        monkeypatch.setenv("J2P_ZONE_C", str(zc))
+        got = copy.deepcopy(planes)
+        rows = j.compute(got, weight, [0.001], its, log=True)
+        assert bit_equal(got[0].fdata, want[0]), f"zones {zb}/{zc}"
+        assert np.allclose(rows, want_rows, rtol=1e-9, atol=1e-9), f"zones {zb}/{zc}: CSV rows"
+        got = copy.deepcopy(planes)
+        j.compute(got, weight, [0.001], its)
+        assert bit_equal(got[0].fdata, want[0]), f"zones {zb}/{zc}, no logging"
+        if h >= 96:
+            with j.TiledSolver(planes, weight, [0.001], its, devices=band_devices(3 if h >= 200 else 2)) as t:
+                t.run(its)
+                assert bit_equal(t.download(0), want[0]), f"zones {zb}/{zc}, bands"
 
 
 def test_concurrent_calls_are_independent(lib, oracle):

@@ -1,0 +1,87 @@
+#!/bin/bash
+# Round 6's GPU calls, one section per call (bash tools/gpu_r06.sh <section>); everything lands under gpurun_out/r06_*.
+set -u
+S=${1:-a}
+O=gpurun_out
+mkdir -p $O
+export TMPDIR=/tmp
+BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-host-to-host"
+line() { grep '^{' | tail -1; }
+brief() { python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']; k=r['per_kernel']
+print(json.dumps({'variant': '$1', 'Mpx_it_per_s': d['value'] or d.get('unverified_value'), 'us_per_iteration': round(r['iteration_ms']*1e3,2), 'k_gradient_us': round(k['k_gradient']['avg_launch_ms']*1e3,1), 'k_project_us': round(k['k_project']['avg_launch_ms']*1e3,1), 'bit_identical_to_reference': (d.get('parity') or {}).get('bit_identical')}))"; }
+sized() {  # sized W H ITER VARIANT [LIB]
+  ( J2P_LIBRARY=${5:-} timeout 300 python bench.py --size $1 --height $2 --iterations $3 --steps 4 --warmup 2 --no-cpu-baseline --no-other-configs --no-host-to-host ) 2>/dev/null | line | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print(json.dumps({'plane': '$1x$2', 'variant': '$4', 'us_per_iteration': round(r['iteration_ms']*1e3,2), 'frac': r['frac'], 'k_gradient_us': round(r['per_kernel']['k_gradient']['avg_launch_ms']*1e3,1), 'k_project_us': round(r['per_kernel']['k_project']['avg_launch_ms']*1e3,1)}))"
+}
+case $S in
+a)
+  # the per-SIMD picture of the final round-5 kernels (review item 1), then rows per strip at 4096^2 (timing only: J2P_RPW
+  # other than 16 changes the order of the norm's partial sums)
+  ( timeout 300 python __graft_entry__.py --smoke ) 2>&1 | tail -1
+  J2P_LIBRARY=ab/libj2p_trace.so timeout 300 python tools/wave_trace.py 4096 4096 444 y 12 > $O/r06_wave_trace.jsonl 2>$O/r06_wave_trace.err; tail -c 2500 $O/r06_wave_trace.jsonl
+  for rep in 1 2; do
+    for rpw in 16 17 18 20 24 32 33 34 36 40 48; do
+      J2P_RPW=$rpw sized 4096 4096 100 rpw$rpw jpeg2png_amd/libjpeg2png_amd_exp.so
+    done
+  done | tee $O/r06_rpw_4096.jsonl
+  ;;
+b)
+  # half / quarter items at the end of the gradient launch: parity first, then the shares at 4096^2 (timing; bits are equal by test)
+  ( timeout 900 python -m pytest tests/test_parity_gpu.py -q -x --timeout 600 -k "half_and_quarter or schedule_switch or joint_modes or full_size_against or band" ) > $O/r06_b_tests.log 2>&1; echo "tests rc=$?"; tail -8 $O/r06_b_tests.log
+  for zb in 0 13 26 38 51 64; do
+    for zc in 0 5 10 15 20 26; do
+      J2P_ZONE_B=$zb J2P_ZONE_C=$zc sized 4096 4096 100 zones_${zb}_${zc} jpeg2png_amd/libjpeg2png_amd_exp.so
+    done
+  done | tee $O/r06_zones_4096.jsonl
+  ;;
+c)
+  # the per-SIMD picture with half / quarter items at the end of the launch
+  for z in "0 0" "26 10" "51 26" "100 50"; do
+    set -- $z
+    J2P_ZONE_B=$1 J2P_ZONE_C=$2 J2P_LIBRARY=ab/libj2p_tracex.so timeout 300 python tools/wave_trace.py 4096 4096 444 y 12 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())['launches']['k_gradient']; p=d['per_simd']
+print(json.dumps({'zones': '$1/$2', 'wavefronts': d['wavefronts'], 'span_us': p['span_us'], 'life': d['wave_life_us_p10_p50_p90_max'], 'busy_until': p['busy_until_us_p10_p50_p90_max'], 'mean_resident': p['mean_resident_wavefronts_per_simd'], 'resident_every_5us': p['resident_wavefronts_per_simd_over_time_every_5us'], 'start_p50_p90_max': d['wave_start_us_p50_p90_max']}))"
+  done | tee $O/r06_wave_trace_zones.jsonl
+  ;;
+d)
+  # who are the long-lived wavefronts of k_gradient (no zones)?
+  J2P_LIBRARY=ab/libj2p_tracex.so J2P_ZONE_B=0 J2P_ZONE_C=0 timeout 300 python tools/wave_trace.py 4096 4096 444 y 12 2>$O/r06_d.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())['launches']['k_gradient']['who_lives_long']
+for k,v in d.items(): print(k, json.dumps(v))" | tee $O/r06_who_lives_long.txt
+  tail -3 $O/r06_d.err
+  ;;
+e)
+  # workgroups of four consecutive (tile row, strip) pairs: parity, the per-SIMD picture, then zones by canvas size
+  ( timeout 900 python -m pytest tests/test_parity_gpu.py -q -x --timeout 600 -k "half_and_quarter or schedule_switch or joint_modes or full_size_against or band" ) > $O/r06_e_tests.log 2>&1; echo "tests rc=$?"; tail -8 $O/r06_e_tests.log
+  for z in "0 0" "32 10"; do
+    set -- $z
+    J2P_ZONE_B=$1 J2P_ZONE_C=$2 J2P_LIBRARY=ab/libj2p_tracex.so timeout 300 python tools/wave_trace.py 4096 4096 444 y 12 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())['launches']['k_gradient']; p=d['per_simd']
+print(json.dumps({'zones': '$1/$2', 'wavefronts': d['wavefronts'], 'span_us': p['span_us'], 'life': d['wave_life_us_p10_p50_p90_max'], 'per_simd_histogram': p['wavefronts_per_simd_histogram'], 'busy_until': p['busy_until_us_p10_p50_p90_max'], 'mean_resident': p['mean_resident_wavefronts_per_simd'], 'resident_every_5us': p['resident_wavefronts_per_simd_over_time_every_5us'], 'start_p50_p90_max': d['wave_start_us_p50_p90_max']}))"
+  done | tee $O/r06_wave_trace_linear.jsonl
+  for sz in "2048 2048" "4096 2048" "4096 4096" "8192 4096" "16384 2048" "8192 8192"; do
+    set -- $sz
+    for z in "0 0" "32 10" "64 20" "0 0" "32 10"; do
+      set -- $sz $z
+      J2P_ZONE_B=$3 J2P_ZONE_C=$4 sized $1 $2 100 zones_$3_$4 jpeg2png_amd/libjpeg2png_amd_exp.so
+    done
+  done | tee $O/r06_zones_by_size.jsonl
+  ;;
+f)
+  # half / quarter shares on mid-size canvases (1080p: 8-row tile rows, halves only)
+  ( timeout 600 python -m pytest tests/test_parity_gpu.py -q -x --timeout 600 -k "half_and_quarter or drop_in" ) > $O/r06_f_tests.log 2>&1; echo "tests rc=$?"; tail -5 $O/r06_f_tests.log
+  for sz in "1920 1080" "2048 2048" "3072 2048" "4096 2048" "4096 3072" "4096 4096"; do
+    for z in "0 0" "32 10" "64 20" "96 32" "128 40" "160 64" "256 0" "0 0"; do
+      set -- $sz $z
+      J2P_ZONE_B=$3 J2P_ZONE_C=$4 sized $1 $2 100 zones_$3_$4 jpeg2png_amd/libjpeg2png_amd_exp.so
+    done
+  done | tee $O/r06_zones_mid_sizes.jsonl
+  ;;
+esac

@@ -28,7 +28,10 @@ s.trace(True)
 s.run(its)
 s.sync()
 rec = s.trace(False, fetch=True)
-rec = rec[rec[:, 0] != 0]           # wavefronts past the launch's last strip leave their slot empty
+slot_all = np.arange(rec.shape[0])
+keep = rec[:, 0] != 0               # wavefronts past the launch's last strip leave their slot empty
+slot_all = slot_all[keep]
+rec = rec[keep]
 s.close()
 tag = (rec[:, 3] >> np.uint64(56)).astype(int)
 seq = ((rec[:, 3] >> np.uint64(32)) & np.uint64(0xffffff)).astype(int)
@@ -70,4 +73,63 @@ for k in (1, 2):
         "wave_life_us_p10_p50_p90_max": [round(float(v), 2) for v in np.median(np.array(lives), axis=0)],
         "cus_used_min_max_waves_per_cu": [int(v) for v in np.median(np.array(percu), axis=0)],
     }
+    # the per-SIMD picture of ONE launch (the middle one of those traced): how many wavefronts each SIMD got, how long it
+    # was busy (sum of its wavefronts' lives / its residency), when it ran dry (busy-until), and how full the chip was
+    q = seqs[len(seqs) // 2]
+    m = (tag == k) & (seq == q)
+    t0, t2 = rec[m, 0].astype(np.int64), rec[m, 2].astype(np.int64)
+    base = t0.min()
+    span = (t2.max() - base) * 0.01
+    skey = cu_key[m] * 4 + simd[m]
+    keys = np.unique(skey)
+    nw = np.array([(skey == s_).sum() for s_ in keys])
+    until = np.array([(t2[skey == s_].max() - base) * 0.01 for s_ in keys])
+    first = np.array([(t0[skey == s_].min() - base) * 0.01 for s_ in keys])
+    life = np.array([((t2 - t0)[skey == s_]).sum() * 0.01 for s_ in keys])
+    # wavefronts resident on the chip over the launch, sampled every 0.5 us
+    ts = np.arange(0, span, 0.5)
+    resident = np.array([((t0 - base) * 0.01 <= t).sum() - ((t2 - base) * 0.01 <= t).sum() for t in ts])
+    hist = collections.Counter(nw.tolist())
+    out["launches"][names[k]]["per_simd"] = {
+        "launch_seq": int(q), "span_us": round(float(span), 2), "simds_used": int(len(keys)),
+        "wavefronts_per_simd_histogram": {str(a): int(b) for a, b in sorted(hist.items())},
+        "busy_until_us_p10_p50_p90_max": [round(float(v), 2) for v in np.percentile(until, [10, 50, 90, 100])],
+        "first_start_us_p50_p90_max": [round(float(v), 2) for v in np.percentile(first, [50, 90, 100])],
+        "busy_until_us_by_wavefront_count": {str(a): round(float(np.median(until[nw == a])), 2) for a in sorted(hist)},
+        "mean_resident_wavefronts_per_simd": round(float(life.sum() / (len(keys) * span)), 2),
+        "resident_wavefronts_per_simd_over_time_every_5us": [round(float(v) / len(keys), 2) for v in resident[::10]],
+    }
+    if k == 1 and y_only and __import__("os").environ.get("J2P_ZONE_B") == "0" and __import__("os").environ.get("J2P_ZONE_C") == "0":
+        # who are the long-lived wavefronts?  (whole tile rows only: slot -> workgroup -> (tile row, strip), grad_item)
+        sl = slot_all[m] - slot_all[m].min()
+        b_, wv = sl // 4, sl % 4
+        ntx = (W - 4 + 123) // 124
+        ntr = (H + 15) // 16
+        n = (ntx * ntr + 3) // 4
+        qx, jx = b_ & 7, b_ >> 3
+        cb = qx * (n >> 3) + np.minimum(qx, n & 7)
+        ident = 4 * (cb + jx) + wv
+        trow, wcol = ident // ntx, ident % ntx
+        life_w = (t2 - t0) * 0.01
+        start_w = (t0 - base) * 0.01
+        xcc = (hw[m] >> 24) & 0xf
+        def by(keyv, nbins=None):
+            out_ = {}
+            for v in sorted(set(keyv.tolist())):
+                sel = keyv == v
+                out_[str(v)] = [round(float(np.median(life_w[sel])), 2), round(float(np.percentile(life_w[sel], 95)), 2), int(sel.sum())]
+            return out_
+        long_ = life_w > np.percentile(life_w, 98)
+        out["launches"][names[k]]["who_lives_long"] = {
+            "life_p50_p95_count_by_xcd": by(xcc),
+            "life_p50_p95_count_by_strip_column": by(wcol),
+            "life_p50_p95_count_by_start_5us": by((start_w // 5).astype(int) * 5),
+            "life_p50_p95_count_by_tile_row_mod_32": by(trow % 32),
+            "life_p50_p95_count_by_simd": by(simd[m]),
+            "wavefronts_by_simd_x_wave_in_workgroup": np.bincount(simd[m] * 4 + wv, minlength=16).reshape(4, 4).tolist(),
+            "top2pct": {"n": int(long_.sum()), "strip_columns": collections.Counter(wcol[long_].tolist()).most_common(8),
+                        "xcd": collections.Counter(xcc[long_].tolist()).most_common(8),
+                        "tile_rows_mod_32": collections.Counter((trow[long_] % 32).tolist()).most_common(8),
+                        "start_5us": collections.Counter(((start_w[long_] // 5).astype(int) * 5).tolist()).most_common(12)},
+        }
 print(json.dumps(out))
