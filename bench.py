@@ -485,36 +485,87 @@ def per_kernel_roofline(px_gradient, px_project, g_ms, p_ms):
     return per_kernel
 
 
-def pmc_traffic():
-    """HBM bytes per iteration from the rocprofv3 PMC passes of the N = 1 workload (profiles/, corrected as
-    MI355X_MICROARCH.md prescribes)"""
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
-        pmc = os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json")
-        if not os.path.exists(pmc):
-            continue
-        with open(pmc) as f:
+def _pmc_phase_bytes(path):
+    """k_gradient + k_project bytes per launch at the L2's memory side from one tools/pmc_summary.py file, or None"""
+    try:
+        with open(path) as f:
             summ = json.load(f)
-        tot = {}
-        for name, v in summ.items():
-            if isinstance(v, dict) and "hbm_bytes_per_launch" in v:
-                for kk in ("k_gradient", "k_project"):
-                    if name.startswith("j2p::" + kk) or name.startswith(kk):
-                        tot[kk] = v["hbm_bytes_per_launch"]
-        if len(tot) == 2:
-            return tot["k_gradient"] + tot["k_project"], f"profiles/{tag}_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE; k_gradient + k_project)"
+    except (OSError, ValueError):
+        return None
+    tot = {}
+    for name, v in summ.items():
+        if isinstance(v, dict) and "hbm_bytes_per_launch" in v:
+            for kk in ("k_gradient", "k_project"):
+                if name.startswith("j2p::" + kk) or name.startswith(kk):
+                    tot[kk] = v["hbm_bytes_per_launch"]
+    return tot["k_gradient"] + tot["k_project"] if len(tot) == 2 else None
+
+
+def pmc_traffic(W=4096, H=4096):
+    """HBM bytes per iteration of a WxH Y plane solved on one GPU, from the committed rocprofv3 PMC passes (profiles/,
+    corrected as MI355X_MICROARCH.md prescribes: FETCH_SIZE x2 + WRITE_SIZE): the per-shape files of round 6
+    (profiles/r06_pmc_<W>x<H>.json: 4096^2, the band shapes and the canvases past the Infinity Cache), else — the
+    headline shape only — the newest rNN_pmc_summary.json"""
+    shape = os.path.join(ROOT, "profiles", f"r06_pmc_{W}x{H}.json")
+    got = _pmc_phase_bytes(shape)
+    if got is not None:
+        return got, f"profiles/r06_pmc_{W}x{H}.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE; k_gradient + k_project of a {W}x{H} plane on one GPU)"
+    if (W, H) == (4096, 4096):
+        for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
+            got = _pmc_phase_bytes(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"))
+            if got is not None:
+                return got, f"profiles/{tag}_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE; k_gradient + k_project)"
+    return None, None
+
+
+def band_pmc_traffic(W, rows):
+    """HBM bytes per iteration of ONE band of a row-tiled run (k_gradient + k_project of a `rows`-row band of a W-wide
+    plane, exchange `direct`), from profiles/r06_pmc_band.json — collected on one GPU with two bands (tools/band_pmc.py)"""
+    path = os.path.join(ROOT, "profiles", "r06_pmc_band.json")
+    try:
+        with open(path) as f:
+            about = json.load(f).get("_shape")
+    except (OSError, ValueError):
+        return None, None
+    if about != [W, rows]:
+        return None, None
+    got = _pmc_phase_bytes(path)
+    if got is None:
+        return None, None
+    return got, (f"profiles/r06_pmc_band.json (rocprofv3 --pmc, FETCH_SIZE x2 + WRITE_SIZE; k_gradient + k_project of one {W}x{rows} band "
+                 "of a two-band run on one GPU, exchange direct: per GPU and iteration)")
+
+
+def rocprof_kernel_us():
+    """the phase kernels' average launch durations on the headline workload as rocprofv3 saw them (the committed kernel
+    stats of the bench command, profiles/rNN_bench_kernel_stats.csv): what the HIP-event figures of this run stand beside"""
+    import csv
+    for tag in ("r06", "r05", "r04", "r03"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats.csv")
+        if not os.path.exists(path):
+            continue
+        out = {}
+        for r in csv.DictReader(open(path)):
+            for kk in ("k_gradient", "k_project", "k_norm_whole"):
+                if ("j2p::" + kk) in r["Name"] and kk not in out:
+                    out[kk] = round(float(r["AverageNs"]) / 1e3, 2)
+        if "k_gradient" in out and "k_project" in out:
+            return out, f"profiles/{tag}_bench_kernel_stats.csv"
     return None, None
 
 
 def roofline_object(value_mpx, gpus_used, its, elapsed, steps, band_px, per_kernel, samples, timing_every, traffic=None, traffic_src=None):
     kern = min(per_kernel, key=lambda k: per_kernel[k]["frac"])
     it_gbs = BYTES_ITERATION * value_mpx * 1e6 / gpus_used / 1e9
-    return {"bound": "hbm", "scope": "whole iteration (k_gradient + k_project, launch gaps included), wall clock, per GPU",
+    return {"bound": "hbm", "scope": "whole iteration (k_gradient + k_project, launch gaps included), wall clock, per GPU; "
+                                     "`frac` is that; `kernel` names the phase kernel with the lower per-kernel fraction and "
+                                     "`event_kernel_frac` is ITS fraction from this run's HIP-event brackets",
             "kernel": kern, "achieved": round(it_gbs, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(it_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
             "traffic_unit": "bytes per iteration", "traffic_source": traffic_src,
             "algorithmic_bytes_per_iteration": band_px * BYTES_ITERATION,
             "iteration_ms": round(elapsed / steps / its * 1e3, 5),
-            "kernel_frac": per_kernel[kern]["frac"],
+            "event_kernel_frac": per_kernel[kern]["frac"],
             "per_kernel": per_kernel,
             "event_samples": samples, "event_pair_overhead_us": EVENT_PAIR_US,
             "note": "per-kernel durations come from HIP events around every "
@@ -550,7 +601,16 @@ def single_gpu(a, j, synth, local_rank):
     # the plane the LAST timed step left behind (every step is a whole solve from iteration 0), against the reference's
     parity = parity_object(plane_digest(solver.download(0)), W, H, its, seed)
     per_kernel = per_kernel_roofline(px, px, g_ms, p_ms)
-    traffic, traffic_src = pmc_traffic() if not a.size else (None, None)
+    traffic, traffic_src = pmc_traffic(W, H)          # (a shape without committed counters: null)
+    roof = roofline_object(value, 1, its, elapsed, a.steps, px, per_kernel, samples, a.timing_every, traffic, traffic_src)
+    if not a.size:
+        # the reproducible per-kernel figures: rocprofv3's, from the committed stats of this same command
+        prof, prof_src = rocprof_kernel_us()
+        if prof:
+            roof["rocprof_per_kernel"] = {
+                "source": prof_src, "avg_launch_us": prof,
+                "frac": {k: round(px * b / (prof[k] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                         for k, b in (("k_gradient", BYTES_GRADIENT), ("k_project", BYTES_PROJECT)) if k in prof}}
     out = {
         "metric": "Mpixel-iterations/sec on 4K Y-plane", "value": round(value, 1),
         "unit": "Mpixel-iterations/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
@@ -558,7 +618,7 @@ def single_gpu(a, j, synth, local_rank):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "iterations_per_step": its, "weight": WEIGHT, "pweight": PWEIGHT,
                    "parallelism": "single GPU", "launches_per_iteration": launches},
-        "roofline": roofline_object(value, 1, its, elapsed, a.steps, px, per_kernel, samples, a.timing_every, traffic, traffic_src),
+        "roofline": roof,
         "parity": parity,
     }
     if parity["bit_identical"] is False:
@@ -618,6 +678,14 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
 
     legs = {}
     want_c = a.tiled_impl in ("both", "c")
+    # what this run can cost at worst: every child leg has its own timeout, the per-rank harness a watchdog (rank 0, stderr,
+    # and in the line: the driver's window has to hold it)
+    n_c_legs = (4 if nband > 2 else 2) + 2 if want_c else 0
+    worst_case_s = n_c_legs * C_LEG_TIMEOUT_S + RCCL_LEG_TIMEOUT_S
+    if rank == 0:
+        print(f"bench: row-tiled run over {n_gpus} GPU(s): up to {n_c_legs} child legs of at most {C_LEG_TIMEOUT_S} s each + the per-rank "
+              f"RCCL harness (watchdog {RCCL_LEG_TIMEOUT_S} s): {worst_case_s} s at worst before the whole-canvas solve, the batch and "
+              "the CPU baseline", file=sys.stderr, flush=True)
     # (the RCCL harness needs one rank per GPU: not in the one-device rehearsal, and with a single rank only on request)
     want_rccl = (a.tiled_impl == "rccl" or (a.tiled_impl == "both" and world > 1)) and not (one_device and world > 1)
 
@@ -650,6 +718,8 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
             env.pop("J2P_TILED_WAIT", None)
             if exchange:
                 env["J2P_TILED_EXCHANGE"] = exchange                  # read by j2p_tiled_create
+            else:
+                env["J2P_TILED_VERIFY"] = "2"                         # the picker at work, and its measurements on stderr
             if wait:
                 env["J2P_TILED_WAIT"] = wait
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
@@ -677,8 +747,12 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
                                 + ": four launches per band and iteration",
                         "rccl": "ncclAllGather of the row sums + grouped ncclSend / ncclRecv of the edge rows on the band streams "
                                 "(librccl dlopen()ed by the C library, one communicator per band)"}.get(how, how)
+                # what the library said while it chose / verified its exchange on these GPUs: one line per candidate it
+                # demoted or found unavailable, and — the picker's leg — each verified candidate's us per scratch iteration
+                picker = [ln.strip() for ln in r.stderr.splitlines() if ln.startswith("jpeg2png_amd: row tiling")]
                 legs[name] = {"elapsed": res["elapsed"], "g_ms": res["g_ms"], "p_ms": res["p_ms"], "samples": res["samples"], "split": False,
                               "host_cpu_s": res["host_cpu_s"], "digest": res["digest"], "exchange": how,
+                              "create_s": res.get("create_s"), "picker_log": picker, "rccl": res.get("rccl"),
                               "parallelism": (f"row-tiled x{nband}: C engine (j2p_tiled), one process drives all GPUs, one host thread per "
                                               f"band; exchange '{how}': {what}")}
             except subprocess.TimeoutExpired:
@@ -736,23 +810,36 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
             others.append({"config": f"the same workload through the other engine ({k})", "parallelism": v["parallelism"],
                            "Mpx_it_per_s": round(px * its * a.steps / v["elapsed"] / 1e6, 1),
                            "ms_per_step": round(v["elapsed"] / a.steps * 1e3, 3),
-                           "bits_equal_to_the_whole_canvas_solve": v["verified"]})
+                           "us_per_iteration": round(v["elapsed"] / a.steps / its * 1e6, 2),
+                           "bits_equal_to_the_whole_canvas_solve": v["verified"],
+                           **{kk: v[kk] for kk in ("create_s", "picker_log", "rccl") if v.get(kk)}})
         for k, v in legs.items():
             if not isinstance(v, dict):
                 others.append({"config": f"engine {k}", "error": v})
         others += extra_other or []
         gpus_used = n_gpus if n_gpus > 1 else 1
+        # real bytes of ONE band's iteration (committed counters of a 2048-row band of the 16384-wide plane in a linked run)
+        traffic, traffic_src = band_pmc_traffic(W, rows_per_gpu)
         out = {
             "metric": (f"Mpixel-iterations/sec on a 16384-wide Y plane row-tiled over {n_gpus} GPUs, 2048 rows per GPU "
                        "(BASELINE configs[3] at 8 GPUs)") if not a.size else "Mpixel-iterations/sec, row-tiled Y plane (debug size)",
             "value": round(value, 1),
             "unit": "Mpixel-iterations/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(L["elapsed"] / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "scaling_note": (f"weak: every GPU holds {rows_per_gpu} rows of the {W}-wide plane whatever N, so the canvas grows with N "
+                             "and `value` is the whole job's rate on it; the ratio to ONE GPU solving that same canvas whole — a "
+                             "strong-scaling figure — is reported separately in other_configs (strong_scaling_speedup)"),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "iterations_per_step": its, "weight": WEIGHT, "pweight": PWEIGHT,
                        "parallelism": L["parallelism"], "engine": best, "band_threads_host_cpu_s": L.get("host_cpu_s"),
-                       "bits_equal_to_the_whole_canvas_solve": L["verified"]},
-            "roofline": roofline_object(value, gpus_used, its, L["elapsed"], a.steps, band_px, per_kernel, L["samples"], a.timing_every),
+                       "bits_equal_to_the_whole_canvas_solve": L["verified"],
+                       "us_per_iteration": round(L["elapsed"] / a.steps / its * 1e6, 2),
+                       # the exchange was chosen by the library on these GPUs (leg `c`): what it verified, demoted, measured
+                       "picker_log": (legs.get("c") or {}).get("picker_log") if isinstance(legs.get("c"), dict) else None,
+                       "create_s": L.get("create_s"), "rccl": L.get("rccl"),
+                       "worst_case_seconds_of_the_legs": worst_case_s},
+            "roofline": roofline_object(value, gpus_used, its, L["elapsed"], a.steps, band_px, per_kernel, L["samples"], a.timing_every,
+                                        traffic, traffic_src),
             "parity": parity_object(L.get("digest"), W, H, its, seed),
             "other_configs": others,
         }
@@ -845,7 +932,7 @@ def tiled(a, j, synth, rank, world, local_rank, one_device):
             r["parity"] = parity_object(whole.get("digest"), W, H, its, seed)
             r["config"] = (f"strong-scaling denominator: the SAME {W}x{H} canvas solved whole on ONE GPU, -i {its} "
                            "(value / this = speed-up of the tiling; its plane's hash is what every leg is compared with)")
-            r["speedup_of_the_tiled_run"] = round(state["out"]["value"] / r["Mpx_it_per_s"], 3)
+            r["strong_scaling_speedup"] = round((state["out"]["value"] or state["out"].get("unverified_value") or 0.0) / r["Mpx_it_per_s"], 3)
             extra.append(r)
         else:
             extra.append({"config": "strong-scaling denominator", "error": (whole or {}).get("error", "not run")})
@@ -876,7 +963,9 @@ def leg_child(spec_json):
     try:
         plane = synth.Plane(spec["W"], spec["H"], 1, 1, np.load(spec["plane"]), np.array(spec["quant"], dtype=np.uint16))
         its = spec["its"]
+        t_create = time.perf_counter()
         with j.TiledSolver([plane], WEIGHT, [PWEIGHT], its, devices=spec["devices"]) as t:
+            create_s = time.perf_counter() - t_create        # (the picker's verification of every candidate is in here)
             eng = t.band_solver(0)
             for _ in range(spec["warmup"]):
                 t.reset()
@@ -892,7 +981,10 @@ def leg_child(spec_json):
             g_ms, p_ms, samples = eng.kernel_times()
             eng.enable_timing(0)
             out = {"elapsed": elapsed, "g_ms": g_ms, "p_ms": p_ms, "samples": samples, "host_cpu_s": round(t.host_cpu_seconds(), 3),
-                   "exchange": t.exchange(), "digest": plane_digest(t.download(0))}
+                   "exchange": t.exchange(), "digest": plane_digest(t.download(0)), "create_s": round(create_s, 3)}
+            if out["exchange"] == "rccl":
+                out["rccl"] = {"ncclGetVersion": j.rccl_version(), "nranks_of_ncclCommInitAll": len(spec["devices"]),
+                               "devices": spec["devices"]}
     except Exception as e:              # noqa: BLE001
         out = {"error": f"{type(e).__name__}: {e}"}
     _flush_c_stdio()

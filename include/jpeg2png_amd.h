@@ -288,6 +288,9 @@ int j2p_tiled_run(j2p_tiled *t, unsigned n, j2p_log_row *rows);   /* asynchronou
 int j2p_tiled_sync(j2p_tiled *t);
 int j2p_tiled_download(j2p_tiled *t, unsigned c, float *out);      /* W * H floats */
 int j2p_tiled_host_cpu_seconds(const j2p_tiled *t, double *seconds);
+/* the librccl the "rccl" exchange would use (dlopen, J2P_RCCL_LIBRARY): ncclGetVersion's code (e.g. 22203), J2P_EDEVICE
+ * when no usable library is found — the exchange SURVEY.md §8e names (RCCL halo send/recv + norm all-gather) */
+int j2p_rccl_version(int *version);
 int j2p_tiled_exchange(const j2p_tiled *t, const char **name);    /* "direct" ("direct, wait root" / "…collector"), "copy", "rccl"; "none": one plain band */
 
 /* CSV logging for band solvers (the "+3 doubles when logging" of the norm exchange): with logging on, the

@@ -79,7 +79,7 @@ C_ABI_SYMBOLS = [
     "j2p_pool_trim", "j2p_solver_debug_option", "j2p_solver_stream", "j2p_solver_halo_rows",
     "j2p_solver_norm_from_bands", "j2p_solver_copy_rows", "j2p_solver_alternate_rowsums",
     "j2p_tiled_create", "j2p_tiled_destroy", "j2p_tiled_canvas", "j2p_tiled_band", "j2p_tiled_run", "j2p_tiled_reset", "j2p_tiled_sync",
-    "j2p_tiled_download", "j2p_tiled_host_cpu_seconds", "j2p_solver_norm_ptr", "j2p_solver_norm_external",
+    "j2p_tiled_download", "j2p_tiled_host_cpu_seconds", "j2p_rccl_version", "j2p_solver_norm_ptr", "j2p_solver_norm_external",
     "j2p_solver_global_rowsums", "j2p_solver_link_bands", "j2p_tiled_exchange",
     "j2p_batch_create", "j2p_batch_destroy", "j2p_batch_submit", "j2p_batch_wait",
     "compute", "j2p_compute", "j2p_compute_tiled", "j2p_compute_timing", "j2p_debug_fail_run_after", "j2p_solver_launches_per_iteration", "j2p_solver_timing_overhead",
@@ -236,6 +236,12 @@ def _check(rc):
 def debug_build():
     """True when the loaded library was compiled with -DJ2P_DEBUG (address checks in the phase kernels)"""
     return bool(load_library().j2p_debug_build())
+
+
+def rccl_version():
+    """ncclGetVersion of the librccl the C row tiling would dlopen for its `rccl` exchange, or None (no usable library)"""
+    v = ctypes.c_int(0)
+    return v.value if load_library().j2p_rccl_version(ctypes.byref(v)) == 0 else None
 
 
 def experiments_build():

@@ -254,6 +254,10 @@ struct Geo {
         // rows) and tile rows of the launch, and the shares (in 1/256) of every XCD's run that are dealt as half and as
         // quarter tile rows
         unsigned units, ntr_launch, zone_b, zone_c;
+        // 1: the launch walks the canvas bottom-up (unit n - 1 - u instead of u).  k_project walks top-down, so each
+        // phase then STARTS on the rows the phase before touched last — what the Infinity Cache still holds of planes
+        // that do not fit it (j2p_solver_create: canvases whose two planes exceed the cache)
+        unsigned reverse;
 #ifdef J2P_TRACE
         unsigned long long *trace;   // TraceRec buffer (record 0 unused) or NULL
         unsigned trace_cap, trace_seq, trace_base;
@@ -1699,6 +1703,7 @@ __device__ __forceinline__ bool grad_item(const Geo &g, unsigned b, int wave, St
         } else {
                 return false;
         }
+        if(g.reverse) { u = n - 1 - u; }
         const unsigned id = J == 1 ? 4 * u + strip_in_group : u;        // (tile row, strip) of the launch, row-major
         const unsigned tr_launch = id / g.ntx;
         it.tr = g.seg_off + tr_launch * g.seg_mul;

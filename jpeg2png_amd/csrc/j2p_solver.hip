@@ -97,6 +97,7 @@ struct j2p_solver {
         // reductions
         bool fold = false;       // norm reduction folded into k_gradient (J2P_OPT_NORM_FOLD); default: band solvers only
         unsigned zone_b = 0, zone_c = 0;   // shares (1/256) of a gradient launch dealt as half / quarter tile rows (grad_item)
+        bool grad_reverse = false;         // the gradient launch walks the canvas bottom-up (Geo::reverse)
         bool joint_inwave = false;   // J2P_OPT_JOINT_INWAVE
         bool norm_in_project = false;   // J2P_OPT_NORM_IN_PROJECT (with fold): level 2 of the norm inside k_project
         int nip_form = 1;               // ... by every wavefront (1: small canvases) or by the workgroup's first (2), see project_strip
@@ -317,9 +318,9 @@ constexpr unsigned long long kPx1Waves = 0;
 // the batch case, where the chip is full anyway — lose 5.7 %; not taken
 constexpr unsigned long long kHalfStripWaves = 2048;
 constexpr unsigned long long kShortStripWaves = 2048;
-// half / quarter items at the end of a gradient launch (see j2p_solver_create): from this many 16-row strips on, and the
-// shares (1/256) of every XCD's run dealt that way
-constexpr unsigned long long kZoneWaves = 6144;
+// half / quarter items at the end of a gradient launch (see j2p_solver_create): launches of fewer strips than this, and
+// the shares (1/256) of every XCD's run dealt that way
+constexpr unsigned long long kZoneMaxWaves = 3 * 4096;
 constexpr unsigned kZoneB = 32, kZoneC = 10;
 
 unsigned gcd_u(unsigned a, unsigned b) { return b ? gcd_u(b, a % b) : a; }
@@ -404,6 +405,7 @@ Geo geo_of(const j2p_solver *s)
         g.units = 0;            // (do_phase_gradient fills in the launch's own)
         g.ntr_launch = 0;
         g.zone_b = g.zone_c = 0;
+        g.reverse = 0;
 #ifdef J2P_TRACE
         g.trace = s->trace_on ? s->trace : nullptr;
         g.trace_cap = s->trace_cap;
@@ -548,6 +550,7 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         a.geo.ntr_launch = nseg_launch;
         // (half / quarter items: whole phases of one channel per workgroup wavefront, see the policy in j2p_solver_create)
         if(part == 0 && s->nch == 1) { a.geo.zone_b = s->zone_b; a.geo.zone_c = s->zone_c; }
+        a.geo.reverse = part == 0 && s->grad_reverse ? 1u : 0u;
         a.factor = s->factor;
         a.a_tv = (float)(1. / (double)sqrtf((float)s->nch));                    // compute.c:90
         const float alpha = s->weight / sqrtf((float)(4 / 2));                  // compute.c:258
@@ -1076,13 +1079,17 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 s->rpw = g;
                 s->ntx = strips(px);
                 // The LAST wavefronts of a gradient launch march half and quarter tile rows (grad_item): a launch ends with
-                // its last wavefront, and on a canvas of several wavefront generations a whole 16-row item dispatched last
-                // keeps a few SIMDs busy for a wavefront life (17 us of 53 at 4096^2, profiles/r06_wave_trace.jsonl) while
-                // the rest of the chip drains.  Shares in 1/256 of every XCD's run; one channel per workgroup wavefront,
-                // 16-row tile rows, at least kZoneWaves strips.  Who marches a row never changes a bit (march_rows).
-                if(nchannel == 1 && g == kTY && waves(px, g) >= kZoneWaves) {
+                // its last wavefront, and a whole 16-row item dispatched last keeps a few SIMDs busy for a wavefront life
+                // (17 us of 53 at 4096^2, profiles/r06_wave_trace.jsonl) while the rest of the chip drains.  Shares in
+                // 1/256 of every XCD's run; one channel per workgroup wavefront.  Who marches a row never changes a bit
+                // (march_rows), so the choice may depend on the BAND: measured (profiles/r06_zones_mid_sizes.jsonl,
+                // r06_zones_by_size.jsonl; us per iteration without / with) 1080p 30.1 / 28.7, 2048^2 45.5 / 42.2,
+                // 4096x2048 70.9 / 67.8, 4096x3072 94.2 / 92.0, 4096^2 120.0 / 118.7; nothing from three wavefront
+                // generations on (8192x4096 235.3 / 235.9, 16384x2048 230.8 / 231.1, 8192^2 515.7 / 515.8).
+                const unsigned long long launch_waves = (unsigned long long)strips(px) * ((s->rows + g - 1) / g);
+                if(nchannel == 1 && g >= 8 && launch_waves < kZoneMaxWaves) {
                         s->zone_b = kZoneB;
-                        s->zone_c = kZoneC;
+                        s->zone_c = g >= 16 ? kZoneC : 0;
                 }
                 // (halves need two groups of four rows per tile row, quarters four: march_rows)
                 if(const char *env = j2p_exp_env("J2P_ZONE_B")) { if(nchannel == 1 && g >= 8) { s->zone_b = (unsigned)atoi(env); } }
@@ -1163,6 +1170,11 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 live_add(device, LiveBytes{s->live_ws, s->live_g, s->live_planes, s->live_d}, +1);
                 s->live_registered = true;
                 s->nt = nt_policy(s);
+                // canvases whose planes x_k, x_{k-1} do not both fit the Infinity Cache: the gradient phase walks bottom-up
+                // (k_project walks top-down), so that each phase starts on the rows the one before touched last (Geo::reverse).
+                // Schedule only: the bits do not depend on who marches a row when.
+                s->grad_reverse = s->live_planes > kNtWorkingSet;
+                if(const char *env = j2p_exp_env("J2P_GRAD_REVERSE")) { s->grad_reverse = atoi(env) != 0; }
         }
 
         // ---- uploads (host arrays: whole-image unless band_local) ----

@@ -91,6 +91,7 @@ struct Rccl {
         int (*GroupStart)() = nullptr;
         int (*GroupEnd)() = nullptr;
         const char *(*GetErrorString)(int) = nullptr;
+        int (*GetVersion)(int *version) = nullptr;          // optional
         char why[256] = "";
 };
 constexpr int kNcclFloat32 = 7, kNcclFloat64 = 8;
@@ -136,6 +137,7 @@ Rccl *rccl_load()
         RCCL_SYM(GroupEnd, "ncclGroupEnd");
         RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef RCCL_SYM
+        *reinterpret_cast<void **>(&r->GetVersion) = dlsym(r->handle, "ncclGetVersion");
         lib = r;
         return lib;
 }
@@ -1147,6 +1149,16 @@ int j2p_tiled_create(j2p_tiled **out, unsigned nband, const int devices[], const
                 }
         }
         return tiled_create_impl(out, nband, devices, cuts, nchannel, planes, weight, pweight, iterations, plan);
+}
+
+int j2p_rccl_version(int *version)
+{
+        if(!version) { return j2p_fail(J2P_EINVAL, "NULL argument"); }
+        *version = 0;
+        Rccl *r = rccl_load();
+        if(!rccl_usable(r)) { return j2p_fail(J2P_EDEVICE, "%s", r ? r->why : "out of host memory"); }
+        if(!r->GetVersion || r->GetVersion(version) != 0) { return j2p_fail(J2P_EDEVICE, "librccl has no ncclGetVersion"); }
+        return J2P_OK;
 }
 
 int j2p_tiled_exchange(const j2p_tiled *t, const char **name)

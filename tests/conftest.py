@@ -28,9 +28,25 @@ def parity_note(msg):
 # GPU suite is about as long, so the reference run starts in a worker thread as soon as collection has finished —
 # if the test that needs it was selected — and the test is moved to the end of the run, where it joins the thread.
 # (ctypes releases the GIL during the call; the plane is synthesised by worker processes.)
+# The run must not be able to turn a green suite red under `-x` on a slower or smaller lease: it is not started with
+# less than 12 GiB of host memory available (it needs ~9), and the test waits for it only as long as the suite's time
+# budget allows (J2P_GPU_SUITE_BUDGET_S, default 1100 s from the start of the session, less 120 s for the test's own GPU
+# work).  Without the live run the test compares with the SAME plane all the same — through the digest of the
+# reference's plane for this workload that tests/golden/bench_digests.json holds ("configs[3] N=8": generated from
+# oracle/_ref by make_golden.py --bench-digests) — and says so, loudly, in the parity section.
 # ---------------------------------------------------------------------------------------------------------------
 _CONFIG3_TEST = "test_config3_full_size_i100_vs_reference_whole_and_8_bands"
 _config3_job = {}
+
+
+def _mem_available_gib():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / (1 << 20)
+    except OSError:
+        pass
+    return None
 
 
 def _config3_work():
@@ -47,6 +63,10 @@ def _config3_work():
         plane = synth.make_y_plane_banded(16384, 16384, 10, seed=1234 + 4, band_rows=1024, workers=16)
         plane.fdata = j.decode_plane(plane)           # device decode: bit-exact vs jpeg.c:83-92 (test_decode_plane_bit_exact)
         job["plane"] = plane
+        avail = _mem_available_gib()
+        if avail is not None and avail < 12.0:
+            job["no_reference"] = f"only {avail:.1f} GiB of host memory available (the reference's compute() on 16384x16384 needs ~9)"
+            return
         t0 = time.perf_counter()
         want, _, secs = bindings.ref_compute([plane], 0.3, [0.001], 100)
         job["want"] = want
@@ -61,8 +81,10 @@ def pytest_collection_finish(session):
     if session.config.option.collectonly:
         return
     import threading
+    import time
     th = threading.Thread(target=_config3_work, name="config3-reference", daemon=True)
     _config3_job["thread"] = th
+    _config3_job["t_session"] = time.perf_counter()
     th.start()
 
 
@@ -74,20 +96,31 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(scope="session")
 def config3_reference():
-    """callable -> (plane, reference planes, seconds inside the reference's compute(), seconds this call waited)"""
+    """callable -> (plane, reference planes or None, seconds inside the reference's compute(), seconds this call waited,
+    why there are no reference planes or None)"""
     def join():
         import time
-        if "thread" not in _config3_job:          # (the test was run in a way that skipped pytest_collection_finish)
+        job = _config3_job
+        if "thread" not in job:                   # (the test was run in a way that skipped pytest_collection_finish)
             _config3_work()
         else:
             t0 = time.perf_counter()
-            _config3_job["thread"].join()
-            _config3_job["waited"] = time.perf_counter() - t0
-        if "skip" in _config3_job:
-            pytest.skip(_config3_job["skip"])
-        if "error" in _config3_job:
-            raise _config3_job["error"]
-        return _config3_job["plane"], _config3_job["want"], _config3_job["seconds"], _config3_job.get("waited", 0.0)
+            budget = float(os.environ.get("J2P_GPU_SUITE_BUDGET_S", "1100"))
+            left = budget - (t0 - job["t_session"]) - 120.0
+            job["thread"].join(timeout=max(left, 0.0))
+            job["waited"] = time.perf_counter() - t0
+            if job["thread"].is_alive():
+                # (the plane itself is ready within the first minute; the thread goes on in the background and ends with the process)
+                while "plane" not in job and "error" not in job and "skip" not in job:
+                    time.sleep(0.5)
+                if "want" not in job:
+                    job["no_reference"] = (f"the reference's compute() had not finished {t0 - job['t_session'] + job['waited']:.0f} s into the "
+                                           f"session (budget {budget:.0f} s, J2P_GPU_SUITE_BUDGET_S)")
+        if "skip" in job:
+            pytest.skip(job["skip"])
+        if "error" in job:
+            raise job["error"]
+        return job["plane"], job.get("want"), job.get("seconds", 0.0), job.get("waited", 0.0), job.get("no_reference")
     return join
 
 

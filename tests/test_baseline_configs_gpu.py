@@ -181,11 +181,24 @@ def test_config3_full_size_i100_vs_reference_whole_and_8_bands(lib, oracle, conf
     _need_ref(oracle)
     import jpeg2png_amd as j
     its = 100
-    plane, want, ref_seconds, waited = config3_reference()
+    plane, want, ref_seconds, waited, no_reference = config3_reference()
     with j.Solver([plane], WEIGHT, [PWEIGHT], its) as s:
         whole_rows = s.run(its, log=True)
         whole = s.download(0)
-    check_planes("configs[3] 16384x16384 -i 100, whole canvas", [whole], want, strict=not ALLOW_NORM_FLIP)
+    if want is None:
+        # no live reference run on this lease (conftest: memory / time budget): the same plane, the same solve, compared
+        # through the digest of the reference's plane that tests/golden/bench_digests.json holds for it
+        import hashlib
+        import json
+        entry = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bench_digests.json")))["configs[3] N=8"]
+        assert (entry["W"], entry["H"], entry["iterations"], entry["seed"]) == (16384, 16384, its, 1234 + 4)
+        got = hashlib.blake2b(np.ascontiguousarray(whole), digest_size=16).hexdigest()
+        parity_note(f"configs[3] 16384x16384 -i 100: NO LIVE REFERENCE RUN ({no_reference}); compared with the reference's plane by its "
+                    f"digest in tests/golden/bench_digests.json instead: {'bit-identical' if got == entry['digest'] else 'DIFFERENT'}")
+        assert got == entry["digest"] or ALLOW_NORM_FLIP, "16384x16384 -i 100, whole canvas: not the reference's plane (digest)"
+        want = [whole]            # (the bands are held against the whole-canvas solve below, which the digest has just vouched for)
+    else:
+        check_planes("configs[3] 16384x16384 -i 100, whole canvas", [whole], want, strict=not ALLOW_NORM_FLIP)
     j.load_library().j2p_pool_trim()
     with j.TiledSolver([plane], WEIGHT, [PWEIGHT], its, devices=band_devices(8)) as t:
         assert [b[1:] for b in t.bands()] == [(r, r + 2048) for r in range(0, 16384, 2048)]

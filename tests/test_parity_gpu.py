@@ -640,7 +640,8 @@ def test_half_and_quarter_items_leave_the_bits_alone(exp_lib, oracle, shape, mon
     """the last workgroups of a large gradient launch march half and quarter tile rows (grad_item / march_rows in
     j2p_kernels.hip.h; the solver's own choice from 6144 strips on): who marches a row must not change a bit — every
     share of halves and quarters (in 1/256 of an XCD's run), on canvases whose last tile row is short (328 = 20 x 16 + 8),
-    whole and as bands, with the CSV sums, against the reference's bits"""
+    whole and as bands, with the CSV sums, top-down and bottom-up (what canvases past the Infinity Cache get), against
+    the reference's bits"""
     import jpeg2png_amd as j
     w, h, weight = shape
     planes = make_case(w, h, "444", 10, seed=97, y_only=True)
@@ -648,9 +649,10 @@ def test_half_and_quarter_items_leave_the_bits_alone(exp_lib, oracle, shape, mon
     want, want_rows = oracle.oracle_compute(planes, weight, [0.001], its, log=True)
     monkeypatch.setenv("J2P_PX", "2")
     monkeypatch.setenv("J2P_RPW", "16")
-    for zb, zc in ((0, 0), (256, 0), (0, 256), (100, 100), (64, 32), (26, 10), (1, 255)):
+    for zb, zc, rev in ((0, 0, 0), (256, 0, 0), (0, 256, 1), (100, 100, 0), (64, 32, 1), (26, 10, 0), (1, 255, 0), (0, 0, 1)):
         monkeypatch.setenv("J2P_ZONE_B", str(zb))
         monkeypatch.setenv("J2P_ZONE_C", str(zc))
+        monkeypatch.setenv("J2P_GRAD_REVERSE", str(rev))         # the launch walks the canvas bottom-up (Geo::reverse)
         got = copy.deepcopy(planes)
         rows = j.compute(got, weight, [0.001], its, log=True)
         assert bit_equal(got[0].fdata, want[0]), f"zones {zb}/{zc}"

@@ -84,4 +84,76 @@ f)
     done
   done | tee $O/r06_zones_mid_sizes.jsonl
   ;;
+g)
+  # canvases past the Infinity Cache (review item 2): real bytes at the L2's memory side, L2 hit rates, address translation;
+  # then the knobs one at a time at 8192^2 and 16384x2048: rows per strip 32 (timing only), ring of five row slots
+  cd /tmp
+  rocprofv3 --list-avail 2>/dev/null | grep -i -E "UTCL|TLB|TCC_HIT|TCC_MISS|TCC_EA0_RDREQ|TCC_EA0_WRREQ|TCP_TCC_READ|TCC_REQ|MALL|TCC_BUBBLE|TCC_EA0_RD_UNCACHED" | cut -c1-160 | sort -u | head -60 > $GRAFT_REPO_ROOT/$O/r06_counters_available.txt
+  cd $GRAFT_REPO_ROOT
+  for sz in "4096 4096" "8192 4096" "8192 8192" "16384 4096" "16384 8192"; do
+    set -- $sz
+    B2="python $GRAFT_REPO_ROOT/bench.py --size $1 --height $2 --steps 1 --warmup 0 --iterations 20 --no-cpu-baseline --no-other-configs --no-host-to-host"
+    T=$O/r06_pmc_$1x$2
+    ( cd /tmp
+      rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/${T}_stats -- $B2 > /dev/null 2>&1
+      rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/${T}_fetch -- $B2 > /dev/null 2>&1
+      rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/${T}_write -- $B2 > /dev/null 2>&1
+      rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $GRAFT_REPO_ROOT/${T}_l2 -- $B2 > /dev/null 2>&1
+      rocprofv3 --kernel-trace --pmc TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum --output-format csv -d $GRAFT_REPO_ROOT/${T}_tlb -- $B2 > /dev/null 2>&1 )
+    find ${T}_stats -name '*kernel_stats.csv' -exec cp {} ${T}_kernel_stats.csv \;
+    python tools/pmc_summary.py --about "$1x$2 Y, -i 20" ${T}_fetch ${T}_write ${T}_l2 ${T}_tlb > ${T}.json
+    rm -rf ${T}_stats ${T}_fetch ${T}_write ${T}_l2 ${T}_tlb
+    python -c "
+import json; d=json.load(open('${T}.json'))
+for k in ('j2p::k_gradient','j2p::k_project'):
+    v=[x for n,x in d.items() if n.startswith(k)]
+    print('$1x$2', k, json.dumps(v[0] if v else None))"
+    head -4 ${T}_kernel_stats.csv | cut -c1-200
+  done 2>&1 | tee $O/r06_pmc_big.log
+  for sz in "8192 8192" "16384 2048"; do
+    set -- $sz
+    for v in base rpw32 base ring5 rpw24; do
+      case $v in
+        base) sized $1 $2 50 base jpeg2png_amd/libjpeg2png_amd_exp.so ;;
+        rpw32) J2P_RPW=32 sized $1 $2 50 rpw32 jpeg2png_amd/libjpeg2png_amd_exp.so ;;
+        rpw24) J2P_RPW=24 sized $1 $2 50 rpw24 jpeg2png_amd/libjpeg2png_amd_exp.so ;;
+        ring5) sized $1 $2 50 ring5 ab/libj2p_bigring5.so ;;
+      h)
+  # does the row stride matter (a power-of-two stride keeps a strip's rows on one set of HBM channels)?  Same pixels per row +- 64
+  for sz in "4096 4096" "4160 4096" "8192 4096" "8256 4096" "8192 8192" "8256 8192" "8320 8192" "16384 2048" "16448 2048" "16384 4096" "16448 4096" "12288 8192" "8192 8192" "8256 8192"; do
+    set -- $sz
+    sized $1 $2 50 stride_probe
+  done | tee $O/r06_stride_probe.jsonl
+  ;;
+i)
+  # the gradient phase bottom-up, the projection top-down: each phase starts on what the Infinity Cache still holds
+  ( timeout 600 python -m pytest tests/test_parity_gpu.py -q -x --timeout 600 -k "half_and_quarter or schedule_switch" ) > $O/r06_i_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/r06_i_tests.log
+  for sz in "4096 4096" "8192 4096" "16384 2048" "8192 8192" "16384 4096" "16384 8192"; do
+    set -- $sz
+    for v in 0 1 0 1; do
+      J2P_GRAD_REVERSE=$v sized $1 $2 50 reverse$v jpeg2png_amd/libjpeg2png_amd_exp.so
+    done
+  done | tee $O/r06_reverse.jsonl
+  ;;
+esac
+    done
+  done | tee $O/r06_big_knobs.jsonl
+  ;;
+h)
+  # does the row stride matter (a power-of-two stride keeps a strip's rows on one set of HBM channels)?  Same pixels per row +- 64
+  for sz in "4096 4096" "4160 4096" "8192 4096" "8256 4096" "8192 8192" "8256 8192" "8320 8192" "16384 2048" "16448 2048" "16384 4096" "16448 4096" "12288 8192" "8192 8192" "8256 8192"; do
+    set -- $sz
+    sized $1 $2 50 stride_probe
+  done | tee $O/r06_stride_probe.jsonl
+  ;;
+i)
+  # the gradient phase bottom-up, the projection top-down: each phase starts on what the Infinity Cache still holds
+  ( timeout 600 python -m pytest tests/test_parity_gpu.py -q -x --timeout 600 -k "half_and_quarter or schedule_switch" ) > $O/r06_i_tests.log 2>&1; echo "tests rc=$?"; tail -3 $O/r06_i_tests.log
+  for sz in "4096 4096" "8192 4096" "16384 2048" "8192 8192" "16384 4096" "16384 8192"; do
+    set -- $sz
+    for v in 0 1 0 1; do
+      J2P_GRAD_REVERSE=$v sized $1 $2 50 reverse$v jpeg2png_amd/libjpeg2png_amd_exp.so
+    done
+  done | tee $O/r06_reverse.jsonl
+  ;;
 esac
