@@ -593,7 +593,7 @@ class Batch:
             # (the C side writes height * width * 3 samples of bits / 8 bytes: anything else is a heap overflow or a
             # half-written array, so it is an error here, not an assert that -O strips)
             if bits not in (8, 16):
-                raise J2PError("bits must be 8 or 16")
+                raise J2PError("job: out_bits must be 0, 8 or 16")
             if out is None:
                 out = np.empty((height, width, 3), dtype=np.uint8 if bits == 8 else ">u2")
             if not (isinstance(out, np.ndarray) and out.shape == (height, width, 3) and out.flags["C_CONTIGUOUS"]

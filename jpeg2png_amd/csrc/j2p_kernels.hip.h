@@ -24,15 +24,8 @@
 //
 // No MFMA anywhere: there is no dense contraction on this path.
 //
-// Timing-only experiment builds (tools/build_variant.py NAME -DJ2P_EXP_...; results are WRONG, never shipped):
-//   J2P_EXP_NOARITH   k_gradient's square roots and quotients replaced by one multiply each: what the loads, the
-//                     FISTA point, the differences, the gather sums and the stores cost on their own
-//   J2P_EXP_NOTRAFFIC every row address of both phase kernels folded into 64 rows of each plane: operands
-//                     cache-resident, the instruction stream unchanged — the compute side on its own
-//   J2P_EXP_NOHALO    k_gradient re-reads its own first / last rows instead of the 2 + 2 halo rows of a strip:
-//                     what the 1.15x over-fetch costs
-//   J2P_EXP_SHORTDIV  k_gradient WITHOUT the all-ones-mantissa test its short division needs (wrong once in ~1e6
-//                     pixels): what that test costs
+// (The timing-only decomposition builds of rounds 3-5 — arithmetic / traffic / halo rows / mantissa test switched off one at
+// a time — are gone from this file; their measurements are profiles/r03_decomposition.jsonl and r05_decomposition.jsonl.)
 // -DJ2P_TRACE -DJ2P_TRACE_CLOCK: the trace record's middle stamp becomes the wavefront's life in CORE-clock ticks (s_memtime)
 // next to its life on the constant 100 MHz clock: the shader clock the kernels actually run at (tools/core_clock.py)
 // (and one that stays correct: J2P_PROJECT_MAXWAVES=N caps k_project's wavefronts per SIMD through its LDS footprint)
@@ -250,10 +243,10 @@ struct Geo {
         // edge ones: 0, nseg - 1).  Plain arithmetic on kernel arguments: a table in memory would put two dependent
         // loads in front of every wavefront's first row fetch
         unsigned seg_off, seg_mul;
-        // how a gradient launch's workgroups map to strips and rows (grad_item): units (workgroups' worth of whole tile
-        // rows) and tile rows of the launch, and the shares (in 1/256) of every XCD's run that are dealt as half and as
+        // how a gradient launch's workgroups map to strips and rows (grad_item): units (four strips x a pair of tile rows)
+        // and tile rows of the launch, and the shares (in 1/256) of every XCD's run that are dealt as double, as half and as
         // quarter tile rows
-        unsigned units, ntr_launch, zone_b, zone_c;
+        unsigned units, ntr_launch, zone_d, zone_b, zone_c;
         // 1: the launch walks the canvas bottom-up (unit n - 1 - u instead of u).  k_project walks top-down, so each
         // phase then STARTS on the rows the phase before touched last — what the Infinity Cache still holds of planes
         // that do not fit it (j2p_solver_create: canvases whose two planes exceed the cache)
@@ -689,12 +682,6 @@ __device__ __forceinline__ V divisor_of(V n)
 template <bool FAST, bool EXACT_ZERO, class V>
 __device__ __forceinline__ void norm_and_reciprocal(V x, V &n, V &d, V &r)
 {
-#ifdef J2P_EXP_NOARITH
-        n = x * 0.75f + splat<V>(1.f);
-        d = n;
-        r = n;
-        return;
-#endif
         if constexpr(FAST && !EXACT_ZERO) {
                 V seed;
                 n = sqrt_rsq(x + splat<V>(0x1p-120f), seed);
@@ -710,11 +697,6 @@ __device__ __forceinline__ void norm_and_reciprocal(V x, V &n, V &d, V &r)
 template <bool FAST, bool EXACT_ZERO, int N, class V>
 __device__ __forceinline__ void div_n(const V (&x)[N], V d, V r, V (&q)[N])
 {
-#ifdef J2P_EXP_NOARITH
-#pragma unroll
-        for(int i = 0; i < N; i++) { q[i] = x[i] * d; }
-        return;
-#endif
         if constexpr(FAST && !EXACT_ZERO) {
 #pragma unroll
                 for(int i = 0; i < N; i++) { q[i] = div_exact_recip(x[i], d, r); }
@@ -927,7 +909,7 @@ template <int NCH, bool TGV, bool LOG, bool FAST, class V>
 __device__ __forceinline__ void source_finish(const V (&gx)[NCH], const V (&gy)[NCH], const SourcePrep<NCH, TGV, V> &p, float a_tv,
                                               float a_tgv, bool log_row, double &tv, double &tv2, SourceTerms<NCH, TGV, V> &s)
 {
-#if J2P_LEVELS && !defined(J2P_EXP_NOARITH)
+#if J2P_LEVELS
         if constexpr(FAST && !LOG && NCH == 1) {
                 (void)log_row; (void)tv; (void)tv2;
                 source_finish_levels<NCH, TGV, V>(gx, gy, p, a_tv, a_tgv, s);
@@ -1189,8 +1171,11 @@ constexpr int kGradWaves3 = 2;    // ... the three-channels-in-one-wavefront sch
 // PX: columns per lane (2: packed arithmetic, 128-column strips; 1: 64-column strips, see the pixel-vector overloads above)
 // What one wavefront of a gradient launch works on (wave-uniform; grad_item): strip `wcol`, band-local target rows
 // [t0, t0 + nrows) of tile row `tr` — the whole tile row (kind 0), one of its halves (kind 1) or quarters (kind 2; `sub`
-// says which).  Half and quarter items exist so that the LAST workgroups of a launch are short: a launch is as long as its
-// last wavefront, and a whole tile row is a wavefront life of ~17 us at 4096^2 (profiles/r06_wave_trace.jsonl).
+// says which), or tile rows tr AND tr + 1 (kind 3).  Half and quarter items exist so that the LAST workgroups of a launch
+// are short: a launch is as long as its last wavefront, and a whole tile row is a wavefront life of ~17 us at 4096^2
+// (profiles/r06_wave_trace.jsonl).  Double items are for the workgroups dispatched FIRST: 34 row trips for 32 rows
+// instead of 2 x 18 — the two source rows above a strip are recomputed half as often, and read half as often.
+constexpr int kKindWhole = 0, kKindHalf = 1, kKindQuarter = 2, kKindDouble = 3;
 struct StripItem {
         int wcol, t0, nrows, tile0;
         unsigned tr;
@@ -1202,11 +1187,14 @@ struct StripItem {
 // The march of one wavefront over its item's rows: FISTA point, gradient, g stored; the sums of g^2 come back per lane in
 // the tile row's canonical order — lo = a0 + a1, hi = a2 + a3 with a_i the running sum over the tile row's i-th group of
 // FOUR rows (an item that covers only part of the tile row leaves the others 0) — so that the partial of a tile row,
-// (a0 + a1) + (a2 + a3) summed over the lanes, has the same bits whether one, two or four wavefronts marched it.
+// (a0 + a1) + (a2 + a3) summed over the lanes, has the same bits whether one, two or four wavefronts marched it — or one
+// wavefront marched it together with the tile row below (second index of the sums: which of the item's tile rows).
 // xchg = the workgroup's LDS (joint images).
+template <int NCH, int J>
+constexpr int kItemTiles = NCH == 1 && J == 1 ? 2 : 1;       // tile rows an item can cover (double items: one channel per wavefront)
 template <int NCH, bool TGV, bool LOG, int J, int NT, int PX, class V>
-__device__ __forceinline__ void march_rows(const GradArgs &a, V *xchg, const StripItem &it, double (&g2_lo)[NCH], double (&g2_hi)[NCH],
-                                           double &tv_acc, double &tv2_acc, unsigned long long &tr_data)
+__device__ __forceinline__ void march_rows(const GradArgs &a, V *xchg, const StripItem &it, double (&g2_lo)[NCH][kItemTiles<NCH, J>],
+                                           double (&g2_hi)[NCH][kItemTiles<NCH, J>], double &tv_acc, double &tv2_acc, unsigned long long &tr_data)
 {
         constexpr int kCols = 64 * PX - 4;                      // output columns per strip: 2 halo columns on each side
         const int lane = (int)threadIdx.x & 63;
@@ -1218,6 +1206,8 @@ __device__ __forceinline__ void march_rows(const GradArgs &a, V *xchg, const Str
         const int t0 = it.t0;                                   // band-local target rows [t0, t1)
         const int t1 = t0 + it.nrows < rows ? t0 + it.nrows : rows;
         const int tile0 = it.tile0;
+        // (the three scalars by value: read through `a` inside the lambdas they ended up in an LDS-promoted alloca)
+        const float fista_factor = a.factor, w_tv = a.a_tv, w_tgv = a.a_tgv;
         // Strip i loads columns [kCols i, kCols i + 64 PX); its two outermost columns on each side are halo — except
         // at the image's left and right edges, where the neighbour beyond the edge contributes nothing anyway, so the
         // first strip also owns its left halo lanes and the last strip its right ones: n strips cover kCols n + 4
@@ -1246,11 +1236,7 @@ __device__ __forceinline__ void march_rows(const GradArgs &a, V *xchg, const Str
         const int xl_c = xl < 0 ? 0 : (xl > W - PX ? W - PX : xl);
         const unsigned xoff = (unsigned)xl_c * 4u;             // byte offset of the lane's pixel vector within a row
         // (rows t0 - 2 ... t1 + 1 are what the segment touches; the x buffers have 2 halo rows above the band's row 0)
-#ifdef J2P_EXP_NOTRAFFIC
-        const int seg_base = 0, grad_base = 0;      // (every segment works on the plane's first 64 rows)
-#else
         const int seg_base = t0 - 2, grad_base = t0;
-#endif
         __amdgpu_buffer_rsrc_t res_cur[NCH], res_prev[NCH], res_grad[NCH], res_pg[NCH];
 #pragma unroll
         for(int c = 0; c < NCH; c++) {
@@ -1269,13 +1255,7 @@ __device__ __forceinline__ void march_rows(const GradArgs &a, V *xchg, const Str
                 constexpr bool FREE = decltype(free_tag)::value;
                 // rows past the strip's last needed row (t1+1) re-read that row: a cache hit, not HBM traffic
                 int lm = lr > t1 + 1 ? t1 + 1 : lr;
-#ifdef J2P_EXP_NOHALO
-                lm = lm < t0 ? t0 : (lm > t1 - 1 ? t1 - 1 : lm);
-#endif
                 int lc = FREE ? lm : (lm < lr_lo ? lr_lo : (lm > lr_hi ? lr_hi : lm));
-#ifdef J2P_EXP_NOTRAFFIC
-                lc = (lc < 0 ? 0 : lc) & 63;
-#endif
                 // wave-uniform resource at the segment's first row + loop-invariant 32-bit lane offset + scalar row offset:
                 // no vector arithmetic in the address (see rows_from)
                 const ptrdiff_t roff = (ptrdiff_t)lc * W;              // (the pointer form: what J2P_DEBUG checks)
@@ -1300,7 +1280,7 @@ __device__ __forceinline__ void march_rows(const GradArgs &a, V *xchg, const Str
                 unsigned hi = 0u, lo = ~0u;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
-                        const V yy = rc[c] + a.factor * (rc[c] - rp[c]);     // compute.c:435
+                        const V yy = rc[c] + fista_factor * (rc[c] - rp[c]);     // compute.c:435
                         y[c] = FREE ? yy : yy * m;
                         screen_update(hi, lo, y[c]);
                 }
@@ -1344,11 +1324,7 @@ __device__ __forceinline__ void march_rows(const GradArgs &a, V *xchg, const Str
                         const ChanDev &k = a.ch[cbase + c];
                         // coefficient row of canvas row lt, clamped into the rows this band holds
                         const int ltc = lt > t1 - 1 ? t1 - 1 : lt;                     // past the strip: re-read its last row
-#ifdef J2P_EXP_NOTRAFFIC
-                        const int gt = row0 + ((ltc < 0 ? 0 : ltc) & 63);
-#else
                         const int gt = row0 + (FREE ? ltc : (ltc < 0 ? 0 : ltc));
-#endif
                         if constexpr(decltype(free_tag)::unit) {
                                 const float *prow = k.pg + (size_t)((unsigned)gt - k.crow0) * k.cw;
                                 J2P_CHK(k, pg, reinterpret_cast<const char *>(prow) + xoff, 4 * PX, 103);
@@ -1379,12 +1355,26 @@ __device__ __forceinline__ void march_rows(const GradArgs &a, V *xchg, const Str
 #pragma unroll
         for(int c = 0; c < NCH; c++) { g2[c] = 0.; }
         // a group of four rows is complete (target row t was its last): into the tile row's lower or upper pair sum
+        const int tile_rows = (int)a.geo.rpw;
         auto close_group = [&](int t) {
-                const bool upper = ((t - tile0) & 8) != 0;       // (wave-uniform)
+                int rel = t - tile0;                             // (everything here is wave-uniform)
+                const bool second = kItemTiles<NCH, J> == 2 && rel >= tile_rows;
+                if(second) { rel -= tile_rows; }
+                const bool upper = (rel & 8) != 0;
 #pragma unroll
                 for(int c = 0; c < NCH; c++) {
-                        if(upper) { g2_hi[c] += g2[c]; }
-                        else { g2_lo[c] += g2[c]; }
+                        if constexpr(kItemTiles<NCH, J> == 2) {
+                                if(second) {
+                                        if(upper) { g2_hi[c][1] += g2[c]; }
+                                        else { g2_lo[c][1] += g2[c]; }
+                                } else {
+                                        if(upper) { g2_hi[c][0] += g2[c]; }
+                                        else { g2_lo[c][0] += g2[c]; }
+                                }
+                        } else {
+                                if(upper) { g2_hi[c][0] += g2[c]; }
+                                else { g2_lo[c][0] += g2[c]; }
+                        }
                         g2[c] = 0.;
                 }
         };
@@ -1454,11 +1444,9 @@ __device__ __forceinline__ void march_rows(const GradArgs &a, V *xchg, const Str
                                         source_prepare<NCH, TGV, !FREE>(GX[P], GY[P], GX[PM1], GY[PM1], m_hx, m_hy, prep);
                                 }
                                 bool slow = badmask != 0;
-#ifndef J2P_EXP_SHORTDIV
                                 if constexpr(!LOG) { slow = slow || __builtin_amdgcn_ballot_w64(allones_candidate(prep.n1r, prep.n2r)) != 0; }
-#endif
-                                if(!slow) { source_finish<NCH, TGV, LOG, true>(GX[P], GY[P], prep, a.a_tv, a.a_tgv, log_row, tv_acc, tv2_acc, s); }
-                                else { source_finish<NCH, TGV, LOG, false>(GX[P], GY[P], prep, a.a_tv, a.a_tgv, log_row, tv_acc, tv2_acc, s); }
+                                if(!slow) { source_finish<NCH, TGV, LOG, true>(GX[P], GY[P], prep, w_tv, w_tgv, log_row, tv_acc, tv2_acc, s); }
+                                else { source_finish<NCH, TGV, LOG, false>(GX[P], GY[P], prep, w_tv, w_tgv, log_row, tv_acc, tv2_acc, s); }
                         }
                         // ---- target row t = r-1: rows t-1, t, t+1 live in slots PM2, PM1, P ----
                         const int t = r - 1;
@@ -1484,11 +1472,7 @@ __device__ __forceinline__ void march_rows(const GradArgs &a, V *xchg, const Str
                                         }
                                         if(pair_own) {
                                                 J2P_CHK(k, grad, reinterpret_cast<char *>(k.grad + (size_t)t * W) + (unsigned)xl * 4u, 4 * PX, 106);
-#ifdef J2P_EXP_NOTRAFFIC
-                                                buf_store<(NT >= 1)>(g, res_grad[c], (unsigned)xl * 4u, (unsigned)(t & 63) * (unsigned)W * 4u);
-#else
                                                 buf_store<(NT >= 1)>(g, res_grad[c], (unsigned)xl * 4u, (unsigned)(t - grad_base) * (unsigned)W * 4u);
-#endif
                                                 add_elements(g2[c], g * g);      // compute.c:203
                                         }
                                 }
@@ -1568,9 +1552,13 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
 #endif
 #endif
         unsigned long long tr_data = 0;
-        double lo[NCH], hi[NCH], tv_acc = 0., tv2_acc = 0.;
+        constexpr int kTiles = kItemTiles<NCH, J>;
+        double lo[NCH][kTiles], hi[NCH][kTiles], tv_acc = 0., tv2_acc = 0.;
 #pragma unroll
-        for(int c = 0; c < NCH; c++) { lo[c] = hi[c] = 0.; }
+        for(int c = 0; c < NCH; c++) {
+#pragma unroll
+                for(int k = 0; k < kTiles; k++) { lo[c][k] = hi[c][k] = 0.; }
+        }
         if(it.active) { march_rows<NCH, TGV, LOG, J, NT, PX, V>(a, xchg, it, lo, hi, tv_acc, tv2_acc, tr_data); }
         if(LOG) {
 #pragma unroll
@@ -1581,22 +1569,22 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
         }
         bool publisher = it.active;
         if constexpr(NCH == 1 && J == 1) {
-                if(it.kind != 0) {
+                if(it.kind == kKindHalf || it.kind == kKindQuarter) {
                         // half items: wavefronts (0, 1) and (2, 3) of the workgroup share a strip; quarter items: all four do
-                        const int first = it.kind == 1 ? (wave & ~1) : 0;
+                        const int first = it.kind == kKindHalf ? (wave & ~1) : 0;
                         if(wave != first) {
-                                fold_buf[wave * 64 + lane] = lo[0] + hi[0];              // (one of the two is 0)
+                                fold_buf[wave * 64 + lane] = lo[0][0] + hi[0][0];        // (one of the two is 0)
                                 if(LOG && lane == 0) { fold_buf[256 + 2 * wave] = tv_acc; fold_buf[257 + 2 * wave] = tv2_acc; }
                         }
                         __syncthreads();
                         publisher = wave == first && it.active;
                         if(publisher) {
-                                if(it.kind == 1) {
-                                        hi[0] = fold_buf[(wave + 1) * 64 + lane];
+                                if(it.kind == kKindHalf) {
+                                        hi[0][0] = fold_buf[(wave + 1) * 64 + lane];
                                         if(LOG) { tv_acc += fold_buf[256 + 2 * (wave + 1)]; tv2_acc += fold_buf[257 + 2 * (wave + 1)]; }
                                 } else {
-                                        lo[0] = lo[0] + fold_buf[64 + lane];
-                                        hi[0] = fold_buf[128 + lane] + fold_buf[192 + lane];
+                                        lo[0][0] = lo[0][0] + fold_buf[64 + lane];
+                                        hi[0][0] = fold_buf[128 + lane] + fold_buf[192 + lane];
                                         if(LOG) {
 #pragma unroll
                                                 for(int w = 1; w < 4; w++) { tv_acc += fold_buf[256 + 2 * w]; tv2_acc += fold_buf[257 + 2 * w]; }
@@ -1608,26 +1596,31 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
         if(publisher) {
                 const size_t ntiles_row = a.geo.ntx;
                 const size_t nparts = (size_t)((a.geo.rows + a.geo.rpw - 1) / a.geo.rpw) * ntiles_row;
-                const unsigned tr = it.tr;
+                // (a double item: its second tile row too, if the band has it)
+                const int ntile = kTiles == 2 && it.kind == kKindDouble && it.tile0 + (int)a.geo.rpw < (int)a.geo.rows ? 2 : 1;
+                for(int k = 0; k < ntile; k++) {
+                        const unsigned tr = it.tr + (unsigned)k;
 #pragma unroll
-                for(int c = 0; c < NCH; c++) {
-                        double v = lo[c] + hi[c];
+                        for(int c = 0; c < NCH; c++) {
+                                double v = kTiles == 2 && k == 1 ? lo[c][kTiles - 1] + hi[c][kTiles - 1] : lo[c][0] + hi[c][0];
 #pragma unroll
-                        for(int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); }
-                        // (a folding launch marks its partials with the iteration's parity, see fold_tile_row: the sign bit is SET
-                        // to it, whatever it was — a sum of squares is >= +0, and a NaN must not make the reader wait for ever)
-                        if(a.row_ticket) {
-                                const unsigned long long bits = (__builtin_bit_cast(unsigned long long, v) & ~(1ull << 63)) | ((unsigned long long)a.fold_phase << 63);
-                                v = __builtin_bit_cast(double, bits);
+                                for(int off = 32; off > 0; off >>= 1) { v += __shfl_down(v, off, 64); }
+                                // (a folding launch marks its partials with the iteration's parity, see fold_tile_row: the sign bit is
+                                // SET to it, whatever it was — a sum of squares is >= +0, and a NaN must not make the reader wait for ever)
+                                if(a.row_ticket) {
+                                        const unsigned long long bits = (__builtin_bit_cast(unsigned long long, v) & ~(1ull << 63)) | ((unsigned long long)a.fold_phase << 63);
+                                        v = __builtin_bit_cast(double, bits);
+                                }
+                                if(lane == 0) { publish_double(&a.part_g2[(cbase + c) * nparts + (size_t)tr * ntiles_row + it.wcol], v); }
                         }
-                        if(lane == 0) { publish_double(&a.part_g2[(cbase + c) * nparts + (size_t)tr * ntiles_row + it.wcol], v); }
+                        if(LOG && lane == 0 && cbase == 0) {
+                                // (the CSV sums of a double item sit with its first tile row; the second one's slot holds 0)
+                                const size_t w = (size_t)tr * ntiles_row + it.wcol;
+                                a.part_tv[2 * w] = k == 0 ? tv_acc : 0.;
+                                a.part_tv[2 * w + 1] = k == 0 ? tv2_acc : 0.;
+                        }
+                        if(a.row_ticket) { fold_arrive(a, tr, (unsigned)NCH, nparts, fold_buf, lane); }
                 }
-                if(LOG && lane == 0 && cbase == 0) {
-                        const size_t w = (size_t)tr * ntiles_row + it.wcol;
-                        a.part_tv[2 * w] = tv_acc;
-                        a.part_tv[2 * w + 1] = tv2_acc;
-                }
-                if(a.row_ticket) { fold_arrive(a, tr, (unsigned)NCH, nparts, fold_buf, lane); }
         }
 #ifdef J2P_TRACE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the wavefront's stores have been acknowledged
@@ -1642,34 +1635,31 @@ __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, doubl
 // "workgroup b runs on XCD b % 8" turns into when every XCD is to work on one contiguous region of the canvas
 __host__ __device__ __forceinline__ unsigned chunk_base(unsigned n, unsigned q) { return q * (n >> 3) + (q < (n & 7) ? q : (n & 7)); }
 
-// The order in which a gradient launch hands out its work.  The launch's (tile row, strip) pairs are numbered row-major;
-// a UNIT is four consecutive ones (J == 1: a workgroup's four wavefronts never idle because a row of strips is no multiple
-// of four — 33 strips at W = 4096 — and every workgroup gives each SIMD of its CU one wavefront) or — joint images, a
-// wavefront per channel — one.  Workgroup b runs on XCD b % 8 and the workgroups
-// of an XCD start in the order of their numbers, so every XCD gets a contiguous, row-major run of units — vertically
-// adjacent strips then meet in one L2 and their shared halo rows are fetched from HBM once — and deals the run in three
-// zones: the first units whole (one workgroup = 4 strips x the tile row's 16 rows), then a share zone_b / 256 as HALVES
-// (two workgroups per unit: 2 strips x 2 halves of 8 rows), the last zone_c / 256 as QUARTERS (four workgroups per unit:
-// 1 strip x 4 quarters of 4 rows).  The launch ends when its last wavefront does, and the wavefronts dispatched last are
-// then the short ones.  Zones change who marches which rows, never a bit of the result (march_rows).
-struct ZoneSplit {
-        unsigned whole, halves, quarters;       // units of the run
-        __host__ __device__ unsigned workgroups() const { return whole + 2 * halves + 4 * quarters; }
+// The order in which a gradient launch hands out its work.  Tile rows are taken in PAIRS (2 r, 2 r + 1) and the launch's
+// (pair row, strip) positions are numbered row-major; a UNIT is four consecutive ones (J == 1: a workgroup's four
+// wavefronts never idle because a row of strips is no multiple of four — 33 strips at W = 4096 — and every workgroup
+// gives each SIMD of its CU one wavefront) or — joint images, a wavefront per channel — one.  Workgroup b runs on XCD
+// b % 8 and the workgroups of an XCD start in the order of their numbers, so every XCD gets a contiguous, row-major run
+// of units — vertically adjacent strips then meet in one L2 and their shared halo rows are fetched from HBM once — and
+// deals the run in four zones, long items first: a share zone_d / 256 of the units as DOUBLES (one workgroup per unit: 4
+// strips x both tile rows, 34 row trips for 32 rows), then whole tile rows (two workgroups per unit: 4 strips x 16 rows),
+// then zone_b / 256 as HALVES (four workgroups: 2 strips x 2 halves of 8 rows), the last zone_c / 256 as QUARTERS (eight
+// workgroups: 1 strip x 4 quarters of 4 rows).  The launch ends when its last wavefront does, and the wavefronts
+// dispatched last are then the short ones.  Zones change who marches which rows, never a bit of the result (march_rows).
+struct ZoneShares {
+        unsigned d, b, c;       // doubles, halves, quarters in 1/256 of a run; the rest whole
 };
-__host__ __device__ __forceinline__ ZoneSplit zone_split(unsigned units, unsigned zone_b, unsigned zone_c)
+__host__ __device__ __forceinline__ unsigned zone_workgroups(unsigned run, ZoneShares z)
 {
-        ZoneSplit z;
-        z.quarters = (units * zone_c) >> 8;
-        z.halves = (units * zone_b) >> 8;
-        z.whole = units - z.halves - z.quarters;
-        return z;
+        const unsigned quarters = (run * z.c) >> 8, halves = (run * z.b) >> 8, doubles = (run * z.d) >> 8;
+        return doubles + 2 * (run - doubles - halves - quarters) + 4 * halves + 8 * quarters;
 }
 // workgroups a gradient launch needs: 8 x the longest run's
-__host__ __device__ __forceinline__ unsigned grad_grid(unsigned n /* units */, unsigned zone_b, unsigned zone_c)
+__host__ __device__ __forceinline__ unsigned grad_grid(unsigned n /* units */, ZoneShares z)
 {
         unsigned most = 0;
         for(unsigned q = 0; q < 8; q++) {
-                const unsigned w = zone_split(chunk_base(n, q + 1) - chunk_base(n, q), zone_b, zone_c).workgroups();
+                const unsigned w = zone_workgroups(chunk_base(n, q + 1) - chunk_base(n, q), z);
                 most = w > most ? w : most;
         }
         return 8 * most;
@@ -1682,36 +1672,46 @@ __device__ __forceinline__ bool grad_item(const Geo &g, unsigned b, int wave, St
         const unsigned q = b & 7, j = b >> 3;
         const unsigned n = g.units;
         const unsigned first = chunk_base(n, q);
-        const ZoneSplit z = zone_split(chunk_base(n, q + 1) - first, g.zone_b, g.zone_c);
-        unsigned u, strip_in_group;
-        int kind = 0, sub = 0;
-        if(j < z.whole) {
+        // (plain scalars, no struct for the split: as an object it ended up in LDS, 12 bytes per thread, via the alloca promotion)
+        const unsigned run = chunk_base(n, q + 1) - first;
+        const unsigned quarters = (run * g.zone_c) >> 8, halves = (run * g.zone_b) >> 8, doubles = (run * g.zone_d) >> 8;
+        const unsigned whole = run - doubles - halves - quarters;
+        unsigned u = 0, strip_in_group = (unsigned)wave, tile_in_pair = 0;
+        int kind = kKindWhole, sub = 0;
+        if(j < doubles) {
                 u = first + j;
-                strip_in_group = (unsigned)wave;
-        } else if(j < z.whole + 2 * z.halves) {
-                const unsigned jj = j - z.whole;
-                u = first + z.whole + (jj >> 1);
-                kind = 1;
+                kind = kKindDouble;
+        } else if(j < doubles + 2 * whole) {
+                const unsigned jj = j - doubles;
+                u = first + doubles + (jj >> 1);
+                tile_in_pair = jj & 1;
+        } else if(j < doubles + 2 * whole + 4 * halves) {
+                const unsigned jj = j - doubles - 2 * whole;
+                u = first + doubles + whole + (jj >> 2);
+                kind = kKindHalf;
+                tile_in_pair = (jj >> 1) & 1;
                 strip_in_group = 2 * (jj & 1) + ((unsigned)wave >> 1);
                 sub = wave & 1;
-        } else if(j < z.workgroups()) {
-                const unsigned jj = j - z.whole - 2 * z.halves;
-                u = first + z.whole + z.halves + (jj >> 2);
-                kind = 2;
+        } else if(j < doubles + 2 * whole + 4 * halves + 8 * quarters) {
+                const unsigned jj = j - doubles - 2 * whole - 4 * halves;
+                u = first + doubles + whole + halves + (jj >> 3);
+                kind = kKindQuarter;
+                tile_in_pair = (jj >> 2) & 1;
                 strip_in_group = jj & 3;
                 sub = wave;
         } else {
                 return false;
         }
         if(g.reverse) { u = n - 1 - u; }
-        const unsigned id = J == 1 ? 4 * u + strip_in_group : u;        // (tile row, strip) of the launch, row-major
-        const unsigned tr_launch = id / g.ntx;
+        const unsigned id = J == 1 ? 4 * u + strip_in_group : u;        // (pair row, strip) of the launch, row-major
+        const unsigned pair_row = id / g.ntx;
+        const unsigned tr_launch = 2 * pair_row + tile_in_pair;
         it.tr = g.seg_off + tr_launch * g.seg_mul;
-        it.wcol = (int)(id - tr_launch * g.ntx);
+        it.wcol = (int)(id - pair_row * g.ntx);
         it.kind = kind;
         it.sub = sub;
         it.tile0 = (int)(it.tr * g.rpw);
-        it.nrows = (int)(g.rpw >> kind);
+        it.nrows = kind == kKindDouble ? (int)(2 * g.rpw) : kind == kKindHalf ? (int)(g.rpw >> 1) : kind == kKindQuarter ? (int)(g.rpw >> 2) : (int)g.rpw;
         it.t0 = it.tile0 + sub * it.nrows;
         it.active = tr_launch < g.ntr_launch && it.t0 < (int)g.rows;
         return true;
@@ -2241,11 +2241,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
         const unsigned cx = sx * 64 + lane;                           // coefficient column of this lane
         const unsigned cy0 = (a.geo.row0 / hs) + by * 8;              // first coefficient row (global)
         const bool covered = cx < k.cw && cy0 < k.ch;                 // block-granular: cw, ch multiples of 8
-#ifdef J2P_EXP_NOTRAFFIC
-        const unsigned ly0 = ((by * 8 * hs) & 63);                   // (timing experiment: every strip works on the same 64 rows)
-#else
         const unsigned ly0 = by * 8 * hs;                             // band-local canvas row
-#endif
         // A full-resolution channel whose coefficient plane is smaller than the canvas (the chroma planes pad
         // further than the luma plane: most 4:2:0 images) still goes through the reference's resampling code
         // with a 1 x 1 footprint (compute.c:348-370, 390-403): the DCT sees 0.f + x and the result is
@@ -2433,11 +2429,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
         {
                 int4 raw = make_int4(0, 0, 0, 0);
                 if(bcov) {
-#ifdef J2P_EXP_NOTRAFFIC
-                        const size_t blk = (size_t)((cy0 / 8 - k.crow0 / 8) & 7) * (k.cw / 8) + bx;
-#else
                         const size_t blk = (size_t)(cy0 / 8 - k.crow0 / 8) * (k.cw / 8) + bx;
-#endif
                         J2P_CHK(k, d, k.d + blk * 64 + rr * 8, 16, 211);
                         if constexpr(NT >= 3) {
                                 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -2570,11 +2562,7 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
                 transpose8(e, scratch, lane);
                 idct8(e);
                 if(bcov) {
-#ifdef J2P_EXP_NOTRAFFIC
-                        float4 *dst = reinterpret_cast<float4 *>(k.pg + (size_t)(((cy0 - k.crow0) & 63) + rr) * k.cw + bx * 8);
-#else
                         float4 *dst = reinterpret_cast<float4 *>(k.pg + (size_t)(cy0 - k.crow0 + rr) * k.cw + bx * 8);
-#endif
                         J2P_CHK(k, pg, dst, 32, 214);
                         if constexpr(NT >= 2) {
                                 typedef float v4f __attribute__((ext_vector_type(4)));

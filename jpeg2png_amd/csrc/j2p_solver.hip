@@ -96,7 +96,7 @@ struct j2p_solver {
         size_t arena_bytes = 0;
         // reductions
         bool fold = false;       // norm reduction folded into k_gradient (J2P_OPT_NORM_FOLD); default: band solvers only
-        unsigned zone_b = 0, zone_c = 0;   // shares (1/256) of a gradient launch dealt as half / quarter tile rows (grad_item)
+        unsigned zone_d = 0, zone_b = 0, zone_c = 0;   // shares (1/256) of a gradient launch dealt as double / half / quarter tile rows (grad_item)
         bool grad_reverse = false;         // the gradient launch walks the canvas bottom-up (Geo::reverse)
         bool joint_inwave = false;   // J2P_OPT_JOINT_INWAVE
         bool norm_in_project = false;   // J2P_OPT_NORM_IN_PROJECT (with fold): level 2 of the norm inside k_project
@@ -322,6 +322,7 @@ constexpr unsigned long long kShortStripWaves = 2048;
 // the shares (1/256) of every XCD's run dealt that way
 constexpr unsigned long long kZoneMaxWaves = 3 * 4096;
 constexpr unsigned kZoneB = 32, kZoneC = 10;
+constexpr unsigned kBigZoneD = 200, kBigZoneB = 24, kBigZoneC = 8;
 
 unsigned gcd_u(unsigned a, unsigned b) { return b ? gcd_u(b, a % b) : a; }
 unsigned lcm_u(unsigned a, unsigned b) { return a / gcd_u(a, b) * b; }
@@ -404,7 +405,7 @@ Geo geo_of(const j2p_solver *s)
         g.seg_mul = 1;
         g.units = 0;            // (do_phase_gradient fills in the launch's own)
         g.ntr_launch = 0;
-        g.zone_b = g.zone_c = 0;
+        g.zone_d = g.zone_b = g.zone_c = 0;
         g.reverse = 0;
 #ifdef J2P_TRACE
         g.trace = s->trace_on ? s->trace : nullptr;
@@ -422,19 +423,20 @@ double *rowsums_of(const j2p_solver *s, unsigned iter)
         return (s->rowsum_alternate && (iter & 1)) ? s->rowsum_odd : s->rowsum_local;
 }
 
-// units of a gradient launch over `ntr` tile rows (grad_item): 4 strips per 256-thread workgroup, or — joint images, one
-// wavefront per channel — one strip per workgroup
+// units of a gradient launch over `ntr` tile rows (grad_item): pairs of tile rows x 4 strips (256-thread workgroups), or —
+// joint images, one wavefront per channel — x one strip
 unsigned grad_units(const j2p_solver *s, unsigned ntr)
 {
-        const unsigned strips = s->ntx * ntr;
-        return s->nch == 1 || s->joint_inwave ? (strips + 3) / 4 : strips;
+        const unsigned positions = s->ntx * ((ntr + 1) / 2);
+        return s->nch == 1 || s->joint_inwave ? (positions + 3) / 4 : positions;
 }
+ZoneShares zone_shares(const Geo &g) { return ZoneShares{g.zone_d, g.zone_b, g.zone_c}; }
 
 template <int NCH, int J, int PX = 2>
 void launch_gradient_n(const GradArgs &a, hipStream_t st, bool tgv, bool log, int nt)
 {
         // J == 1: 4 strips per 256-thread workgroup; J > 1: one strip per workgroup of J wavefronts
-        const dim3 grid(grad_grid(a.geo.units, a.geo.zone_b, a.geo.zone_c));
+        const dim3 grid(grad_grid(a.geo.units, zone_shares(a.geo)));
         const dim3 block = J == 1 ? dim3(256) : dim3(64 * J);
         if constexpr(NCH == 1 && PX == 2) {
                 // non-temporal g / prob state (see nt_policy): the one-channel-per-wavefront kernels without logging
@@ -549,7 +551,7 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
         a.geo.units = grad_units(s, nseg_launch);
         a.geo.ntr_launch = nseg_launch;
         // (half / quarter items: whole phases of one channel per workgroup wavefront, see the policy in j2p_solver_create)
-        if(part == 0 && s->nch == 1) { a.geo.zone_b = s->zone_b; a.geo.zone_c = s->zone_c; }
+        if(part == 0 && s->nch == 1 && !s->joint_inwave) { a.geo.zone_d = s->zone_d; a.geo.zone_b = s->zone_b; a.geo.zone_c = s->zone_c; }
         a.geo.reverse = part == 0 && s->grad_reverse ? 1u : 0u;
         a.factor = s->factor;
         a.a_tv = (float)(1. / (double)sqrtf((float)s->nch));                    // compute.c:90
@@ -611,7 +613,7 @@ int do_phase_gradient(j2p_solver *s, bool log, int part = 0, hipStream_t st = nu
 #ifdef J2P_TRACE
         if(s->trace_on) {       // one record per wavefront of the launch (J == 1: 4 strips per workgroup; joint: one strip)
                 const bool per_channel = s->nch > 1 && !s->joint_inwave;
-                s->trace_used += grad_grid(a.geo.units, a.geo.zone_b, a.geo.zone_c) * (per_channel ? s->nch : 4u);
+                s->trace_used += grad_grid(a.geo.units, zone_shares(a.geo)) * (per_channel ? s->nch : 4u);
         }
 #endif
         if(part == 1) {
@@ -1090,12 +1092,22 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 if(nchannel == 1 && g >= 8 && launch_waves < kZoneMaxWaves) {
                         s->zone_b = kZoneB;
                         s->zone_c = g >= 16 ? kZoneC : 0;
+                } else if(nchannel == 1 && g >= 16) {
+                        // ... and from three generations on the FIRST workgroups march two tile rows at once (34 row trips for
+                        // 32 rows: fewer source rows recomputed and re-read), the tail shares smaller: 16384x2048 229.8 -> 227.0
+                        // us per iteration, 8192^2 476.0 -> 471.1; below that doubles cost more at the end of the launch than they
+                        // save (2048^2 43.2 -> 46.0, 4096x2048 69.3 -> 72.4, 4096^2 +-0: profiles/r06_doubles.jsonl)
+                        s->zone_d = kBigZoneD;
+                        s->zone_b = kBigZoneB;
+                        s->zone_c = kBigZoneC;
                 }
                 // (halves need two groups of four rows per tile row, quarters four: march_rows)
                 if(const char *env = j2p_exp_env("J2P_ZONE_B")) { if(nchannel == 1 && g >= 8) { s->zone_b = (unsigned)atoi(env); } }
                 if(const char *env = j2p_exp_env("J2P_ZONE_C")) { if(nchannel == 1 && g >= 16) { s->zone_c = (unsigned)atoi(env); } }
+                if(const char *env = j2p_exp_env("J2P_ZONE_D")) { if(nchannel == 1 && g >= 8) { s->zone_d = (unsigned)atoi(env); } }
                 if(s->zone_b > 256) { s->zone_b = 256; }
                 if(s->zone_b + s->zone_c > 256) { s->zone_c = 256 - s->zone_b; }
+                if(s->zone_d + s->zone_b + s->zone_c > 256) { s->zone_d = 256 - s->zone_b - s->zone_c; }
         }
         s->nseg = (s->rows + s->rpw - 1) / s->rpw;
         s->ntr_local = s->nseg;

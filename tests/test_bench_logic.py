@@ -72,3 +72,36 @@ def test_bench_digest_recipe_reproduces_from_the_compiled_reference():
     plane.fdata = ob.decode_plane(plane)
     outs, _, _ = ob.ref_compute([plane], e["weight"], [e["pweight"]], e["iterations"])
     assert hashlib.blake2b(np.ascontiguousarray(outs[0]), digest_size=16).hexdigest() == e["digest"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the fields of the bench line that point INTO profiles/: they must name files that exist and say what they are
+# ---------------------------------------------------------------------------------------------------------------
+def test_counter_traffic_comes_from_the_committed_profiles_by_shape():
+    import bench
+    for shape in ((4096, 4096), (8192, 8192), (16384, 4096), (16384, 8192)):
+        traffic, src = bench.pmc_traffic(*shape)
+        px = shape[0] * shape[1]
+        assert src and os.path.exists(os.path.join(ROOT, src.split(" ")[0])), shape
+        # real bytes per iteration sit a little above the 38 algorithmic ones (halo rows), never below, never 1.2 x above
+        assert 38 * px <= traffic <= 1.2 * 38 * px, (shape, traffic / px)
+    assert bench.pmc_traffic(1000, 1000) == (None, None)            # a shape nobody profiled: null, not a guess
+
+
+def test_band_traffic_is_for_the_band_shape_only():
+    import bench
+    traffic, src = bench.band_pmc_traffic(16384, 2048)
+    assert src and src.startswith("profiles/r06_pmc_band.json") and os.path.exists(os.path.join(ROOT, "profiles", "r06_pmc_band.json"))
+    assert 38 * 16384 * 2048 <= traffic <= 1.2 * 38 * 16384 * 2048
+    assert bench.band_pmc_traffic(4096, 512) == (None, None)        # the debug size of the rehearsal: no counters on file
+
+
+def test_roofline_object_says_which_fraction_is_which():
+    import bench
+    per_kernel = bench.per_kernel_roofline(4096 * 4096, 4096 * 4096, 0.056, 0.061)
+    r = bench.roofline_object(143000.0, 1, 500, 0.0585 * 25, 25, 4096 * 4096, per_kernel, 100, 16, 676000000, "profiles/x.json")
+    assert "kernel_frac" not in r                                   # (round 5's name: read as the whole iteration's by some)
+    assert r["kernel"] == "k_gradient" and r["event_kernel_frac"] == per_kernel["k_gradient"]["frac"]
+    assert abs(r["frac"] - 38 * 143000.0e6 / 8e12) < 1e-3 and r["traffic"] == 676000000 and r["traffic_source"] == "profiles/x.json"
+    prof, src = bench.rocprof_kernel_us()
+    assert prof and src and os.path.exists(os.path.join(ROOT, src)) and 30 < prof["k_gradient"] < 80 and 40 < prof["k_project"] < 80

@@ -637,9 +637,9 @@ def test_every_schedule_switch_leaves_the_bits_alone(exp_lib, oracle, shape, mon
 
 @pytest.mark.parametrize("shape", [(700, 328, 0.3), (1000, 96, 0.3), (264, 200, 0.0), (4096, 48, 0.3)])
 def test_half_and_quarter_items_leave_the_bits_alone(exp_lib, oracle, shape, monkeypatch):
-    """the last workgroups of a large gradient launch march half and quarter tile rows (grad_item / march_rows in
-    j2p_kernels.hip.h; the solver's own choice from 6144 strips on): who marches a row must not change a bit — every
-    share of halves and quarters (in 1/256 of an XCD's run), on canvases whose last tile row is short (328 = 20 x 16 + 8),
+    """the first workgroups of a gradient launch march two tile rows at once, the last ones half and quarter tile rows
+    (grad_item / march_rows in j2p_kernels.hip.h; the solver's own choice by launch size): who marches a row must not
+    change a bit — every share of doubles, halves and quarters (in 1/256 of an XCD's run), on canvases whose last tile row is short (328 = 20 x 16 + 8),
     whole and as bands, with the CSV sums, top-down and bottom-up (what canvases past the Infinity Cache get), against
     the reference's bits"""
     import jpeg2png_amd as j
@@ -649,21 +649,23 @@ def test_half_and_quarter_items_leave_the_bits_alone(exp_lib, oracle, shape, mon
     want, want_rows = oracle.oracle_compute(planes, weight, [0.001], its, log=True)
     monkeypatch.setenv("J2P_PX", "2")
     monkeypatch.setenv("J2P_RPW", "16")
-    for zb, zc, rev in ((0, 0, 0), (256, 0, 0), (0, 256, 1), (100, 100, 0), (64, 32, 1), (26, 10, 0), (1, 255, 0), (0, 0, 1)):
+    for zd, zb, zc, rev in ((0, 0, 0, 0), (0, 256, 0, 0), (0, 0, 256, 1), (0, 100, 100, 0), (0, 64, 32, 1), (0, 26, 10, 0), (0, 1, 255, 0), (0, 0, 0, 1),
+                            (256, 0, 0, 0), (256, 0, 0, 1), (128, 64, 32, 0), (100, 0, 100, 1), (160, 32, 10, 0)):
+        monkeypatch.setenv("J2P_ZONE_D", str(zd))                # shares of double / half / quarter tile-row items
         monkeypatch.setenv("J2P_ZONE_B", str(zb))
         monkeypatch.setenv("J2P_ZONE_C", str(zc))
         monkeypatch.setenv("J2P_GRAD_REVERSE", str(rev))         # the launch walks the canvas bottom-up (Geo::reverse)
         got = copy.deepcopy(planes)
         rows = j.compute(got, weight, [0.001], its, log=True)
-        assert bit_equal(got[0].fdata, want[0]), f"zones {zb}/{zc}"
-        assert np.allclose(rows, want_rows, rtol=1e-9, atol=1e-9), f"zones {zb}/{zc}: CSV rows"
+        assert bit_equal(got[0].fdata, want[0]), f"zones {zd}/{zb}/{zc} reverse {rev}"
+        assert np.allclose(rows, want_rows, rtol=1e-9, atol=1e-9), f"zones {zd}/{zb}/{zc}: CSV rows"
         got = copy.deepcopy(planes)
         j.compute(got, weight, [0.001], its)
-        assert bit_equal(got[0].fdata, want[0]), f"zones {zb}/{zc}, no logging"
+        assert bit_equal(got[0].fdata, want[0]), f"zones {zd}/{zb}/{zc}, no logging"
         if h >= 96:
             with j.TiledSolver(planes, weight, [0.001], its, devices=band_devices(3 if h >= 200 else 2)) as t:
                 t.run(its)
-                assert bit_equal(t.download(0), want[0]), f"zones {zb}/{zc}, bands"
+                assert bit_equal(t.download(0), want[0]), f"zones {zd}/{zb}/{zc}, bands"
 
 
 def test_concurrent_calls_are_independent(lib, oracle):

@@ -135,6 +135,41 @@ i)
     done
   done | tee $O/r06_reverse.jsonl
   ;;
+j)
+  # the whole GPU suite on the round's library so far
+  ( timeout 1700 python -m pytest tests -m gpu -q --durations=8 --timeout 900 ) > $O/r06_j_suite.log 2>&1; echo "suite rc=$?"; tail -40 $O/r06_j_suite.log
+  ;;
+k)
+  # one band's counters (review item 3a), the batch engine's occupancy (item 4), the 2-rank launch shape on one GPU (item 3)
+  T=$O/r06_pmc_band
+  ( cd /tmp
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/${T}_fetch -- python $GRAFT_REPO_ROOT/tools/band_pmc.py > /dev/null 2>&1
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/${T}_write -- python $GRAFT_REPO_ROOT/tools/band_pmc.py > /dev/null 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/${T}_stats -- python $GRAFT_REPO_ROOT/tools/band_pmc.py > /dev/null 2>&1 )
+  find ${T}_stats -name '*kernel_stats.csv' -exec cp {} ${T}_kernel_stats.csv \;
+  python tools/pmc_summary.py --about "two 2048-row bands of the 16384-wide plane on one GPU through j2p_tiled, exchange direct, -i 20 (tools/band_pmc.py): per launch = per band" ${T}_fetch ${T}_write > ${T}.json
+  python - <<PY
+import json
+d=json.load(open("${T}.json")); d["_shape"]=[16384, 2048]
+json.dump(d, open("${T}.json","w"), indent=1)
+print({k:v.get("hbm_bytes_per_launch") for k,v in d.items() if isinstance(v,dict) and "hbm_bytes_per_launch" in v})
+PY
+  rm -rf ${T}_fetch ${T}_write ${T}_stats; head -4 ${T}_kernel_stats.csv | cut -c1-220
+  ( cd /tmp; rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/r06_batch_trace -- python $GRAFT_REPO_ROOT/bench.py --config batch --steps 1 --warmup 1 --batch 32 > $GRAFT_REPO_ROOT/$O/r06_batch_trace.log 2>&1 )
+  F=$(find $O/r06_batch_trace -name '*kernel_trace.csv' | head -1); python tools/batch_occupancy.py $F 64 | tee $O/r06_batch_occupancy.json; rm -rf $O/r06_batch_trace
+  grep '^{' $O/r06_batch_trace.log | tail -1 | cut -c1-300
+  ( J2P_BENCH_ONE_DEVICE=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 --size 4096 ) > $O/r06_bench_2ranks.log 2>&1; echo "2-rank bench rc=$?"; grep '^{' $O/r06_bench_2ranks.log | tail -1 > $O/r06_bench_2ranks_1gpu_gloo.json; cut -c1-1500 $O/r06_bench_2ranks_1gpu_gloo.json; grep "^bench:" $O/r06_bench_2ranks.log | head -5
+  ;;
+l)
+  # double items at the start of the launch: parity, then shares by size (timing)
+  ( timeout 900 python -m pytest tests/test_parity_gpu.py tests/test_batch_gpu.py -q -x --timeout 600 -k "half_and_quarter or schedule_switch or tile_gate or wrong_kind or band" ) > $O/r06_l_tests.log 2>&1; echo "tests rc=$?"; tail -5 $O/r06_l_tests.log
+  for sz in "2048 2048" "4096 2048" "4096 4096" "16384 2048" "8192 8192"; do
+    for z in "0 32 10" "64 32 10" "128 32 10" "176 32 10" "200 24 8" "230 16 6" "256 0 0" "0 32 10"; do
+      set -- $sz $z
+      J2P_ZONE_D=$3 J2P_ZONE_B=$4 J2P_ZONE_C=$5 sized $1 $2 100 zones_$3_$4_$5 jpeg2png_amd/libjpeg2png_amd_exp.so
+    done
+  done | tee $O/r06_doubles.jsonl
+  ;;
 esac
     done
   done | tee $O/r06_big_knobs.jsonl
@@ -155,5 +190,40 @@ i)
       J2P_GRAD_REVERSE=$v sized $1 $2 50 reverse$v jpeg2png_amd/libjpeg2png_amd_exp.so
     done
   done | tee $O/r06_reverse.jsonl
+  ;;
+j)
+  # the whole GPU suite on the round's library so far
+  ( timeout 1700 python -m pytest tests -m gpu -q --durations=8 --timeout 900 ) > $O/r06_j_suite.log 2>&1; echo "suite rc=$?"; tail -40 $O/r06_j_suite.log
+  ;;
+k)
+  # one band's counters (review item 3a), the batch engine's occupancy (item 4), the 2-rank launch shape on one GPU (item 3)
+  T=$O/r06_pmc_band
+  ( cd /tmp
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/${T}_fetch -- python $GRAFT_REPO_ROOT/tools/band_pmc.py > /dev/null 2>&1
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/${T}_write -- python $GRAFT_REPO_ROOT/tools/band_pmc.py > /dev/null 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/${T}_stats -- python $GRAFT_REPO_ROOT/tools/band_pmc.py > /dev/null 2>&1 )
+  find ${T}_stats -name '*kernel_stats.csv' -exec cp {} ${T}_kernel_stats.csv \;
+  python tools/pmc_summary.py --about "two 2048-row bands of the 16384-wide plane on one GPU through j2p_tiled, exchange direct, -i 20 (tools/band_pmc.py): per launch = per band" ${T}_fetch ${T}_write > ${T}.json
+  python - <<PY
+import json
+d=json.load(open("${T}.json")); d["_shape"]=[16384, 2048]
+json.dump(d, open("${T}.json","w"), indent=1)
+print({k:v.get("hbm_bytes_per_launch") for k,v in d.items() if isinstance(v,dict) and "hbm_bytes_per_launch" in v})
+PY
+  rm -rf ${T}_fetch ${T}_write ${T}_stats; head -4 ${T}_kernel_stats.csv | cut -c1-220
+  ( cd /tmp; rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/r06_batch_trace -- python $GRAFT_REPO_ROOT/bench.py --config batch --steps 1 --warmup 1 --batch 32 > $GRAFT_REPO_ROOT/$O/r06_batch_trace.log 2>&1 )
+  F=$(find $O/r06_batch_trace -name '*kernel_trace.csv' | head -1); python tools/batch_occupancy.py $F 64 | tee $O/r06_batch_occupancy.json; rm -rf $O/r06_batch_trace
+  grep '^{' $O/r06_batch_trace.log | tail -1 | cut -c1-300
+  ( J2P_BENCH_ONE_DEVICE=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 --size 4096 ) > $O/r06_bench_2ranks.log 2>&1; echo "2-rank bench rc=$?"; grep '^{' $O/r06_bench_2ranks.log | tail -1 > $O/r06_bench_2ranks_1gpu_gloo.json; cut -c1-1500 $O/r06_bench_2ranks_1gpu_gloo.json; grep "^bench:" $O/r06_bench_2ranks.log | head -5
+  ;;
+l)
+  # double items at the start of the launch: parity, then shares by size (timing)
+  ( timeout 900 python -m pytest tests/test_parity_gpu.py tests/test_batch_gpu.py -q -x --timeout 600 -k "half_and_quarter or schedule_switch or tile_gate or wrong_kind or band" ) > $O/r06_l_tests.log 2>&1; echo "tests rc=$?"; tail -5 $O/r06_l_tests.log
+  for sz in "2048 2048" "4096 2048" "4096 4096" "16384 2048" "8192 8192"; do
+    for z in "0 32 10" "64 32 10" "128 32 10" "176 32 10" "200 24 8" "230 16 6" "256 0 0" "0 32 10"; do
+      set -- $sz $z
+      J2P_ZONE_D=$3 J2P_ZONE_B=$4 J2P_ZONE_C=$5 sized $1 $2 100 zones_$3_$4_$5 jpeg2png_amd/libjpeg2png_amd_exp.so
+    done
+  done | tee $O/r06_doubles.jsonl
   ;;
 esac

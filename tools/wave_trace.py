@@ -99,17 +99,17 @@ for k in (1, 2):
         "mean_resident_wavefronts_per_simd": round(float(life.sum() / (len(keys) * span)), 2),
         "resident_wavefronts_per_simd_over_time_every_5us": [round(float(v) / len(keys), 2) for v in resident[::10]],
     }
-    if k == 1 and y_only and __import__("os").environ.get("J2P_ZONE_B") == "0" and __import__("os").environ.get("J2P_ZONE_C") == "0":
+    if k == 1 and y_only and all(__import__("os").environ.get(v) == "0" for v in ("J2P_ZONE_D", "J2P_ZONE_B", "J2P_ZONE_C")):
         # who are the long-lived wavefronts?  (whole tile rows only: slot -> workgroup -> (tile row, strip), grad_item)
         sl = slot_all[m] - slot_all[m].min()
         b_, wv = sl // 4, sl % 4
         ntx = (W - 4 + 123) // 124
         ntr = (H + 15) // 16
-        n = (ntx * ntr + 3) // 4
+        n = (ntx * ((ntr + 1) // 2) + 3) // 4       # units: four strips x a PAIR of tile rows, two workgroups each
         qx, jx = b_ & 7, b_ >> 3
         cb = qx * (n >> 3) + np.minimum(qx, n & 7)
-        ident = 4 * (cb + jx) + wv
-        trow, wcol = ident // ntx, ident % ntx
+        ident = 4 * (cb + (jx >> 1)) + wv
+        trow, wcol = 2 * (ident // ntx) + (jx & 1), ident % ntx
         life_w = (t2 - t0) * 0.01
         start_w = (t0 - base) * 0.01
         xcc = (hw[m] >> 24) & 0xf
