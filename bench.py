@@ -90,6 +90,7 @@ def parse():
     ap.add_argument("--tiled-impl", choices=["both", "c", "rccl"], default="both",
                     help="N > 1: which row-tiling engine(s) to time (default both; the faster one is `value`)")
     ap.add_argument("--norm-fold", type=int, default=-1, help="A/B: 1 = norm reduction inside k_gradient, 0 = stand-alone kernels; default: the library's choice")
+    ap.add_argument("--nt", type=int, default=-1, help="A/B: non-temporal level 0..3 of the phase kernels (J2P_OPT_NT_GRADIENT); default: the library's policy")
     ap.add_argument("--norm-in-project", type=int, default=-1, help="A/B: final norm tree inside k_project (needs --norm-fold 1)")
     return ap.parse_args()
 
@@ -578,11 +579,12 @@ def roofline_object(value_mpx, gpus_used, its, elapsed, steps, band_px, per_kern
                     f"{timing_every}th iteration; the brackets themselves are in the figures (event_pair_overhead_us = what an EMPTY "
                     "bracket measures on the same stream: the scale of it; not subtracted, because with a kernel in between part of it "
                     "overlaps), so per-kernel durations read 2-3 us above rocprofv3's (profiles/), which are the reproducible ones",
-            "what_limits_it": "both limits at once: k_project moves its bytes at about the achievable HBM rate of this part (6.29 TB/s "
-                              "float4 copy, MI355X_MICROARCH.md; peak above is the 8 TB/s spec the contract asks for); k_gradient moves "
-                              "its real traffic (1.15 x algorithmic: halo rows) at 0.9 of that rate while its vector ALUs are about "
-                              "90 % busy at the 1.96 GHz the SIMDs sustain under it (profiles/r03_core_clock.jsonl, r03_decomposition.jsonl; "
-                              "DESIGN.md sections 4-5)"}
+            "what_limits_it": "k_project moves its bytes at the rate anything reaches through this part's fabric (6.1-6.3 TB/s: a float4 copy, "
+                              "and k_project itself at 8192^2 where every byte comes from HBM — the same 58-60 us per 16.8 Mpixel as at 4096^2 "
+                              "where most come from the Infinity Cache; peak above is the 8 TB/s spec the contract asks for); k_gradient is "
+                              "bound by instruction issue: four resident wavefronts finish one 16-row strip per ~6.1 us per SIMD whatever "
+                              "their order (oldest-first arbitration, profiles/r06_wave_trace.jsonl), 8.25 strips per SIMD, at the 1.96 GHz "
+                              "the SIMDs sustain under it — and moves 1.15 x its algorithmic bytes (halo rows) meanwhile (DESIGN.md sections 4-5)"}
 
 
 def single_gpu(a, j, synth, local_rank):
@@ -597,6 +599,8 @@ def single_gpu(a, j, synth, local_rank):
         solver.debug_option(j.J2P_OPT_NORM_FOLD, a.norm_fold)
     if a.norm_in_project >= 0:
         solver.debug_option(j.J2P_OPT_NORM_IN_PROJECT, a.norm_in_project)
+    if a.nt >= 0:
+        solver.debug_option(j.J2P_OPT_NT_GRADIENT, a.nt)
     del planes
     ranks = Ranks(0, 1, local_rank, False)
     launches = solver.launches_per_iteration()

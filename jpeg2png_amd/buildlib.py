@@ -111,9 +111,9 @@ EXP_LIB = os.path.join(HERE, "libjpeg2png_amd_exp.so")
 
 def build_experiments(force=False, verbose=False):
     """The experiments build (-DJ2P_EXPERIMENTS, jpeg2png_amd/libjpeg2png_amd_exp.so): the release sources plus the
-    schedules that lost their measurements (one column per lane, all channels of a joint image in one wavefront, the
-    reduction as the gradient launch's last workgroup, split phases, the single-launch iteration) and the environment
-    knobs that select them (j2p_internal.h: j2p_exp_env).  What the schedule-equivalence tests load (conftest.exp_lib)
+    schedules that lost their measurements (one column per lane, all channels of a joint image in one wavefront, split
+    phases) and the environment knobs that select them or move the shares of a gradient launch's item sizes
+    (j2p_internal.h: j2p_exp_env).  What the schedule-equivalence tests load (conftest.exp_lib)
     and the timing tools run on (J2P_LIBRARY=<this file>); never what a user of the library gets."""
     build(force=False, verbose=verbose)             # compute_host.o is shared
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

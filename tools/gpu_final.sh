@@ -9,6 +9,10 @@ export TMPDIR=/tmp
 if [ "${SKIP_SUITE:-0}" != 1 ]; then ( timeout 1500 python -m pytest tests -m gpu -q --durations=8 --timeout 900 ) > $O/pytest_gpu.log 2>&1; echo "pytest gpu rc=$?"; tail -26 $O/pytest_gpu.log; fi
 ( timeout 300 python __graft_entry__.py --smoke ) 2>&1 | tail -1
 bash tools/collect_profiles.sh $TAG 2>&1 | tail -6
+# the line as the driver runs it (BENCH_rNN.json: `python3 bench.py --gpus 1 --steps 20 --warmup 5`)
+( timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ) 2>/dev/null | grep '^{' | tail -1 > gpurun_out/${TAG}_bench_driver_shape.json; python -c "
+import json; d=json.load(open('gpurun_out/${TAG}_bench_driver_shape.json')); r=d['roofline']; h=d.get('host_to_host',{})
+print('driver shape:', d['value'], d['ms_per_step'], r['frac'], d['parity']['bit_identical'], h.get('ms_per_call'), h.get('ms_per_call_in_call_order'), [o.get('Mpx_it_per_s') for o in d.get('other_configs',[])])"
 # two ranks on this box's one GPU (gloo): the driver's --gpus N launch shape, rank 0 driving two bands, both C schedules
 ( J2P_BENCH_ONE_DEVICE=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 --size 4096 ) > $O/bench_2ranks.log 2>&1; echo "2-rank bench rc=$?"; grep '^{' $O/bench_2ranks.log | tail -1 > gpurun_out/${TAG}_bench_2ranks_1gpu_gloo.json; cut -c1-400 gpurun_out/${TAG}_bench_2ranks_1gpu_gloo.json
 # 8 bands of 16384x2048 on one GPU (C engine, both schedules; strong-scaling denominator; 256-image batch)
@@ -41,7 +45,7 @@ PY
 for combo in "direct root" "copy root" "copy all"; do set -- $combo; J2P_TILED_EXCHANGE=$1 J2P_TILED_NORM=$2 timeout 300 python tools/band_alone.py; done 2>&1 | grep '^{' | tee gpurun_out/${TAG}_band_alone.jsonl
 timeout 300 python tools/nt_scope.py | tee gpurun_out/${TAG}_nt_scope.jsonl
 # size sweep on the final kernels
-for sz in "1920 1080" "2048 2048" "4096 2048" "4096 4096" "4096 5120" "8192 4096" "16384 2048" "8192 8192"; do
+for sz in "1920 1080" "2048 2048" "4096 2048" "4096 4096" "4096 5120" "8192 4096" "16384 2048" "8192 8192" "16384 4096" "16384 8192"; do
   set -- $sz
   ( timeout 200 python bench.py --size $1 --height $2 --iterations 100 --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs ) 2>&1 | grep '^{' | tail -1 > $O/tmp.json
   python - <<PY

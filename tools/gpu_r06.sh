@@ -170,6 +170,35 @@ l)
     done
   done | tee $O/r06_doubles.jsonl
   ;;
+m)
+  # zig-zag (gradient bottom-up, projection top-down) x non-temporal level: does the alternation let MORE stay in the Infinity Cache?
+  ntsized() {  # W H ITER NT REV
+    ( J2P_GRAD_REVERSE=$5 J2P_LIBRARY=jpeg2png_amd/libjpeg2png_amd_exp.so timeout 300 python bench.py --size $1 --height $2 --iterations $3 --nt $4 --steps 4 --warmup 2 --no-cpu-baseline --no-other-configs --no-host-to-host ) 2>/dev/null | line | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print(json.dumps({'plane': '$1x$2', 'nt': $4, 'reverse': $5, 'us_per_iteration': round(r['iteration_ms']*1e3,2), 'frac': r['frac'], 'k_gradient_us': round(r['per_kernel']['k_gradient']['avg_launch_ms']*1e3,1), 'k_project_us': round(r['per_kernel']['k_project']['avg_launch_ms']*1e3,1)}))"
+  }
+  for sz in "4096 4096" "4096 5120" "8192 4096" "16384 2048" "8192 8192"; do
+    set -- $sz
+    for nt in 0 1 2 3; do
+      for rev in 0 1; do ntsized $1 $2 100 $nt $rev; done
+    done
+  done | tee $O/r06_zigzag_nt.jsonl
+  ;;
+s)
+  # randomised parity sweeps on the round's library, new seeds: as shipped, and — experiments build — with every
+  # one-channel solve forced through double / half / quarter items walked bottom-up (16-row tile rows on every canvas)
+  ( timeout 900 python tools/sweep_vs_ref.py 800 81 ) 2>&1 | tail -1 | tee $O/r06_final_sweeps.txt
+  ( timeout 600 python tools/sweep_wide.py 300 82 ) 2>&1 | tail -1 | tee -a $O/r06_final_sweeps.txt
+  ( timeout 900 python tools/sweep_tiled.py 250 83 ) 2>&1 | tail -1 | tee -a $O/r06_final_sweeps.txt
+  ( timeout 600 python tools/sweep_bands.py 120 84 ) 2>&1 | tail -1 | tee -a $O/r06_final_sweeps.txt
+  ( timeout 900 python tools/sweep_cli.py 60 85 ) 2>&1 | tail -1 | tee -a $O/r06_final_sweeps.txt
+  export J2P_LIBRARY=$PWD/jpeg2png_amd/libjpeg2png_amd_exp.so J2P_RPW=16 J2P_ZONE_D=90 J2P_ZONE_B=70 J2P_ZONE_C=50 J2P_GRAD_REVERSE=1
+  echo "experiments build, J2P_RPW=16 J2P_ZONE_D=90 J2P_ZONE_B=70 J2P_ZONE_C=50 J2P_GRAD_REVERSE=1:" | tee -a $O/r06_final_sweeps.txt
+  ( timeout 900 python tools/sweep_vs_ref.py 600 86 ) 2>&1 | tail -1 | tee -a $O/r06_final_sweeps.txt
+  ( timeout 600 python tools/sweep_wide.py 200 87 ) 2>&1 | tail -1 | tee -a $O/r06_final_sweeps.txt
+  ( timeout 900 python tools/sweep_tiled.py 150 88 ) 2>&1 | tail -1 | tee -a $O/r06_final_sweeps.txt
+  ;;
 esac
     done
   done | tee $O/r06_big_knobs.jsonl
@@ -225,5 +254,34 @@ l)
       J2P_ZONE_D=$3 J2P_ZONE_B=$4 J2P_ZONE_C=$5 sized $1 $2 100 zones_$3_$4_$5 jpeg2png_amd/libjpeg2png_amd_exp.so
     done
   done | tee $O/r06_doubles.jsonl
+  ;;
+m)
+  # zig-zag (gradient bottom-up, projection top-down) x non-temporal level: does the alternation let MORE stay in the Infinity Cache?
+  ntsized() {  # W H ITER NT REV
+    ( J2P_GRAD_REVERSE=$5 J2P_LIBRARY=jpeg2png_amd/libjpeg2png_amd_exp.so timeout 300 python bench.py --size $1 --height $2 --iterations $3 --nt $4 --steps 4 --warmup 2 --no-cpu-baseline --no-other-configs --no-host-to-host ) 2>/dev/null | line | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print(json.dumps({'plane': '$1x$2', 'nt': $4, 'reverse': $5, 'us_per_iteration': round(r['iteration_ms']*1e3,2), 'frac': r['frac'], 'k_gradient_us': round(r['per_kernel']['k_gradient']['avg_launch_ms']*1e3,1), 'k_project_us': round(r['per_kernel']['k_project']['avg_launch_ms']*1e3,1)}))"
+  }
+  for sz in "4096 4096" "4096 5120" "8192 4096" "16384 2048" "8192 8192"; do
+    set -- $sz
+    for nt in 0 1 2 3; do
+      for rev in 0 1; do ntsized $1 $2 100 $nt $rev; done
+    done
+  done | tee $O/r06_zigzag_nt.jsonl
+  ;;
+s)
+  # randomised parity sweeps on the round's library, new seeds: as shipped, and — experiments build — with every
+  # one-channel solve forced through double / half / quarter items walked bottom-up (16-row tile rows on every canvas)
+  ( timeout 900 python tools/sweep_vs_ref.py 800 81 ) 2>&1 | tail -1 | tee $O/r06_final_sweeps.txt
+  ( timeout 600 python tools/sweep_wide.py 300 82 ) 2>&1 | tail -1 | tee -a $O/r06_final_sweeps.txt
+  ( timeout 900 python tools/sweep_tiled.py 250 83 ) 2>&1 | tail -1 | tee -a $O/r06_final_sweeps.txt
+  ( timeout 600 python tools/sweep_bands.py 120 84 ) 2>&1 | tail -1 | tee -a $O/r06_final_sweeps.txt
+  ( timeout 900 python tools/sweep_cli.py 60 85 ) 2>&1 | tail -1 | tee -a $O/r06_final_sweeps.txt
+  export J2P_LIBRARY=$PWD/jpeg2png_amd/libjpeg2png_amd_exp.so J2P_RPW=16 J2P_ZONE_D=90 J2P_ZONE_B=70 J2P_ZONE_C=50 J2P_GRAD_REVERSE=1
+  echo "experiments build, J2P_RPW=16 J2P_ZONE_D=90 J2P_ZONE_B=70 J2P_ZONE_C=50 J2P_GRAD_REVERSE=1:" | tee -a $O/r06_final_sweeps.txt
+  ( timeout 900 python tools/sweep_vs_ref.py 600 86 ) 2>&1 | tail -1 | tee -a $O/r06_final_sweeps.txt
+  ( timeout 600 python tools/sweep_wide.py 200 87 ) 2>&1 | tail -1 | tee -a $O/r06_final_sweeps.txt
+  ( timeout 900 python tools/sweep_tiled.py 150 88 ) 2>&1 | tail -1 | tee -a $O/r06_final_sweeps.txt
   ;;
 esac
