@@ -123,6 +123,13 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value);
  * (1xx = gradient phase, 2xx = projection phase, see j2p_kernels.hip.h) and its offset; J2P_ESTATE in a release
  * build, where the checks are compiled out. */
 int j2p_debug_build(void);
+/* Test hook (no device needed): the map from k_gradient's workgroups to (strip, rows) — j2p_kernels.hip.h: grad_item —
+ * evaluated on the host for a W x rows plane with `rows_per_tile`-row tile rows, one wavefront per strip
+ * (channel_wavefronts 1) or per strip and channel (2, 3), the given shares (1/256 of every XCD's run) of double / half /
+ * quarter tile-row items, top-down or bottom-up.  items: up to max_items records of five unsigned {strip, first row,
+ * rows, tile row, kind (0 whole, 1 half, 2 quarter, 3 double)}; *n_items: how many the launch has; *workgroups: its grid. */
+int j2p_debug_grad_items(unsigned W, unsigned rows, unsigned rows_per_tile, unsigned channel_wavefronts, unsigned zone_d, unsigned zone_b,
+                         unsigned zone_c, int reverse, unsigned *items, unsigned max_items, unsigned *n_items, unsigned *workgroups);
 int j2p_solver_debug_violations(j2p_solver *s, unsigned long long *count, unsigned *site, unsigned long long *offset);
 
 /* Timing tool (builds with -DJ2P_TRACE only, tools/wave_trace.py; J2P_ESTATE otherwise): while on, every wavefront

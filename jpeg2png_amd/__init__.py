@@ -83,7 +83,7 @@ C_ABI_SYMBOLS = [
     "j2p_solver_global_rowsums", "j2p_solver_link_bands", "j2p_tiled_exchange",
     "j2p_batch_create", "j2p_batch_destroy", "j2p_batch_submit", "j2p_batch_wait",
     "compute", "j2p_compute", "j2p_compute_tiled", "j2p_compute_timing", "j2p_debug_fail_run_after", "j2p_solver_launches_per_iteration", "j2p_solver_timing_overhead",
-    "j2p_debug_build", "j2p_experiments_build", "j2p_solver_debug_violations", "j2p_solver_trace", "j2p_division_exhaustive",
+    "j2p_debug_build", "j2p_debug_grad_items", "j2p_experiments_build", "j2p_solver_debug_violations", "j2p_solver_trace", "j2p_division_exhaustive",
 ]
 J2P_OPT_NORM_FOLD, J2P_OPT_JOINT_INWAVE, J2P_OPT_NORM_IN_PROJECT, J2P_OPT_NT_GRADIENT, J2P_OPT_MIXED_PROJECT = 1, 2, 4, 5, 6
 

@@ -1666,8 +1666,9 @@ __host__ __device__ __forceinline__ unsigned grad_grid(unsigned n /* units */, Z
 }
 
 // workgroup -> item of the calling wavefront (everything wave-uniform); false: the workgroup has nothing to do
+// (host too: j2p_debug_grad_items enumerates a launch's items for the CPU test of this map, tests/test_capi.py)
 template <int J>
-__device__ __forceinline__ bool grad_item(const Geo &g, unsigned b, int wave, StripItem &it)
+__host__ __device__ __forceinline__ bool grad_item(const Geo &g, unsigned b, int wave, StripItem &it)
 {
         const unsigned q = b & 7, j = b >> 3;
         const unsigned n = g.units;
@@ -1717,8 +1718,17 @@ __device__ __forceinline__ bool grad_item(const Geo &g, unsigned b, int wave, St
         return true;
 }
 
+// (the checked build carries its range descriptors in registers: at four wavefronts per SIMD it spilled 132-164 bytes to
+// scratch, and kernels that need scratch on several streams waiting for each other's events — a row-tiled run with its
+// bands on one GPU — hung the queue every other run, tests/test_debug_build_gpu.py; two wavefronts per SIMD, no scratch)
+#ifdef J2P_DEBUG
+constexpr int kDebugWaveCap = 2;
+#else
+constexpr int kDebugWaveCap = 64;
+#endif
+constexpr int grad_waves(int want) { return want < kDebugWaveCap ? want : kDebugWaveCap; }
 template <int NCH, bool TGV, bool LOG, int J = 1, int NT = 0, int PX = 2>
-__global__ __launch_bounds__((J == 1 ? 256 : 64 * J), (PX == 1 ? (J == 1 && !LOG ? 6 : 2) : NCH == 1 ? (J == 1 && !LOG ? (NT >= 1 ? kBigWaves : kHotWaves) : kGradWaves1) : NCH == 2 ? 3 : kGradWaves3))
+__global__ __launch_bounds__((J == 1 ? 256 : 64 * J), grad_waves(PX == 1 ? (J == 1 && !LOG ? 6 : 2) : NCH == 1 ? (J == 1 && !LOG ? (NT >= 1 ? kBigWaves : kHotWaves) : kGradWaves1) : NCH == 2 ? 3 : kGradWaves3))
 void k_gradient(GradArgs a)
 {
         static_assert(J == 1 || NCH == 1, "channel-per-wavefront mode keeps one channel per wavefront");

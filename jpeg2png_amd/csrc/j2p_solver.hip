@@ -1338,6 +1338,45 @@ int j2p_experiments_build(void)
 #endif
 }
 
+int j2p_debug_grad_items(unsigned W, unsigned rows, unsigned rows_per_tile, unsigned channel_wavefronts, unsigned zone_d, unsigned zone_b,
+                         unsigned zone_c, int reverse, unsigned *items /* [max][5]: strip, first row, rows, tile row, kind */, unsigned max_items,
+                         unsigned *n_items, unsigned *workgroups)
+{
+        // the map of k_gradient's launch (grad_item) evaluated on the HOST, wavefront by wavefront: no device needed
+        if(!items || !n_items || !workgroups || W < 8 || rows == 0 || rows_per_tile == 0 || channel_wavefronts < 1 || channel_wavefronts > 3) {
+                return fail(J2P_EINVAL, "bad argument");
+        }
+        Geo g;
+        memset(&g, 0, sizeof(g));
+        g.W = W; g.H = rows; g.row0 = 0; g.rows = rows; g.rpw = rows_per_tile;
+        g.ntx = W <= 4 ? 1u : (W - 4 + 123) / 124;
+        g.seg_off = 0; g.seg_mul = 1;
+        g.ntr_launch = (rows + rows_per_tile - 1) / rows_per_tile;
+        const unsigned positions = g.ntx * ((g.ntr_launch + 1) / 2);
+        const bool joint = channel_wavefronts > 1;
+        g.units = joint ? positions : (positions + 3) / 4;
+        g.zone_d = zone_d; g.zone_b = zone_b; g.zone_c = zone_c;
+        g.reverse = reverse ? 1u : 0u;
+        const unsigned nwg = grad_grid(g.units, zone_shares(g));
+        *workgroups = nwg;
+        unsigned n = 0;
+        for(unsigned b = 0; b < nwg; b++) {
+                for(int wave = 0; wave < (joint ? 1 : 4); wave++) {
+                        StripItem it;
+                        const bool ok = joint ? grad_item<3>(g, b, wave, it) : grad_item<1>(g, b, wave, it);
+                        if(!ok || !it.active) { continue; }
+                        if(n < max_items) {
+                                unsigned *o = items + 5 * (size_t)n;
+                                const unsigned t1 = (unsigned)(it.t0 + it.nrows) < rows ? (unsigned)(it.t0 + it.nrows) : rows;
+                                o[0] = (unsigned)it.wcol; o[1] = (unsigned)it.t0; o[2] = t1 - (unsigned)it.t0; o[3] = it.tr; o[4] = (unsigned)it.kind;
+                        }
+                        n++;
+                }
+        }
+        *n_items = n;
+        return J2P_OK;
+}
+
 int j2p_debug_build(void)
 {
 #ifdef J2P_DEBUG

@@ -150,3 +150,70 @@ def test_struct_layouts_against_the_reference_headers(lib, tmp_path):
                        check=True)
         outs.append(subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout)
     assert outs[0] == outs[1] == outs[2], outs
+
+
+def test_gradient_launch_map_covers_every_row_of_every_strip_exactly_once():
+    """k_gradient's workgroups decode their work from their number (j2p_kernels.hip.h: grad_item): units of four strips x a
+    pair of tile rows, every XCD a contiguous run, dealt as double / whole / half / quarter tile-row items.  Whatever the
+    shares, the canvas and the walking direction, every row of every strip must be marched exactly once, a half or quarter
+    item must stay inside its tile row, a double item must be two whole tile rows of one strip — evaluated on the host
+    through j2p_debug_grad_items (no GPU needed)."""
+    import ctypes
+    import numpy as np
+    import jpeg2png_amd as j
+    lib = j.load_library()
+    lib.j2p_debug_grad_items.argtypes = [ctypes.c_uint] * 7 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_uint,
+                                         ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
+    rng = np.random.default_rng(606)
+    cases = [(4096, 4096, 16, 1, 0, 32, 10, 0), (4096, 4096, 16, 1, 200, 24, 8, 1), (16384, 2048, 16, 1, 200, 24, 8, 0),
+             (1920, 1080, 8, 1, 0, 32, 0, 0), (8, 8, 4, 1, 0, 0, 0, 0), (520, 136, 16, 3, 0, 0, 0, 0), (264, 200, 8, 2, 0, 0, 0, 1)]
+    for _ in range(60):
+        rpw = int(rng.choice([4, 8, 16]))
+        zd, zb, zc = (int(v) for v in rng.integers(0, 257, 3))
+        if rpw < 16:
+            zc = 0
+        if rpw < 8:
+            zd = zb = 0
+        if zb + zc > 256:
+            zc = 256 - zb
+        if zd + zb + zc > 256:
+            zd = 256 - zb - zc
+        cases.append((int(rng.integers(1, 300)) * 8, int(rng.integers(1, 80)) * 8, rpw, 1, zd, zb, zc, int(rng.integers(0, 2))))
+    buf = np.zeros((1 << 18, 5), np.uint32)
+    for W, rows, rpw, cw, zd, zb, zc, rev in cases:
+        n, wgs = ctypes.c_uint(), ctypes.c_uint()
+        rc = lib.j2p_debug_grad_items(W, rows, rpw, cw, zd, zb, zc, rev, buf.ctypes.data, buf.shape[0], ctypes.byref(n), ctypes.byref(wgs))
+        assert rc == 0 and n.value <= buf.shape[0], (W, rows, rpw)
+        it = buf[:n.value].astype(np.int64)
+        ntx = 1 if W <= 4 else (W - 4 + 123) // 124
+        cover = np.zeros((ntx, rows), np.int32)
+        for strip, t0, nr, tr, kind in it:
+            assert 0 <= strip < ntx and nr > 0 and t0 + nr <= rows
+            cover[strip, t0:t0 + nr] += 1
+            if kind == 3:
+                assert t0 == tr * rpw and (nr == 2 * rpw or t0 + nr == rows)
+            else:
+                assert tr * rpw <= t0 and t0 + nr <= min((tr + 1) * rpw, rows), "an item leaves its tile row"
+                assert nr <= rpw >> (0 if kind == 0 else kind)
+        assert (cover == 1).all(), f"{W}x{rows} rpw {rpw} zones {zd}/{zb}/{zc} reverse {rev}: rows marched {np.unique(cover)} times"
+        # one workgroup = four wavefronts (one channel) or one strip (joint): the grid holds the items with little to spare
+        per_wg = 4 if cw == 1 else 1
+        assert n.value <= wgs.value * per_wg
+
+
+@pytest.mark.parametrize("flags", [[], ["-DJ2P_DEBUG"]], ids=["release", "checked"])
+def test_no_kernel_spills_to_scratch(flags):
+    """No kernel of either build may need scratch memory.  Besides the speed: kernels that use scratch on several streams
+    which wait for each other's events — the bands of a row-tiled run that share a GPU — hung the queues every other run
+    (round 6: the checked build's k_gradient had grown to 128 VGPRs + 132 bytes of scratch at four wavefronts per SIMD;
+    tests/test_debug_build_gpu.py timed out on the GPU box).  Read from the device assembly's metadata; no GPU needed."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_resources.py"), *flags], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-500:]
+    rows = [ln for ln in r.stdout.splitlines() if " scratch " in ln]
+    assert len(rows) > 40, "kernel_resources.py found too few kernels"
+    bad = [ln for ln in rows if not re.search(r"scratch 0$", ln)]
+    assert not bad, "kernels with scratch:\n" + "\n".join(bad)
