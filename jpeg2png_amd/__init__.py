@@ -563,9 +563,10 @@ class Batch:
         self._pending = {}
 
     def submit(self, planes, weight, pweight, iterations, separate=False, width=None, height=None, bits=0, tile=False,
-               tile_devices=None, tile_min_band_pixels=None, out=None):
+               tile_devices=None, tile_min_band_pixels=None, out=None, on_progress=None):
         """tile=True: the image is row-tiled over the batch's devices instead of solved on one of them;
-        tile_devices=(first, count): over that slice of the batch's device list only"""
+        tile_devices=(first, count): over that slice of the batch's device list only; on_progress(n): called from the worker
+        thread whenever n more iterations of one of the job's solves have finished (the CLI's progress bar, jpeg2png.c:449-452)"""
         n = len(planes)
         job = _CJob()
         job.nchannel = n
@@ -606,6 +607,10 @@ class Batch:
             out = [np.empty(shapes[c], dtype=np.float32) for c in range(n)]
             for c in range(n):
                 job.out_planes[c] = out[c].ctypes.data
+        if on_progress is not None:
+            cb = _PROGRESS_CB(lambda _user, n: on_progress(int(n)))
+            job.on_progress = cb
+            keep = (keep, cb)                       # the trampoline lives as long as the job
         t = ctypes.c_int()
         _check(self._lib.j2p_batch_submit(self._h, ctypes.byref(job), ctypes.byref(t)))
         self._pending[t.value] = (out, keep)

@@ -10,6 +10,7 @@
 // a job performs no hipMalloc / hipFree — the device-wide synchronisation inside hipFree is what used to
 // serialise concurrent compute() calls.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -52,7 +53,23 @@ struct j2p_batch {
 
 namespace {
 
-constexpr unsigned kChunk = 32;         // iterations per round trip when a job wants progress or log rows
+// iterations per round trip when a job wants progress or log rows: as compute() does it (compute_host.c) — one iteration
+// each at first, then a sixth of the iterations done so far, never more than ~50 ms worth or kChunkMax (the row buffer):
+// the bar of the default `-i 50` moves two dozen times, not twice (compute.c:449-452 ticks once per iteration)
+constexpr unsigned kChunkMax = 256;
+constexpr double kChunkMs = 50.;
+unsigned next_chunk(unsigned done, unsigned left, std::chrono::steady_clock::time_point t_loop)
+{
+        unsigned chunk = done / 6;
+        if(done) {
+                const double per_it = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop).count() / done;
+                const double most = per_it > 0. ? kChunkMs / per_it : (double)kChunkMax;
+                if((double)chunk > most) { chunk = (unsigned)most; }
+        }
+        if(chunk > kChunkMax) { chunk = kChunkMax; }
+        if(chunk < 1) { chunk = 1; }
+        return left < chunk ? left : chunk;
+}
 
 #define JOB_TRY(expr)                                                                              \
         do {                                                                                       \
@@ -148,12 +165,13 @@ int run_job_tiled(const j2p_job &d, const std::vector<int> &devices, bool *handl
         if(!chunked) {
                 for(unsigned k = 0; k < nsolve; k++) { JOB_TRY(j2p_tiled_run(t[k], its[k], nullptr)); }
         } else {
-                j2p_log_row rows[kChunk];
+                j2p_log_row rows[kChunkMax];
+                const auto t_loop = std::chrono::steady_clock::now();
                 for(;;) {
                         bool any = false;
                         for(unsigned k = 0; k < nsolve; k++) {
                                 const unsigned left = its[k] - done[k];
-                                const unsigned step = left < kChunk ? left : kChunk;
+                                const unsigned step = next_chunk(done[k], left, t_loop);
                                 if(!step) { continue; }
                                 any = true;
                                 JOB_TRY(j2p_tiled_run(t[k], step, d.on_rows ? rows : nullptr));
@@ -220,13 +238,14 @@ int run_job(const j2p_job &d, int device)
         } else {
                 // compute.c:427-453 in chunks so that the caller's bar and CSV keep moving; without log rows the
                 // chunks of the (up to three) solvers are issued back to back and overlap on the GPU
-                j2p_log_row rows[kChunk];
+                j2p_log_row rows[kChunkMax];
+                const auto t_loop = std::chrono::steady_clock::now();
                 for(;;) {
                         unsigned step[J2P_MAX_CHANNELS] = {0, 0, 0};
                         bool any = false;
                         for(unsigned c = 0; c < nsolver; c++) {
                                 const unsigned left = its[c] - done[c];
-                                step[c] = left < kChunk ? left : kChunk;
+                                step[c] = next_chunk(done[c], left, t_loop);
                                 if(!step[c]) { continue; }
                                 any = true;
                                 JOB_TRY(j2p_solver_run(s[c], step[c], d.on_rows ? rows : nullptr));

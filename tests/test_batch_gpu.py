@@ -84,6 +84,28 @@ def test_batch_refuses_an_output_array_of_the_wrong_kind(lib):
         assert good8.any() and good16.any()
 
 
+@pytest.mark.parametrize("tile", [False, True])
+def test_progress_ticks_follow_the_clock(lib, tile):
+    """the CLI's progress bar is fed through j2p_job.on_progress: like the reference's once-per-iteration tick
+    (compute.c:449-452) it must move WHILE the solve runs — one iteration per round trip at first, then a sixth of what is
+    done, never more than ~50 ms worth (j2p_batch.hip: next_chunk; compute_host.c does the same for compute()) — not in a
+    few bursts of 32; one solver and the row tiling"""
+    import time
+    import jpeg2png_amd as j
+    planes = make_case(160, 144, "420", 10, seed=9)
+    its, ticks = 50, []
+    with j.Batch(devices=band_devices(2 if tile else 1), slots_per_device=1) as b:
+        t = b.submit(planes, 0.3, [0.001] * 3, its, tile=tile, tile_min_band_pixels=0,
+                     on_progress=lambda n: ticks.append((time.perf_counter(), n)))
+        out = b.wait(t)
+    assert sum(n for _, n in ticks) == its
+    assert len(ticks) >= 20 and ticks[0][1] == 1 and max(n for _, n in ticks) <= 9
+    ref = copy.deepcopy(planes)
+    j.compute(ref, 0.3, [0.001] * 3, its)
+    for c in range(3):
+        assert bit_equal(out[c], ref[c].fdata)              # chunking changes nothing about the result
+
+
 def test_batch_reports_a_bad_job_and_carries_on(lib):
     import jpeg2png_amd as j
     good = make_case(64, 48, "444", 20, seed=3)
