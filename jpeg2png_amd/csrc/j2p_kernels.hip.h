@@ -1528,9 +1528,7 @@ __device__ __forceinline__ void march_rows(const GradArgs &a, V *xchg, const Str
         }
         // (rows per strip that are no multiple of four — J2P_RPW experiments only — leave a group open)
         if(((t1 - t0) & 3) != 0) { close_group(t1 - 1); }
-#ifdef J2P_TRACE
-        (void)tr_data;
-#endif
+        (void)tr_data;          // (J2P_TRACE builds: stamped when the first rows have arrived)
 }
 
 // One wavefront of a gradient launch: march the item's rows, then turn the per-lane sums of g^2 into the partial of
@@ -1541,7 +1539,7 @@ __device__ __forceinline__ void march_rows(const GradArgs &a, V *xchg, const Str
 template <int NCH, bool TGV, bool LOG, int J, int NT, int PX, class V>
 __device__ __forceinline__ void gradient_strip(const GradArgs &a, V *xchg, double *fold_buf, const StripItem &it)
 {
-        static_assert(NCH == 1 || J == 1, "");
+        static_assert(NCH == 1 || J == 1, "one channel per wavefront when a workgroup holds several");
         const int lane = (int)threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
         const int cbase = J == 1 ? 0 : wave;
