@@ -91,6 +91,7 @@ def parse():
                     help="N > 1: which row-tiling engine(s) to time (default both; the faster one is `value`)")
     ap.add_argument("--norm-fold", type=int, default=-1, help="A/B: 1 = norm reduction inside k_gradient, 0 = stand-alone kernels; default: the library's choice")
     ap.add_argument("--nt", type=int, default=-1, help="A/B: non-temporal level 0..3 of the phase kernels (J2P_OPT_NT_GRADIENT); default: the library's policy")
+    ap.add_argument("--narrow", type=int, default=-1, help="A/B: 0 = the projection reads int16 coefficients although one byte each would do (J2P_OPT_NARROW_COEFFICIENTS)")
     ap.add_argument("--norm-in-project", type=int, default=-1, help="A/B: final norm tree inside k_project (needs --norm-fold 1)")
     return ap.parse_args()
 
@@ -601,6 +602,8 @@ def single_gpu(a, j, synth, local_rank):
         solver.debug_option(j.J2P_OPT_NORM_IN_PROJECT, a.norm_in_project)
     if a.nt >= 0:
         solver.debug_option(j.J2P_OPT_NT_GRADIENT, a.nt)
+    if a.narrow >= 0:
+        solver.debug_option(j.J2P_OPT_NARROW_COEFFICIENTS, a.narrow)
     del planes
     ranks = Ranks(0, 1, local_rank, False)
     launches = solver.launches_per_iteration()

@@ -114,7 +114,12 @@ void j2p_pool_trim(void);
                                      create and reset (environment J2P_NT_SCOPE=solver: this solver's own only) */
 #define J2P_OPT_MIXED_PROJECT 6   /* 1 (default): canvases up to 1 Mpixel project all channels in ONE launch whatever their
                                      sampling; 0: one launch per sampling class, as large canvases do */
+#define J2P_OPT_NARROW_COEFFICIENTS 7 /* 1 (default): a channel whose quantised coefficients all lie in [-127, 127] (found at create)
+                                     keeps them resident as one byte each and the projection reads those: 21 instead of
+                                     22 bytes per pixel; 0: the int16 form (jpeg2png.h:14) for every channel — same floats, same bits */
 int j2p_solver_debug_option(j2p_solver *s, int option, int value);
+/* bytes per quantised coefficient the projection kernel reads for channel c: 1 or 2 (J2P_OPT_NARROW_COEFFICIENTS) */
+int j2p_solver_coefficient_bytes(const j2p_solver *s, unsigned c, unsigned *bytes);
 
 /* The checked build (the analogue of the reference's DEBUG=1, whose pixel indexer p() asserts every access,
  * utils.h:68-81): compiled with -DJ2P_DEBUG, every global load and store of the two phase kernels is compared

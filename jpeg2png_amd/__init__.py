@@ -84,8 +84,10 @@ C_ABI_SYMBOLS = [
     "j2p_batch_create", "j2p_batch_destroy", "j2p_batch_submit", "j2p_batch_wait",
     "compute", "j2p_compute", "j2p_compute_tiled", "j2p_compute_timing", "j2p_debug_fail_run_after", "j2p_solver_launches_per_iteration", "j2p_solver_timing_overhead",
     "j2p_debug_build", "j2p_debug_grad_items", "j2p_experiments_build", "j2p_solver_debug_violations", "j2p_solver_trace", "j2p_division_exhaustive",
+    "j2p_solver_coefficient_bytes",
 ]
 J2P_OPT_NORM_FOLD, J2P_OPT_JOINT_INWAVE, J2P_OPT_NORM_IN_PROJECT, J2P_OPT_NT_GRADIENT, J2P_OPT_MIXED_PROJECT = 1, 2, 4, 5, 6
+J2P_OPT_NARROW_COEFFICIENTS = 7
 
 _lib = None
 
@@ -410,6 +412,12 @@ class Solver:
         """kernel launches per iteration of an unlogged run (2, or 3 with a reduction launch between the phases)"""
         n = ctypes.c_uint()
         _check(self._lib.j2p_solver_launches_per_iteration(self._h, ctypes.byref(n)))
+        return n.value
+
+    def coefficient_bytes(self, c=0):
+        """bytes per quantised coefficient the projection reads for channel c: 1 (every |d| <= 127) or 2"""
+        n = ctypes.c_uint()
+        _check(self._lib.j2p_solver_coefficient_bytes(self._h, int(c), ctypes.byref(n)))
         return n.value
 
     def debug_option(self, option, value):

@@ -220,6 +220,7 @@ struct ChanDev {
         float *grad;        // objective gradient, own rows
         float *pg;          // carried prob-gradient state, coefficient raster, band-local
         const int16_t *d;   // quantised coefficients, block-major, band-local
+        const uint8_t *d8;  // the same as d + 128 in one byte each when every |d| of the channel is <= 127 (k_narrow_coefficients), else NULL
         const float *q;     // 64 floats
         unsigned cw, ch;    // coefficient plane size (whole image)
         unsigned ws, hs;    // subsampling
@@ -2435,25 +2436,47 @@ __device__ __forceinline__ void project_strip(const ProjArgs &a, ProjShared &sh)
         float e[8];
         double dist = 0.;
         {
-                int4 raw = make_int4(0, 0, 0, 0);
-                if(bcov) {
-                        const size_t blk = (size_t)(cy0 / 8 - k.crow0 / 8) * (k.cw / 8) + bx;
-                        J2P_CHK(k, d, k.d + blk * 64 + rr * 8, 16, 211);
-                        if constexpr(NT >= 3) {
-                                typedef int v4i __attribute__((ext_vector_type(4)));
-                                const v4i rv = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(k.d + blk * 64 + rr * 8));
-                                raw = make_int4(rv.x, rv.y, rv.z, rv.w);
-                        } else {
-                                raw = *reinterpret_cast<const int4 *>(k.d + blk * 64 + rr * 8);
+                // the lane's eight coefficients d as floats.  Wide form: 16 bytes of int16, two per dword (low half = even
+                // coefficient).  Narrow form (ChanDev::d8, wave-uniform: channels all of whose |d| are <= 127 — every
+                // coefficient of a Q <= 50 image): 8 bytes of d + 128, (float)byte - 128.f is d exactly; one byte per pixel
+                // less for the phase to read
+                v2f dfs[4];
+                const size_t blk = bcov ? (size_t)(cy0 / 8 - k.crow0 / 8) * (k.cw / 8) + bx : 0;
+                if(k.d8) {
+                        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                        v2u rb = v2u{0x80808080u, 0x80808080u};
+                        if(bcov) {
+                                J2P_CHK(k, d, k.d8 + blk * 64 + rr * 8, 8, 214);
+                                if constexpr(NT >= 3) { rb = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(k.d8 + blk * 64 + rr * 8)); }
+                                else { rb = *reinterpret_cast<const v2u *>(k.d8 + blk * 64 + rr * 8); }
                         }
+                        const unsigned rw[2] = {rb.x, rb.y};
+#pragma unroll
+                        for(int p = 0; p < 4; p++) {
+                                const unsigned w = rw[p >> 1] >> (16 * (p & 1));
+                                dfs[p] = v2f{(float)(w & 0xffu), (float)((w >> 8) & 0xffu)} - 128.f;
+                        }
+                } else {
+                        int4 raw = make_int4(0, 0, 0, 0);
+                        if(bcov) {
+                                J2P_CHK(k, d, k.d + blk * 64 + rr * 8, 16, 211);
+                                if constexpr(NT >= 3) {
+                                        typedef int v4i __attribute__((ext_vector_type(4)));
+                                        const v4i rv = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(k.d + blk * 64 + rr * 8));
+                                        raw = make_int4(rv.x, rv.y, rv.z, rv.w);
+                                } else {
+                                        raw = *reinterpret_cast<const int4 *>(k.d + blk * 64 + rr * 8);
+                                }
+                        }
+                        const int rw[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                        for(int p = 0; p < 4; p++) { dfs[p] = v2f{(float)(short)(rw[p] & 0xffff), (float)(rw[p] >> 16)}; }
                 }
-                const int rw[4] = {raw.x, raw.y, raw.z, raw.w};
                 v2f t2[4], q2[4];
                 NumScreen scr;
 #pragma unroll
                 for(int p = 0; p < 4; p++) {
-                        // two int16 per dword: low half = even coefficient
-                        const v2f df = v2f{(float)(short)(rw[p] & 0xffff), (float)(rw[p] >> 16)};
+                        const v2f df = dfs[p];
                         const v2f q = *reinterpret_cast<const v2f *>(&qs[rr * 8 + 2 * p]);
                         const v2f lo = (df - 0.5f) * q, hi = (df + 0.5f) * q;
                         v2f x = v2f{v[2 * p], v[2 * p + 1]};
@@ -2663,6 +2686,33 @@ __global__ __launch_bounds__(256) void k_fill_zero(float *p, size_t n)
 }
 
 // decode_coefficients + unbox (jpeg.c:83-92, box.c:5-19): one wavefront per 8 blocks
+// The coefficients of a channel once more as one byte each (d + 128), and the largest |d| met: when that is <= 127 the
+// projection reads the bytes (ChanDev::d8) — the values it computes with are the same floats.  16 bytes in, 8 out per step.
+__global__ __launch_bounds__(256) void k_narrow_coefficients(const int16_t *d, uint8_t *d8, size_t cells, unsigned *maxabs)
+{
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        unsigned m = 0;
+        const size_t n8 = cells / 8;                                   // (cells is a multiple of 64: whole blocks)
+        for(size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+                const v4i r = *reinterpret_cast<const v4i *>(d + i * 8);
+                const int w[4] = {r.x, r.y, r.z, r.w};
+                unsigned b[8];
+#pragma unroll
+                for(int p = 0; p < 4; p++) {
+                        const int lo = (short)(w[p] & 0xffff), hi = w[p] >> 16;
+                        m = max(m, (unsigned)(lo < 0 ? -lo : lo));
+                        m = max(m, (unsigned)(hi < 0 ? -hi : hi));
+                        b[2 * p] = (unsigned)(lo + 128) & 0xffu;
+                        b[2 * p + 1] = (unsigned)(hi + 128) & 0xffu;
+                }
+                *reinterpret_cast<v2u *>(d8 + i * 8) = v2u{b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24), b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24)};
+        }
+#pragma unroll
+        for(int off = 32; off > 0; off >>= 1) { m = max(m, (unsigned)__shfl_down((int)m, off, 64)); }
+        if((threadIdx.x & 63) == 0 && m) { atomicMax(maxabs, m); }
+}
+
 __global__ __launch_bounds__(256) void k_decode(const int16_t *d, const float *q, float *out, unsigned cw, unsigned nblocks_y)
 {
         __shared__ __attribute__((aligned(16))) float tp[4 * kTpWave];

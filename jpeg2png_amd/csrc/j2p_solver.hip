@@ -64,6 +64,9 @@ struct ChanHost {
         float *grad = nullptr;
         float *pg = nullptr;
         int16_t *d = nullptr;
+        uint8_t *d8 = nullptr;               // d + 128 in bytes (k_narrow_coefficients); read by k_project instead of d when `narrow`
+        bool narrow_fits = false;            // every |d| of the channel's rows held here is <= 127
+        bool narrow = false;                 // ... and the projection reads the bytes (J2P_OPT_NARROW_COEFFICIENTS, default on)
         float *q = nullptr;
         float *decoded = nullptr;            // frows * cw floats
         float *scratch_f = nullptr;          // decode scratch of bands too short to lend their x buffers (create only)
@@ -107,6 +110,7 @@ struct j2p_solver {
         size_t live_ws = 0, live_g = 0, live_planes = 0, live_d = 0;
         bool phase_log = false;         // the gradient phase of the running iteration was issued with logging
         bool mixed_project = true;      // small canvases: all samplings in one projection launch (J2P_OPT_MIXED_PROJECT)
+        unsigned *d_maxabs = nullptr;                 // [channel] largest |d| (k_narrow_coefficients, create only)
         unsigned long long *dbg_counters = nullptr;   // J2P_DEBUG builds: [0] address violations, [1] first site, [2] first offset
         unsigned long long *trace = nullptr;          // J2P_TRACE builds: wave records (tools/wave_trace.py)
         unsigned trace_cap = 0, trace_used = 0;      // records reserved by the launches so far
@@ -361,6 +365,7 @@ ChanDev chan_dev(const j2p_solver *s, unsigned c)
         k.grad = h.grad;
         k.pg = h.pg;
         k.d = h.d;
+        k.d8 = h.narrow ? h.d8 : nullptr;
         k.q = h.q;
         k.cw = h.cw;
         k.ch = h.ch;
@@ -385,7 +390,8 @@ ChanDev chan_dev(const j2p_solver *s, unsigned c)
                 const size_t cells = (size_t)(h.crows ? h.crows : 1) * h.cw;
                 k.dbg.grad = {reinterpret_cast<const char *>(h.grad), reinterpret_cast<const char *>(h.grad + (size_t)s->rows * s->W)};
                 k.dbg.pg = {reinterpret_cast<const char *>(h.pg), reinterpret_cast<const char *>(h.pg + cells)};
-                k.dbg.d = {reinterpret_cast<const char *>(h.d), reinterpret_cast<const char *>(h.d + cells)};
+                if(h.narrow) { k.dbg.d = {reinterpret_cast<const char *>(h.d8), reinterpret_cast<const char *>(h.d8 + cells)}; }
+                else { k.dbg.d = {reinterpret_cast<const char *>(h.d), reinterpret_cast<const char *>(h.d + cells)}; }
                 k.dbg.counters = s->dbg_counters;
         }
 #endif
@@ -1140,6 +1146,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                         carve.take(h.pg, (size_t)(h.crows ? h.crows : 1) * h.cw);
                         carve.take(h.decoded, (size_t)h.frows * h.cw);
                         carve.take(h.d, (size_t)(h.crows ? h.crows : 1) * h.cw);
+                        carve.take(h.d8, (size_t)(h.crows ? h.crows : 1) * h.cw);
                         // device-side decode of a band's input window (own rows + halo rows, rounded out to whole
                         // block rows) normally borrows the two x buffers as scratch; a band of only a few rows is
                         // smaller than that window, and gets scratch of its own
@@ -1165,6 +1172,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                 carve.take(s->norm, kMaxCh);
                 carve.take(s->tickets, (size_t)s->ntr_local + 1);
                 carve.take(s->dbg_counters, 3);
+                carve.take(s->d_maxabs, kMaxCh);
                 carve.take(s->part_tv, ntiles * 2);
                 carve.take(s->part_prob, (size_t)max_strips * nchannel);
         }
@@ -1199,6 +1207,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         CREATE_TRY(hipMemsetAsync(s->tickets, 0, ((size_t)s->ntr_local + 1) * sizeof(unsigned), s->stream));
         CREATE_TRY(hipMemsetAsync(s->part_prob, 0, (size_t)max_strips * nchannel * sizeof(double), s->stream));
         CREATE_TRY(hipMemsetAsync(s->dbg_counters, 0, 3 * sizeof(unsigned long long), s->stream));
+        CREATE_TRY(hipMemsetAsync(s->d_maxabs, 0, kMaxCh * sizeof(unsigned), s->stream));
         for(unsigned c = 0; c < nchannel; c++) {
                 const j2p_plane &p = planes[c];
                 ChanHost &h = s->ch[c];
@@ -1207,6 +1216,11 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                         // block-major: coefficient row r lives in block row r/8; rows are block aligned
                         const int16_t *src = p.data + (size_t)(h.crow0 - host_row0) * h.cw;
                         CREATE_TRY(hipMemcpyAsync(h.d, src, (size_t)h.crows * h.cw * sizeof(int16_t), hipMemcpyHostToDevice, s->stream));
+                        // ... and once more as bytes, with the largest |d| (decided behind the synchronisation below)
+                        const size_t cells = (size_t)h.crows * h.cw;
+                        const unsigned blocks = (unsigned)((cells / 8 + 255) / 256);
+                        hipLaunchKernelGGL(k_narrow_coefficients, dim3(blocks < 2048 ? (blocks ? blocks : 1) : 2048), dim3(256), 0, s->stream,
+                                           (const int16_t *)h.d, h.d8, cells, s->d_maxabs + c);
                 }
                 if(p.fdata) {
                         const float *src = p.fdata + (size_t)(h.frow0 - host_row0) * h.cw;
@@ -1255,6 +1269,17 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
         }
         // the host arrays (and the stack tables above) may go away as soon as this returns
         CREATE_TRY(hipStreamSynchronize(s->stream));
+        {
+                // one byte per coefficient where the channel's values allow it: the projection then reads d8 (ChanDev::d8)
+                unsigned maxabs[kMaxCh] = {0};
+                CREATE_TRY(hipMemcpy(maxabs, s->d_maxabs, sizeof(maxabs), hipMemcpyDeviceToHost));
+                const char *env = j2p_exp_env("J2P_NARROW_COEFFICIENTS");
+                for(unsigned c = 0; c < nchannel; c++) {
+                        ChanHost &h = s->ch[c];
+                        h.narrow_fits = h.crows != 0 && maxabs[c] <= 127;
+                        h.narrow = h.narrow_fits && !(env && atoi(env) == 0);
+                }
+        }
 #undef CREATE_TRY
         rc = launch_init(s);
         if(rc != J2P_OK) { j2p_solver_destroy(s); return rc; }
@@ -1295,8 +1320,18 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
                 s->nt = value < 0 ? nt_policy(s) : (value > 3 ? 3 : value);
                 break;
         case J2P_OPT_MIXED_PROJECT: s->mixed_project = value != 0; break;
+        case J2P_OPT_NARROW_COEFFICIENTS:
+                for(unsigned c = 0; c < s->nch; c++) { s->ch[c].narrow = value != 0 && s->ch[c].narrow_fits; }
+                break;
         default: return fail(J2P_EINVAL, "unknown option %d", option);
         }
+        return J2P_OK;
+}
+
+int j2p_solver_coefficient_bytes(const j2p_solver *s, unsigned c, unsigned *bytes)
+{
+        if(!s || !bytes || c >= s->nch) { return fail(J2P_EINVAL, "j2p_solver_coefficient_bytes: bad argument"); }
+        *bytes = s->ch[c].narrow ? 1u : 2u;
         return J2P_OK;
 }
 

@@ -173,6 +173,49 @@ def test_reset_and_device_decode(lib, oracle):
     assert bit_equal(second, want[0])
 
 
+@pytest.mark.parametrize("shape", [(264, 200, "420", 10), (520, 136, "444", 50), (136, 72, "411", 30)])
+def test_narrow_coefficients_leave_the_bits_alone(lib, oracle, shape):
+    """Channels whose quantised coefficients all fit [-127, 127] stay resident as one byte each and k_project reads those
+    (J2P_OPT_NARROW_COEFFICIENTS): the same planes as with the int16 form and as the reference's; a channel with one
+    larger coefficient keeps the int16 form, channel by channel; +-127 are still narrow, -128 is not."""
+    import jpeg2png_amd as j
+    W, H, sub, q = shape
+    planes = make_case(W, H, sub, q, seed=21)
+    pw = [0.001, 0.01, 0.0]
+    assert all(np.abs(p.data).max() <= 127 for p in planes)
+    planes[1].data[5] = 127
+    planes[1].data[70] = -127
+    for p in planes:
+        p.fdata = oracle.decode_plane(p)
+    want, _, _ = oracle.ref_compute(planes, 0.3, pw, 9)
+    with j.Solver(planes, 0.3, pw, 9) as s:
+        assert [s.coefficient_bytes(c) for c in range(3)] == [1, 1, 1]
+        s.run(9)
+        narrow = [s.download(c) for c in range(3)]
+        s.reset()
+        s.debug_option(j.J2P_OPT_NARROW_COEFFICIENTS, 0)
+        assert [s.coefficient_bytes(c) for c in range(3)] == [2, 2, 2]
+        s.run(9)
+        wide = [s.download(c) for c in range(3)]
+    for c in range(3):
+        assert bit_equal(narrow[c], want[c]), f"channel {c}, one byte per coefficient"
+        assert bit_equal(wide[c], want[c]), f"channel {c}, int16"
+    # one coefficient out of range: that channel alone keeps the int16 form
+    for value in (128, -128, 1000):
+        big = copy.deepcopy(planes)
+        big[2].data[64 * 3 + 9] = value
+        for p in big:
+            p.fdata = oracle.decode_plane(p)
+        want, _, _ = oracle.ref_compute(big, 0.3, pw, 4)
+        with j.Solver(big, 0.3, pw, 4) as s:
+            assert [s.coefficient_bytes(c) for c in range(3)] == [1, 1, 2], value
+            s.debug_option(j.J2P_OPT_NARROW_COEFFICIENTS, 1)
+            assert [s.coefficient_bytes(c) for c in range(3)] == [1, 1, 2], value      # the option cannot narrow what does not fit
+            s.run(4)
+            for c in range(3):
+                assert bit_equal(s.download(c), want[c]), (value, c)
+
+
 def test_projection_property_full_size(lib, oracle):
     """size-independent property at a larger size: after every projection all DCT coefficients of
     the returned plane lie inside their quantisation interval (SURVEY.md §8c ii), up to the
