@@ -355,6 +355,23 @@ int nt_policy(const j2p_solver *s)
         return 3;
 }
 
+// the bytes of the coefficients the projection actually reads (one or two per coefficient, ChanHost::narrow) in the
+// solver's share of the device's live total, and the policy again
+void account_coefficient_bytes(j2p_solver *s)
+{
+        size_t d_bytes = 0;
+        for(unsigned c = 0; c < s->nch; c++) {
+                const ChanHost &h = s->ch[c];
+                d_bytes += (size_t)(h.crows ? h.crows : 1) * h.cw * (h.narrow ? sizeof(uint8_t) : sizeof(int16_t));
+        }
+        if(d_bytes == s->live_d) { return; }
+        if(s->live_registered) { live_add(s->device, LiveBytes{s->live_ws, s->live_g, s->live_planes, s->live_d}, -1); }
+        s->live_ws = s->live_ws - s->live_d + d_bytes;
+        s->live_d = d_bytes;
+        if(s->live_registered) { live_add(s->device, LiveBytes{s->live_ws, s->live_g, s->live_planes, s->live_d}, +1); }
+        if(!s->nt_forced) { s->nt = nt_policy(s); }
+}
+
 ChanDev chan_dev(const j2p_solver *s, unsigned c)
 {
         const ChanHost &h = s->ch[c];
@@ -1279,6 +1296,7 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                         h.narrow_fits = h.crows != 0 && maxabs[c] <= 127;
                         h.narrow = h.narrow_fits && !(env && atoi(env) == 0);
                 }
+                account_coefficient_bytes(s);
         }
 #undef CREATE_TRY
         rc = launch_init(s);
@@ -1322,6 +1340,7 @@ int j2p_solver_debug_option(j2p_solver *s, int option, int value)
         case J2P_OPT_MIXED_PROJECT: s->mixed_project = value != 0; break;
         case J2P_OPT_NARROW_COEFFICIENTS:
                 for(unsigned c = 0; c < s->nch; c++) { s->ch[c].narrow = value != 0 && s->ch[c].narrow_fits; }
+                account_coefficient_bytes(s);
                 break;
         default: return fail(J2P_EINVAL, "unknown option %d", option);
         }
