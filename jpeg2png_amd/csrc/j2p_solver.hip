@@ -1284,12 +1284,14 @@ int j2p_solver_create(j2p_solver **out, int device, void *stream, unsigned nchan
                         CREATE_TRY(hipGetLastError());
                 }
         }
+        // (the largest |d| per channel comes back on the solver's own stream: a synchronous copy would wait for every
+        // blocking stream of the device)
+        unsigned maxabs[kMaxCh] = {0};
+        CREATE_TRY(hipMemcpyAsync(maxabs, s->d_maxabs, sizeof(maxabs), hipMemcpyDeviceToHost, s->stream));
         // the host arrays (and the stack tables above) may go away as soon as this returns
         CREATE_TRY(hipStreamSynchronize(s->stream));
         {
                 // one byte per coefficient where the channel's values allow it: the projection then reads d8 (ChanDev::d8)
-                unsigned maxabs[kMaxCh] = {0};
-                CREATE_TRY(hipMemcpy(maxabs, s->d_maxabs, sizeof(maxabs), hipMemcpyDeviceToHost));
                 const char *env = j2p_exp_env("J2P_NARROW_COEFFICIENTS");
                 for(unsigned c = 0; c < nchannel; c++) {
                         ChanHost &h = s->ch[c];
