@@ -2685,7 +2685,6 @@ __global__ __launch_bounds__(256) void k_fill_zero(float *p, size_t n)
         for(size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { p[i] = 0.f; }
 }
 
-// decode_coefficients + unbox (jpeg.c:83-92, box.c:5-19): one wavefront per 8 blocks
 // The coefficients of a channel once more as one byte each (d + 128), and the largest |d| met: when that is <= 127 the
 // projection reads the bytes (ChanDev::d8) — the values it computes with are the same floats.  16 bytes in, 8 out per step.
 __global__ __launch_bounds__(256) void k_narrow_coefficients(const int16_t *d, uint8_t *d8, size_t cells, unsigned *maxabs)
@@ -2713,6 +2712,7 @@ __global__ __launch_bounds__(256) void k_narrow_coefficients(const int16_t *d, u
         if((threadIdx.x & 63) == 0 && m) { atomicMax(maxabs, m); }
 }
 
+// decode_coefficients + unbox (jpeg.c:83-92, box.c:5-19): one wavefront per 8 blocks
 __global__ __launch_bounds__(256) void k_decode(const int16_t *d, const float *q, float *out, unsigned cw, unsigned nblocks_y)
 {
         __shared__ __attribute__((aligned(16))) float tp[4 * kTpWave];
